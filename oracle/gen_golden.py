@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON MODULES on CPU.
+
+Build-container only (``/root/reference`` does not exist on the GPU box).  This
+script is ours; it imports the reference read-only through ``sys.path`` and
+copies none of its source.  What it commits is data: inputs (token ids, CSR
+sets, seeds) and the reference's outputs for them.
+
+    cd /root/repo && python oracle/gen_golden.py            # all groups
+    python oracle/gen_golden.py g1 g5                         # selected groups
+
+Harness-side shims -- none touches the reference tree:
+  * stub modules for uninstalled imports (boto3/botocore, torch_geometric, wandb,
+    tensorboardX, ipdb) so ``models/*`` and ``train/*`` import;
+  * run from a scratch cwd with ``vocabs``/``resources`` symlinks and a writable
+    ``tokenizers/`` (``utils/tokenizer.py:35-38,49`` writes there);
+  * ``tokenizer.batch_encode_plus`` no longer exists in transformers 5.x
+    (``dataloader/retriever.py:23,53``) -> bound to ``__call__``.
+Weights come from ``oracle.gpt2_ref.make_state_dict`` (seeded) and are LOADED
+INTO the reference model, so reference and oracle/HIP see identical tensors
+without committing them.
+"""
+import hashlib
+import importlib.machinery
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle import gpt2_ref  # noqa: E402
+
+
+def _install_stubs():
+    import transformers.activations  # noqa: F401  (before the boto3 stub)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+    class _Missing:
+        def __init__(self, *a, **k):
+            raise RuntimeError("stubbed dependency")
+
+    stub("boto3"); stub("botocore"); stub("botocore.config", Config=object)
+    stub("botocore.exceptions", ClientError=Exception)
+    stub("torch_geometric"); stub("torch_geometric.nn", GCNConv=_Missing)
+    stub("torch_geometric.utils", from_networkx=None)
+    stub("wandb"); stub("tensorboardX", SummaryWriter=object); stub("ipdb")
+    sys.path.insert(0, REF)
+
+
+def _scratch_cwd():
+    d = tempfile.mkdtemp(prefix="r4d_gold_")
+    os.symlink(os.path.join(REF, "vocabs"), os.path.join(d, "vocabs"))
+    os.symlink(os.path.join(REF, "resources"), os.path.join(d, "resources"))
+    os.makedirs(os.path.join(d, "tokenizers"))
+    os.chdir(d)
+    return d
+
+
+def _ref_model(flavour, n_layer, n_head, n_embd, vocab, n_positions, sd, output_hidden_states=False):
+    from models import GPT2Config
+    import models.modeling_gpt2 as mg
+    import models.modeling_rag as mr
+    cfg = GPT2Config(vocab_size=vocab, n_positions=n_positions, n_ctx=n_positions, n_embd=n_embd,
+                     n_layer=n_layer, n_head=n_head)
+    cfg.output_hidden_states = output_hidden_states
+    cls = {"gpt2": mg.GPT2LMHeadModel, "rag": mr.GPT2LMHeadModel}[flavour]
+    m = cls(cfg).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("attn.bias") for k in missing), missing   # causal buffers only
+    return m
+
+
+def _save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def _ragged(seqs):
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    flat = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs]) if len(seqs) else np.zeros(0, np.int32)
+    return flat, off
+
+
+# --------------------------------------------------------------------------- G1
+def g1_tiny_forward():
+    """Tiny model, every layer's residual stream, ln_f output, logits, LM loss."""
+    print("G1 tiny forward")
+    L, H, d, V, P = 2, 2, 64, 40, 32
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=11, random_affine=True)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (3, 17), generator=g)
+    out = {}
+    with torch.no_grad():
+        m = _ref_model("gpt2", L, H, d, V, P, sd, output_hidden_states=True)
+        res = m(ids, labels=ids)                    # (loss, logits, presents, all_hidden)
+        loss, logits, presents, hs = res
+        out["loss"] = loss.numpy()
+        out["logits"] = logits.numpy()
+        out["present0"] = presents[0].numpy()        # [2,B,H,T,hd]
+        for i, h in enumerate(hs[:-1]):
+            out[f"layer{i}"] = h.numpy()             # residual stream entering block i
+        out["hidden"] = hs[-1].numpy()               # ln_f output
+        m2 = _ref_model("rag", L, H, d, V, P, sd)
+        (logits2, _), hidden2 = m2(input_ids=ids)    # retriever flavour returns (outputs, hidden)
+        assert torch.equal(logits2, logits) and torch.equal(hidden2, hs[-1])
+        emb = wte_embeds = m2.transformer.wte(ids)
+        (logits3, _), hidden3 = m2(inputs_embeds=emb)   # generator-style call
+        assert torch.equal(hidden3, hidden2)
+    _save("g1_tiny_forward", ids=ids.numpy(), cfg=np.array([L, H, d, V, P, 11]), **out)
+
+
+# --------------------------------------------------------------------------- G2
+def g2_ops():
+    """Per-op vectors from the reference modules: LayerNorm, Conv1D, gelu_new MLP, _attn."""
+    print("G2 per-op")
+    from models import GPT2Config
+    import models.modeling_gpt2 as mg
+    from models.modeling_utils import Conv1D
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    with torch.no_grad():
+        x = torch.randn(5, 9, 96, generator=g) * 3 + 0.5
+        ln = torch.nn.LayerNorm(96, eps=1e-5)
+        ln.weight.copy_(1 + 0.1 * torch.randn(96, generator=g)); ln.bias.copy_(0.1 * torch.randn(96, generator=g))
+        out.update(ln_x=x.numpy(), ln_w=ln.weight.numpy(), ln_b=ln.bias.numpy(), ln_y=ln(x).numpy())
+        c = Conv1D(80, 96)
+        c.weight.copy_(torch.randn(96, 80, generator=g) * 0.05); c.bias.copy_(torch.randn(80, generator=g) * 0.1)
+        out.update(conv_w=c.weight.numpy(), conv_b=c.bias.numpy(), conv_y=c(x).numpy())
+        gx = torch.linspace(-6, 6, 257)
+        out.update(gelu_x=gx.numpy(), gelu_y=mg.gelu_new(gx).numpy())
+        for hd, T, scale in ((32, 40, 1.0), (64, 33, 1.0), (96, 24, 1.0), (128, 24, 1.0), (256, 20, 1.0), (64, 48, 30.0)):
+            cfg = GPT2Config(vocab_size=8, n_positions=64, n_ctx=64, n_embd=2 * hd, n_layer=1, n_head=2)
+            att = mg.Attention(2 * hd, 64, cfg, scale=True).eval()
+            q = torch.randn(2, 2, T, hd, generator=g) * scale
+            k = torch.randn(2, 2, hd, T, generator=g) * scale
+            v = torch.randn(2, 2, T, hd, generator=g)
+            a = att._attn(q, k, v)[0]
+            tag = f"attn_hd{hd}_T{T}_s{int(scale)}"
+            out.update({tag + "_q": q.numpy(), tag + "_k": k.numpy(), tag + "_v": v.numpy(), tag + "_a": a.numpy()})
+    _save("g2_ops", **out)
+
+
+# --------------------------------------------------------------------------- G3
+def g3_config_shapes():
+    """Config-shape forwards (cfg1 SimpleDyG B8xT128 incl. logits + loss; retriever shapes)."""
+    print("G3 config shapes")
+    shapes = {  # name: flavour, L, H, d, V, B, T, seed
+        "cfg1_simpledyg": ("gpt2", 6, 8, 768, 1800, 8, 128, 101),
+        "cfg2_uci": ("rag", 4, 2, 512, 1801, 32, 128, 102),
+        "cfg4_wikiv2": ("rag", 2, 6, 768, 8814, 32, 96, 104),
+        "hepth": ("rag", 12, 2, 256, 4756, 16, 80, 103),
+    }
+    for name, (fl, L, H, d, V, B, T, seed) in shapes.items():
+        sd = gpt2_ref.make_state_dict(L, d, V, seed=seed, random_affine=True)
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, V, (B, T), generator=g)
+        m = _ref_model(fl, L, H, d, V, 1024, sd)
+        with torch.no_grad():
+            if fl == "gpt2":
+                loss, logits, _ = m(ids, labels=ids)
+                hidden = m.transformer(ids)[0]
+                extra = dict(loss=loss.numpy(), logits_rows=logits[:, [0, T // 2, T - 1], :].numpy())
+            else:
+                (logits, _), hidden = m(input_ids=ids)
+                extra = dict(logits_rows=logits[:, [0, T - 1], :256].numpy())
+        rows = [0, 1, T // 2, T - 1]
+        _save("g3_" + name, cfg=np.array([L, H, d, V, B, T, seed]), ids=ids.numpy(),
+              hidden_rows=hidden[:, rows, :].numpy(), rows=np.array(rows),
+              meanpool=hidden.mean(dim=1).numpy(),
+              hidden_abs_sum=np.array(hidden.double().abs().sum().item()), **extra)
+
+
+# --------------------------------------------------------------------------- G4/G6
+def _ref_tokenizer(dataset, timestamp):
+    """Tokenizer built by the reference's own ``utils/tokenizer.get_model_tokenizer`` (tiny model)."""
+    from models import GPT2Config
+    import models.modeling_rag as mr
+    from transformers import PreTrainedTokenizerFast
+    from utils.tokenizer import get_model_tokenizer
+    assert dataset != "hepth"      # hepth branch needs .cuda() (utils/tokenizer.py:56-66); not used here
+    args = types.SimpleNamespace(model_type="gpt2", config_name=None, model_name_or_path=None, cache_dir=None,
+                                 n_head=2, n_layer=1, n_embed=16, eta=0.0, gamma=0.0, beta=0.0,
+                                 timestamp=str(timestamp), dataset=dataset, device="cpu", node_feat_file=None)
+    classes = {"gpt2": (GPT2Config, mr.GPT2LMHeadModel, PreTrainedTokenizerFast)}
+    _, tok, _, _ = get_model_tokenizer(args, classes)
+    if not hasattr(tok, "batch_encode_plus"):
+        type(tok).batch_encode_plus = lambda self, lines, **kw: self(lines, **kw)
+    return tok
+
+
+def g4_g6_uci_retrieval():
+    """UCI_13/12 through the reference tokenizer + datasets + model: ids, embeddings, scores, ranks."""
+    print("G4/G6 UCI_13 retrieval")
+    import dataloader.retriever as dr
+    tok = _ref_tokenizer("UCI_13", 12)
+    base = "resources/UCI_13/12/"
+    args = types.SimpleNamespace()
+    pool_ds = dr.LineByLineTextDatasetHistory(tok, args, base + "train.link_prediction", block_size=512)
+    test_ds = dr.LineByLineTextDataset(tok, args, base + "test.link_prediction", block_size=512)
+    val_ds = dr.LineByLineTextDataset(tok, args, base + "val.link_prediction", block_size=512)
+    full_ds = dr.LineByLineTextDataset(tok, args, base + "train.link_prediction", block_size=512)
+    # truncation case: 600-token line keeps the LAST 512
+    long_line = "<|endoftext|> <|history|> 3 " + " ".join(str(i % 1700) for i in range(596)) + " <|endofhistory|>"
+    trunc = tok.batch_encode_plus([long_line], add_special_tokens=True, max_length=512, truncation="longest_first")["input_ids"][0]
+    special = {t: tok.convert_tokens_to_ids(t) for t in
+               ["<|endoftext|>", "<|history|>", "<|endofhistory|>", "<|pre|>", "<|endofpre|>", "<|time0|>", "<|time12|>", "[PAD]", "[MASK]"]}
+    pf, po = _ragged(pool_ds.examples); tf, to = _ragged(test_ds.examples); vf, vo = _ragged(val_ds.examples)
+    ff, fo = _ragged(full_ds.examples[:40])
+    _save("g6_uci_tokens", pool_flat=pf, pool_off=po, test_flat=tf, test_off=to, val_flat=vf, val_off=vo,
+          full_flat=ff, full_off=fo, trunc_ids=np.asarray(trunc, np.int32),
+          special_names=np.array(list(special.keys())), special_ids=np.array(list(special.values())),
+          len_tok=np.array(len(tok)), vocab_size=np.array(tok.vocab_size), pad_id=np.array(tok.pad_token_id))
+
+    L, H, d, V = 4, 2, 512, len(tok)
+    assert V == 1801
+    sd = gpt2_ref.make_state_dict(L, d, V, seed=2026, random_affine=True)
+    m = _ref_model("rag", L, H, d, V, 1024, sd)
+
+    def batches(examples):          # restates dataloader/retriever.py:153-166 around the reference model
+        for s in range(0, len(examples), 32):
+            ch = [torch.tensor(e, dtype=torch.long) for e in examples[s:s + 32]]
+            yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=tok.pad_token_id)
+
+    with torch.no_grad():
+        pool = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool_ds.examples)], dim=0)
+        q = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(test_ds.examples)], dim=0)
+        qn = q / q.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
+        pn = pool / pool.norm(dim=1, keepdim=True)
+        S = (torch.matmul(qn, pn.t()) + 1) / 2
+    S = S.numpy()
+    top10 = np.argsort(-S, axis=1, kind="stable")[:, :10]
+    _save("g4_uci_retrieval", seed=np.array(2026), pool_emb_head=pool[:64].numpy(), pool_emb_tail=pool[-52:].numpy(),
+          pool_emb_norms=pool.norm(dim=1).numpy(), pool_emb_colsum=pool.double().sum(0).numpy(),
+          query_emb=q.numpy(), scores=S, top10_stable=top10.astype(np.int32))
+
+
+# --------------------------------------------------------------------------- G5
+def g5_jaccard():
+    """Jaccard matrices from the reference's own functions on UCI_13/12 and hepth/11."""
+    print("G5 jaccard")
+    import retrieval_data_annotation as rda
+    for ds, ts in (("UCI_13", "12"), ("hepth", "11")):
+        base = f"resources/{ds}/{ts}/"
+
+        def rd(n):
+            with open(base + n) as f:
+                return [l for l in f.read().splitlines() if (len(l) > 0 and not l.isspace())]
+        train, test, test_gt, val, val_gt = (rd(n) for n in ("train.link_prediction", "test.link_prediction",
+                                                             "test_gt.link_prediction", "val.link_prediction",
+                                                             "val_gt.link_prediction"))
+        tr_in, tr_out = rda.get_inout_list(train, train)
+        te_in, te_out = rda.get_inout_list(test, test_gt)
+        va_in, va_out = rda.get_inout_list(val, val_gt)
+        m_test = rda.occurrence_matrix(te_out, tr_out)
+        m_val = rda.occurrence_matrix(va_out, tr_out)
+        m_out = rda.occurrence_matrix(tr_out, tr_out)
+        m_in = rda.occurrence_matrix(tr_in, tr_in)
+        np.fill_diagonal(m_out, 0); np.fill_diagonal(m_in, 0)      # :172-173
+        # reference train annotation (threshold 0.8, README); RNG column is not pinned
+        rda.dataset = ds
+        np.random.seed(0)
+        rda.save_train_annotation(m_out, m_in, "ann_idx.txt", "ann_score.txt", threshold=0.8, neg_num=5)
+        ann = np.loadtxt("ann_idx.txt", dtype=np.int64).reshape(-1, 3)
+        from oracle.jaccard_ref import sets_to_csr          # inputs as data: CSR of the reference's token lists
+        vocab = {}
+        csr = {}
+        for nm, seqs in (("tr_out", tr_out), ("tr_in", tr_in), ("te_out", te_out), ("va_out", va_out)):
+            ip, ix, vocab = sets_to_csr(seqs, vocab)
+            csr[nm + "_ptr"], csr[nm + "_idx"] = ip, ix
+        csr["vocab_tokens"] = np.array(sorted(vocab, key=vocab.get))
+        csr["tr_out_listlen"] = np.array([len(s) for s in tr_out], np.int32)
+        rows = np.arange(0, m_out.shape[0], 97)
+        sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+        _save(f"g5_jaccard_{ds}", m_test=m_test, m_val=m_val,
+              out_sha256=sha(m_out), in_sha256=sha(m_in), sample_rows=rows,
+              out_rows=m_out[rows], in_rows=m_in[rows],
+              out_top10=np.argsort(-m_out, axis=1, kind="stable")[:, :10].astype(np.int32),
+              out_top10_val=np.take_along_axis(m_out, np.argsort(-m_out, axis=1, kind="stable")[:, :10], axis=1),
+              out_rowsum=m_out.sum(1), in_rowsum=m_in.sum(1), ann_triples=ann,
+              n=np.array([len(train), len(test), len(val)]), **csr)
+
+
+def main():
+    groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard}
+    want = [a for a in sys.argv[1:] if a in groups] or list(groups)
+    torch.set_num_threads(os.cpu_count() or 1)
+    _install_stubs()
+    _scratch_cwd()
+    for k in want:
+        groups[k]()
+
+
+if __name__ == "__main__":
+    main()

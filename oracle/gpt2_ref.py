@@ -1,0 +1,162 @@
+"""torch-CPU fp32 restatement of the SimpleDyG GPT-2 forward (oracle; test infra only).
+
+Functional style over a reference-layout ``state_dict`` (keys as written by
+``models/modeling_utils.py:277-297`` ``save_pretrained``):
+
+    transformer.wte.weight [V,d]      transformer.wpe.weight [n_positions,d]
+    transformer.h.<i>.ln_1.{weight,bias} [d]
+    transformer.h.<i>.attn.c_attn.{weight [d,3d], bias [3d]}
+    transformer.h.<i>.attn.c_proj.{weight [d,d],  bias [d]}
+    transformer.h.<i>.ln_2.{weight,bias} [d]
+    transformer.h.<i>.mlp.c_fc.{weight [d,4d],  bias [4d]}
+    transformer.h.<i>.mlp.c_proj.{weight [4d,d], bias [d]}
+    transformer.ln_f.{weight,bias} [d]       lm_head.weight (tied alias of wte)
+
+Dropout is the identity (``model.eval()``, ``train/train_retriever.py:400``).
+"""
+import math
+
+import torch
+
+
+def conv1d(x, weight, bias):
+    """``Conv1D.forward`` -- ``models/modeling_utils.py:1267-1271``.
+
+    ``addmm(bias, x[BT,nx], W[nx,nf])``: weight is stored [in,out].
+    """
+    size_out = x.shape[:-1] + (weight.shape[1],)
+    y = torch.addmm(bias, x.reshape(-1, x.shape[-1]), weight)
+    return y.view(size_out)
+
+
+def gelu_new(x):
+    """``gelu_new`` -- ``models/modeling_gpt2.py:25,206`` (tanh form from
+    ``transformers.activations``): 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """``nn.LayerNorm(nx, eps=config.layer_norm_epsilon)`` --
+    ``models/modeling_gpt2.py:219,221,339``; eps 1e-5 ``configuration_gpt2.py:131``."""
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def attn_core(q, k, v):
+    """``Attention._attn`` -- ``models/modeling_gpt2.py:140-160`` with ``scale=True`` (:338).
+
+    q [B,H,T,hd], k [B,H,hd,T], v [B,H,T,hd].  The mask is the reference's
+    multiplicative/additive form ``w*b - 1e4*(1-b)`` (:146) -- masked logits are
+    exactly -10000, NOT -inf -- followed by a softmax over all T keys (:152).
+    """
+    w = torch.matmul(q, k)
+    w = w / math.sqrt(v.size(-1))
+    nd, ns = w.size(-2), w.size(-1)
+    b = torch.tril(torch.ones(ns, ns, dtype=w.dtype))[ns - nd:ns, :ns].view(1, 1, nd, ns)
+    w = w * b - 1e4 * (1 - b)
+    w = torch.softmax(w, dim=-1)
+    return torch.matmul(w, v)
+
+
+def attention(x, sd, prefix, n_head):
+    """``Attention.forward`` -- ``models/modeling_gpt2.py:177-197`` (no past, no masks)."""
+    B, T, d = x.shape
+    hd = d // n_head
+    qkv = conv1d(x, sd[prefix + "c_attn.weight"], sd[prefix + "c_attn.bias"])
+    q, k, v = qkv.split(d, dim=2)
+    q = q.view(B, T, n_head, hd).permute(0, 2, 1, 3)      # split_heads :166-172
+    k = k.view(B, T, n_head, hd).permute(0, 2, 3, 1)      # k=True -> [B,H,hd,T]
+    v = v.view(B, T, n_head, hd).permute(0, 2, 1, 3)
+    a = attn_core(q, k, v)
+    a = a.permute(0, 2, 1, 3).contiguous().view(B, T, d)  # merge_heads :161-164
+    return conv1d(a, sd[prefix + "c_proj.weight"], sd[prefix + "c_proj.bias"])
+
+
+def mlp(x, sd, prefix):
+    """``MLP.forward`` -- ``models/modeling_gpt2.py:209-212``."""
+    h = gelu_new(conv1d(x, sd[prefix + "c_fc.weight"], sd[prefix + "c_fc.bias"]))
+    return conv1d(h, sd[prefix + "c_proj.weight"], sd[prefix + "c_proj.bias"])
+
+
+def block(x, sd, i, n_head, eps):
+    """``Block.forward`` -- ``models/modeling_gpt2.py:224-235`` (pre-LN residual)."""
+    p = f"transformer.h.{i}."
+    a = attention(layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps), sd, p + "attn.", n_head)
+    x = x + a
+    m = mlp(layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps), sd, p + "mlp.")
+    return x + m
+
+
+def n_layers_of(sd):
+    n = 0
+    while f"transformer.h.{n}.ln_1.weight" in sd:
+        n += 1
+    return n
+
+
+@torch.no_grad()
+def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logits=True, want_layers=False):
+    """``GPT2Model.forward`` + ``GPT2LMHeadModel.forward`` --
+    ``models/modeling_gpt2.py:400-509,583-603`` (== ``models/modeling_rag.py:455-564,664-687``).
+
+    position ids are always 0..T-1 (:420-423); no token types; lm_head is the
+    tied ``wte`` (``modeling_utils.py:165-181``).  Returns a dict with
+    ``hidden`` = ln_f output [B,T,d], optional ``logits`` [B,T,V] and the
+    per-layer residual stream ``layers`` (embedding output first).
+    """
+    wte = sd["transformer.wte.weight"]
+    wpe = sd["transformer.wpe.weight"]
+    if inputs_embeds is None:
+        inputs_embeds = wte[input_ids]
+    T = inputs_embeds.shape[1]
+    x = inputs_embeds + wpe[torch.arange(T)].unsqueeze(0)
+    layers = [x]
+    for i in range(n_layers_of(sd)):
+        x = block(x, sd, i, n_head, eps)
+        layers.append(x)
+    h = layer_norm(x, sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"], eps)
+    out = {"hidden": h}
+    if want_logits:
+        out["logits"] = torch.matmul(h, wte.t())
+    if want_layers:
+        out["layers"] = layers
+    return out
+
+
+def lm_loss(logits, labels):
+    """Shifted cross entropy -- ``models/modeling_gpt2.py:604-615``."""
+    shift_logits = logits[..., :-1, :].contiguous()
+    shift_labels = labels[..., 1:].contiguous()
+    return torch.nn.functional.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.view(-1))
+
+
+def make_state_dict(n_layer, n_embd, vocab, n_positions=1024, seed=1234, std=0.02, random_affine=False):
+    """Deterministic reference-layout weights for tests and benches.
+
+    The reference initialises Linear/Embedding/Conv1D ~ N(0, 0.02), zero biases,
+    LayerNorm weight 1 / bias 0 (``models/modeling_gpt2.py:251-262``).  The RNG
+    draw ORDER of the reference constructor is not reproduced; instead the
+    golden generator loads exactly these tensors into the reference model
+    (``load_state_dict``), so both sides see identical weights.  With
+    ``random_affine`` biases / LN affine are randomised too so that parity tests
+    exercise them (a trained checkpoint has non-trivial values there).
+    """
+    g = torch.Generator().manual_seed(seed)
+
+    def nrm(*shape, s=std):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * s
+
+    d = n_embd
+    sd = {"transformer.wte.weight": nrm(vocab, d), "transformer.wpe.weight": nrm(n_positions, d)}
+    for i in range(n_layer):
+        p = f"transformer.h.{i}."
+        for ln in ("ln_1", "ln_2"):
+            sd[p + ln + ".weight"] = 1.0 + nrm(d, s=0.1) if random_affine else torch.ones(d)
+            sd[p + ln + ".bias"] = nrm(d, s=0.1) if random_affine else torch.zeros(d)
+        for name, (nx, nf) in (("attn.c_attn", (d, 3 * d)), ("attn.c_proj", (d, d)),
+                               ("mlp.c_fc", (d, 4 * d)), ("mlp.c_proj", (4 * d, d))):
+            sd[p + name + ".weight"] = nrm(nx, nf)
+            sd[p + name + ".bias"] = nrm(nf, s=0.05) if random_affine else torch.zeros(nf)
+    sd["transformer.ln_f.weight"] = 1.0 + nrm(d, s=0.1) if random_affine else torch.ones(d)
+    sd["transformer.ln_f.bias"] = nrm(d, s=0.1) if random_affine else torch.zeros(d)
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    return sd
