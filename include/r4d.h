@@ -1,0 +1,156 @@
+/*
+ * r4d.h -- C ABI of librag4dyg_hip.so: the MI355X (gfx950) encode-and-retrieve hot path of RAG4DyG.
+ *
+ * The reference (YuxiaWu/RAG4DyG) is 100 % Python and has no FFI/plugin layer;
+ * each entry point below cites the reference Python call surface it replaces.  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types;
+ *   - every pointer named *_d / documented "device" is a caller-owned HBM pointer (e.g. torch
+ *     tensor.data_ptr()); the library never allocates device memory: scratch comes from an explicit
+ *     caller-provided workspace whose size is returned by the matching *_workspace_bytes query;
+ *   - kernels are enqueued on the caller's stream (a hipStream_t passed as void*; NULL = default
+ *     stream) and the call returns without synchronising (graph-capturable);
+ *   - return value: 0 = R4D_OK, negative = error; the message is available from r4d_last_error()
+ *     (thread-local).  No exceptions cross the ABI;
+ *   - all floating-point data is fp32 (the reference computes in fp32), Jaccard ratios are f64
+ *     (python floats), indices are int32 / int64 as stated.
+ */
+#ifndef R4D_H
+#define R4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R4D_OK 0
+#define R4D_ERR_INVALID (-1)      /* bad argument / unsupported shape */
+#define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
+#define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
+
+#define R4D_ABI_VERSION 1
+
+/* ABI version of the loaded library. */
+int r4d_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* r4d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GPT-2 encoder (SimpleDyG backbone).
+ * Replaces GPT2Model.forward  models/modeling_gpt2.py:357-509 (== models/modeling_rag.py:412-564)
+ * and its callees Block :224-235, Attention :140-197, MLP :209-212, Conv1D modeling_utils.py:1267-1271,
+ * plus the retriever's mean-pool  train/train_retriever.py:419-420,430-432.
+ * Weight pointers use the reference checkpoint layout (Conv1D weights are [in,out]).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct r4d_gpt2_config {
+    int32_t n_layer;
+    int32_t n_head;
+    int32_t n_embd;        /* d; d % 64 == 0, (d / n_head) % 16 == 0 */
+    int32_t vocab;         /* rows of wte (len(tokenizer) after resize_token_embeddings) */
+    int32_t n_positions;   /* rows of wpe (1024) */
+    float   ln_eps;        /* layer_norm_epsilon (1e-5) */
+} r4d_gpt2_config;
+
+typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer.h.<i> */
+    const float* ln_1_w;      const float* ln_1_b;        /* [d] */
+    const float* c_attn_w;    const float* c_attn_b;      /* [d,3d], [3d] */
+    const float* attn_proj_w; const float* attn_proj_b;   /* [d,d],  [d]  */
+    const float* ln_2_w;      const float* ln_2_b;        /* [d] */
+    const float* c_fc_w;      const float* c_fc_b;        /* [d,4d], [4d] */
+    const float* mlp_proj_w;  const float* mlp_proj_b;    /* [4d,d], [d]  */
+} r4d_gpt2_layer;
+
+typedef struct r4d_gpt2_weights {
+    const float* wte;                /* device [vocab,d]  transformer.wte.weight (== lm_head.weight) */
+    const float* wpe;                /* device [n_positions,d] */
+    const float* ln_f_w;             /* device [d] */
+    const float* ln_f_b;
+    const r4d_gpt2_layer* layers;    /* HOST array [n_layer] of device-pointer structs */
+} r4d_gpt2_weights;
+
+/* Scratch bytes r4d_gpt2_encode_f32 needs for a [B,T] batch. */
+size_t r4d_gpt2_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B, int32_t T);
+
+/*
+ * One encoder forward over a right-padded batch.
+ *   ids_d           device int64 [B,T] token ids, or NULL when inputs_embeds_d is given
+ *   inputs_embeds_d device f32 [B,T,d] (generator-style call, modeling_rag.py:460-461,517-524) or NULL
+ *   out_hidden_d    device f32 [B,T,d]  ln_f output ("hidden_states"), or NULL
+ *   out_meanpool_d  device f32 [B,d]    mean over ALL T padded positions (train_retriever.py:420), or NULL
+ *   out_layers_d    device f32 [n_layer,B,T,d] residual stream ENTERING each block (debug/parity), or NULL
+ *   out_qkv_d       device f32 [n_layer,B,T,3d] c_attn outputs ("presents" source, modeling_gpt2.py:187), or NULL
+ * Position ids are 0..T-1 (modeling_gpt2.py:420-423); dropout is the identity (eval).
+ */
+int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w,
+                        const int64_t* ids_d, const float* inputs_embeds_d, int32_t B, int32_t T,
+                        float* out_hidden_d, float* out_meanpool_d, float* out_layers_d, float* out_qkv_d,
+                        void* workspace_d, size_t workspace_bytes, void* stream);
+
+/* lm_logits = hidden @ wte^T  (tied lm_head, modeling_gpt2.py:585; modeling_rag.py:675).
+ * hidden_d [M,d], wte_d [V,d] -> logits_d [M,V]. */
+int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d,
+                      float* logits_d, void* stream);
+
+/* --- single ops, exported for per-op parity tests (same kernels the encoder launches) --- */
+/* y = LayerNorm(x) over the last dim.  nn.LayerNorm, modeling_gpt2.py:219,221,339. */
+int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int32_t rows, int32_t d,
+                      float eps, float* y_d, void* stream);
+/* y = epilogue(x[M,K] @ W[K,N] + bias[N]); epilogue: 0 none, 1 gelu_new (modeling_gpt2.py:206),
+ * 2 add residual_d[M,N].  Conv1D.forward, modeling_utils.py:1267-1271. */
+int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* bias_d, const float* residual_d,
+                   int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
+/* Causal multi-head attention on packed c_attn output qkv_d [B,T,3d] -> a_d [B,T,d] (heads merged).
+ * Attention._attn + split/merge_heads, modeling_gpt2.py:140-175; scale = division by sqrt(hd) (:143).
+ * scores_ws_d: device scratch of r4d_attention_workspace_bytes(B,H,T). */
+size_t r4d_attention_workspace_bytes(int32_t B, int32_t n_head, int32_t T);
+int r4d_attention_f32(const float* qkv_d, int32_t B, int32_t T, int32_t n_head, int32_t d,
+                      float* a_d, void* scores_ws_d, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Retrieval scoring.  Replaces train/train_retriever.py:433-438 (normalise, dot, (x+1)/2) and the
+ * ranking of save_index_score :357-358 / the hit loop :461-467.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[i,:] = x[i,:] / ||x[i,:]||_2 (no eps, train_retriever.py:433,436). */
+int r4d_normalize_rows_f32(const float* x_d, int32_t n, int32_t d, float* out_d, void* stream);
+
+size_t r4d_score_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k);
+/*
+ * S = (q_hat @ pool_hat^T + 1) / 2 over one pool shard, then per-row top-k with the canonical order
+ * (score descending, pool index ascending).
+ *   q_hat_d [Q,d], pool_hat_d [N,d] row-normalised;  index_offset = global index of shard row 0
+ *   out_val_d f32 [Q,k], out_idx_d int64 [Q,k] (global indices)        (k <= 64, k <= N)
+ *   out_scores_d f32 [Q,N] full score rows (file-compat mode) or NULL
+ */
+int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q, int32_t N, int32_t d,
+                       int32_t k, int64_t index_offset, float* out_val_d, int64_t* out_idx_d,
+                       float* out_scores_d, void* workspace_d, size_t workspace_bytes, void* stream);
+/* Merge G per-shard candidate lists (after the RCCL all-gather): vals_d [G,Q,k], idx_d [G,Q,k]
+ * -> out [Q,k], same canonical order; result == single-GPU top-k by construction. */
+int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k,
+                       float* out_val_d, int64_t* out_idx_d, void* stream);
+/* Full-row ranking (file-compat mode): perm_d int32 [rows,n] = stable argsort of -scores (ties by
+ * ascending index) == np.argsort(-S, axis=1, kind='stable').  n <= 65536. */
+int r4d_argsort_desc_f32(const float* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream);
+int r4d_argsort_desc_f64(const double* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Jaccard pool annotation.  Replaces occurrence_matrix / co_occurrence_ratio,
+ * retrieval_data_annotation.py:36-41 / :5-15, and np.fill_diagonal :172-173.
+ * Sets are CSR: ptr int32 [n+1], idx int32 sorted-unique token ids in [0,vocab).
+ * ---------------------------------------------------------------------------------------------- */
+/* out_d f64 [na,nb] row-major: |A_i & B_j| / |A_i | B_j|, 0.0 when either set is empty;
+ * zero_diag != 0 additionally writes 0.0 at i == j. */
+int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na,
+                    const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb,
+                    int32_t vocab, int32_t zero_diag, double* out_d, void* stream);
+/* Per-row top-k (value descending, index ascending) of an f64 matrix: save_score_file_train,
+ * retrieval_data_annotation.py:97-103 (topk=10).  ws from r4d_topk_f64_workspace_bytes. */
+size_t r4d_topk_f64_workspace_bytes(int32_t rows, int32_t n, int32_t k);
+int r4d_topk_f64(const double* m_d, int32_t rows, int32_t n, int32_t k, double* out_val_d,
+                 int32_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R4D_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of librag4dyg_hip.so (the C ABI declared in include/r4d.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "librag4dyg_hip.so")
+
+R4D_ABI_VERSION = 1
+
+
+class R4DError(RuntimeError):
+    pass
+
+
+class GPT2ConfigC(Structure):
+    _fields_ = [("n_layer", c_int32), ("n_head", c_int32), ("n_embd", c_int32), ("vocab", c_int32),
+                ("n_positions", c_int32), ("ln_eps", c_float)]
+
+
+class GPT2LayerC(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_1_w", "ln_1_b", "c_attn_w", "c_attn_b", "attn_proj_w", "attn_proj_b",
+                                         "ln_2_w", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b")]
+
+
+class GPT2WeightsC(Structure):
+    _fields_ = [("wte", c_void_p), ("wpe", c_void_p), ("ln_f_w", c_void_p), ("ln_f_b", c_void_p),
+                ("layers", POINTER(GPT2LayerC))]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); one entry per symbol declared in include/r4d.h
+PROTOTYPES = {
+    "r4d_abi_version": (c_int32, []),
+    "r4d_last_error": (c_char_p, []),
+    "r4d_gpt2_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, c_int32]),
+    "r4d_gpt2_encode_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), _P, _P, c_int32, c_int32,
+                                      _P, _P, _P, _P, _P, c_size_t, _P]),
+    "r4d_lm_logits_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_layernorm_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),
+    "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_attention_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "r4d_attention_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "r4d_normalize_rows_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "r4d_score_topk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "r4d_score_topk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P,
+                                     c_size_t, _P]),
+    "r4d_merge_topk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "r4d_argsort_desc_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "r4d_argsort_desc_f64": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "r4d_jaccard_f64": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises R4DError when the HIP extension is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise R4DError(f"{LIB_PATH} not found: build it with `python -m rag4dyg_amd.build` "
+                       "(there is no CPU fallback for the product path)")
+    import torch  # noqa: F401  -- torch's bundled libamdhip64 must be the HIP runtime both sides share
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.r4d_abi_version()
+    if got != R4D_ABI_VERSION:
+        raise R4DError(f"ABI mismatch: library {got}, binding {R4D_ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().r4d_last_error().decode("utf-8", "replace")
+        raise R4DError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels behind include/r4d.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/r4d.h"
+
+namespace r4d {
+
+void set_error(const char* fmt, ...);
+
+#define R4D_REQUIRE(cond, ...)                     \
+    do {                                           \
+        if (!(cond)) {                             \
+            r4d::set_error(__VA_ARGS__);           \
+            return R4D_ERR_INVALID;                \
+        }                                          \
+    } while (0)
+
+#define R4D_CHECK_LAUNCH(name)                                                         \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            r4d::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return R4D_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ fp32 MFMA GEMM (gemm_f32.hip)
+enum GemmEpilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_SCALE_DIV = 3, EPI_HALF_PLUS = 4 };
+enum GemmCausal { CAUSAL_NONE = 0, CAUSAL_QK = 1, CAUSAL_PV = 2 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;      // [N] or null
+    const float* resid;     // [M,N] (ldr) or null
+    int M, N, K;            // K = full contraction length (CAUSAL_PV trims it per row tile)
+    int lda, ldb, ldc, ldr;
+    int b_trans;            // 0: B is [K,N] (ldb >= N)   1: B is [N,K] (ldb >= K)
+    int b_rows;             // valid rows of B (guards loads): K for NN, N for NT
+    int nbatch, nb1;        // batch z = z0 * nb1 + z1
+    long long sA0, sA1, sB0, sB1, sC0, sC1;   // element strides per batch index
+    int epilogue; float scale_div;
+    int causal;
+};
+int launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
+
+// ------------------------------------------------------------------ encoder_ops.hip
+int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
+                     hipStream_t s);
+int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const float* wte, const float* wpe,
+                           int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
+                           float* x_out, float* y_out, hipStream_t s);
+int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
+int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
+                        float* hidden_out, float* pool_out, hipStream_t s);
+
+}  // namespace r4d

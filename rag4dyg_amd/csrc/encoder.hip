@@ -1,0 +1,188 @@
+// C-ABI entry points of the GPT-2 encoder: orchestration of the gfx950 kernels, no device allocation,
+// everything enqueued on the caller's stream (graph-capturable).  See include/r4d.h for the contract.
+#include <math.h>
+#include <string.h>
+#include "common.h"
+
+namespace r4d {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int conv1d(const float* x, const float* w, const float* bias, const float* resid, int M, int K, int N,
+                  int epilogue, float* y, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.B = w; g.C = y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = N; g.ldc = N; g.ldr = N;
+    g.b_trans = 0; g.b_rows = K; g.nbatch = 1; g.nb1 = 1;
+    g.epilogue = epilogue; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
+    return launch_gemm_f32(g, s);
+}
+
+static inline int tpad(int T) { return (T + 127) / 128 * 128; }
+
+// Attention._attn + split_heads/merge_heads (modeling_gpt2.py:140-175) as three launches over the packed
+// c_attn output: batched per-head Q.K^T (tiles above the diagonal skipped, logits DIVIDED by sqrt(hd) as
+// in :143), in-place causal softmax, batched P.V (K-loop trimmed to the causal range) writing straight
+// into the merged-head layout.  The B*H*T*T score block (29 MB at the worst UCI_13 batch) stays in
+// the 256 MB Infinity Cache between the launches.
+static int attention(const float* qkv, int B, int T, int H, int d, float* a_out, float* scores, hipStream_t s) {
+    const int hd = d / H, ld = tpad(T);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = qkv; g.B = qkv + d; g.C = scores;
+    g.M = T; g.N = T; g.K = hd; g.lda = 3 * d; g.ldb = 3 * d; g.ldc = ld;
+    g.b_trans = 1; g.b_rows = T; g.nbatch = B * H; g.nb1 = H;
+    g.sA0 = (long long)T * 3 * d; g.sA1 = hd; g.sB0 = g.sA0; g.sB1 = hd;
+    g.sC0 = (long long)H * T * ld; g.sC1 = (long long)T * ld;
+    g.epilogue = EPI_SCALE_DIV; g.scale_div = (float)sqrt((double)hd); g.causal = CAUSAL_QK;
+    int rc = launch_gemm_f32(g, s);
+    if (rc) return rc;
+    rc = launch_causal_softmax(scores, B * H, T, ld, 128, s);
+    if (rc) return rc;
+    memset(&g, 0, sizeof(g));
+    g.A = scores; g.B = qkv + 2 * d; g.C = a_out;
+    g.M = T; g.N = hd; g.K = T; g.lda = ld; g.ldb = 3 * d; g.ldc = d;
+    g.b_trans = 0; g.b_rows = T; g.nbatch = B * H; g.nb1 = H;
+    g.sA0 = (long long)H * T * ld; g.sA1 = (long long)T * ld;
+    g.sB0 = (long long)T * 3 * d; g.sB1 = hd; g.sC0 = (long long)T * d; g.sC1 = hd;
+    g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_PV;
+    return launch_gemm_f32(g, s);
+}
+
+struct Workspace {
+    float *x, *ln, *qkv, *att, *fc, *scores;
+    size_t bytes;
+};
+static Workspace carve(void* base, int B, int T, int H, int d) {
+    const size_t M = (size_t)B * T;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) {
+        float* p = base ? (float*)((char*)base + off) : nullptr;
+        off += align_up(nfloat * sizeof(float), 256);
+        return p;
+    };
+    Workspace w;
+    w.x = take(M * d); w.ln = take(M * d); w.qkv = take(M * 3 * d); w.att = take(M * d); w.fc = take(M * 4 * d);
+    w.scores = take((size_t)B * H * T * tpad(T));
+    w.bytes = off;
+    return w;
+}
+
+static int check_cfg(const r4d_gpt2_config* c) {
+    R4D_REQUIRE(c != nullptr, "gpt2: null config");
+    R4D_REQUIRE(c->n_layer >= 1 && c->n_head >= 1 && c->n_embd >= 64, "gpt2: bad config L=%d H=%d d=%d", c->n_layer,
+                c->n_head, c->n_embd);
+    R4D_REQUIRE(c->n_embd % 64 == 0 && c->n_embd <= 2048, "gpt2: n_embd=%d must be a multiple of 64, <= 2048", c->n_embd);
+    R4D_REQUIRE(c->n_embd % c->n_head == 0 && (c->n_embd / c->n_head) % 16 == 0,
+                "gpt2: head_dim=%d/%d must be a multiple of 16", c->n_embd, c->n_head);
+    return R4D_OK;
+}
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" {
+
+int r4d_abi_version(void) { return R4D_ABI_VERSION; }
+const char* r4d_last_error(void) { return g_err; }
+
+size_t r4d_gpt2_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B, int32_t T) {
+    if (!cfg || B <= 0 || T <= 0) return 0;
+    return carve(nullptr, B, T, cfg->n_head, cfg->n_embd).bytes;
+}
+
+int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                        const float* inputs_embeds_d, int32_t B, int32_t T, float* out_hidden_d,
+                        float* out_meanpool_d, float* out_layers_d, float* out_qkv_d, void* workspace_d,
+                        size_t workspace_bytes, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    R4D_REQUIRE(w && w->wte && w->wpe && w->ln_f_w && w->ln_f_b && w->layers, "gpt2: null weights");
+    R4D_REQUIRE((ids_d != nullptr) != (inputs_embeds_d != nullptr),
+                "gpt2: specify exactly one of input_ids and inputs_embeds");         // modeling_gpt2.py:400-401,409
+    R4D_REQUIRE(B >= 1 && T >= 1, "gpt2: empty batch B=%d T=%d", B, T);
+    R4D_REQUIRE(T <= cfg->n_positions && T <= 1024, "gpt2: T=%d exceeds n_positions=%d", T, cfg->n_positions);
+    R4D_REQUIRE(out_hidden_d || out_meanpool_d, "gpt2: no output requested");
+    const int d = cfg->n_embd, H = cfg->n_head, M = B * T;
+    Workspace ws = carve(workspace_d, B, T, H, d);
+    if (!workspace_d || workspace_bytes < ws.bytes) {
+        set_error("gpt2: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
+        return R4D_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < cfg->n_layer; ++l) {
+        const r4d_gpt2_layer& L = w->layers[l];
+        R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
+                    "gpt2: null weight in layer %d", l);
+        if (l == 0) rc = launch_embed_layernorm(ids_d, inputs_embeds_d, w->wte, w->wpe, cfg->vocab, M, T, d, L.ln_1_w,
+                                                L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s);
+        else rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s);
+        if (rc) return rc;
+        if (out_layers_d &&
+            hipMemcpyAsync(out_layers_d + (size_t)l * M * d, ws.x, (size_t)M * d * sizeof(float),
+                           hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("gpt2: layer copy failed");
+            return R4D_ERR_HIP;
+        }
+        float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
+        if ((rc = attention(qkv, B, T, H, d, ws.att, ws.scores, s))) return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+    }
+    return launch_lnf_meanpool(ws.x, w->ln_f_w, w->ln_f_b, B, T, d, cfg->ln_eps, out_hidden_d, out_meanpool_d, s);
+}
+
+int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d, float* logits_d,
+                      void* stream) {
+    R4D_REQUIRE(hidden_d && wte_d && logits_d, "lm_logits: null pointer");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = hidden_d; g.B = wte_d; g.C = logits_d;
+    g.M = M; g.N = V; g.K = d; g.lda = d; g.ldb = d; g.ldc = V;
+    g.b_trans = 1; g.b_rows = V; g.nbatch = 1; g.nb1 = 1; g.epilogue = EPI_NONE; g.scale_div = 1.f;
+    return launch_gemm_f32(g, (hipStream_t)stream);
+}
+
+int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int32_t rows, int32_t d, float eps,
+                      float* y_d, void* stream) {
+    R4D_REQUIRE(x_d && w_d && b_d && y_d, "layernorm: null pointer");
+    return launch_layernorm(x_d, w_d, b_d, rows, d, eps, y_d, (hipStream_t)stream);
+}
+
+int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* bias_d, const float* residual_d, int32_t M,
+                   int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream) {
+    R4D_REQUIRE(x_d && w_d && y_d, "conv1d: null pointer");
+    R4D_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv1d: epilogue %d not in {0,1,2}", epilogue);
+    R4D_REQUIRE(epilogue != EPI_RESIDUAL || residual_d, "conv1d: residual epilogue needs residual_d");
+    return conv1d(x_d, w_d, bias_d, residual_d, M, K, N, epilogue, y_d, (hipStream_t)stream);
+}
+
+size_t r4d_attention_workspace_bytes(int32_t B, int32_t n_head, int32_t T) {
+    if (B <= 0 || n_head <= 0 || T <= 0) return 0;
+    return align_up((size_t)B * n_head * T * tpad(T) * sizeof(float), 256);
+}
+
+int r4d_attention_f32(const float* qkv_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d,
+                      void* scores_ws_d, size_t ws_bytes, void* stream) {
+    R4D_REQUIRE(qkv_d && a_d && scores_ws_d, "attention: null pointer");
+    R4D_REQUIRE(n_head >= 1 && d % n_head == 0 && (d / n_head) % 16 == 0, "attention: head_dim must be a multiple of 16");
+    R4D_REQUIRE(T >= 1 && T <= 1024, "attention: T=%d out of range", T);
+    if (ws_bytes < r4d_attention_workspace_bytes(B, n_head, T)) {
+        set_error("attention: workspace too small");
+        return R4D_ERR_WORKSPACE;
+    }
+    return attention(qkv_d, B, T, n_head, d, a_d, (float*)scores_ws_d, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+// HBM-bound row kernels of the encoder (gfx950): embedding gather + LayerNorm, LayerNorm, causal
+// softmax, ln_f + mean-pool.  One 64-lane wavefront owns one row; reductions are wavefront shuffles
+// (no LDS, no atomics -> bitwise reproducible run to run).
+#include "common.h"
+
+namespace r4d {
+
+constexpr int MAXV = 32;   // values per lane: d <= 64*32 = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Normalise the row held in v[0..nv) (element c = lane + 64*i), nn.LayerNorm semantics
+// (biased variance, eps inside the sqrt) -- modeling_gpt2.py:219,221,339.
+__device__ __forceinline__ void ln_row(float (&v)[MAXV], int nv, int d, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) if (i < nv) s += v[i];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) if (i < nv) { const float t = v[i] - mean; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = (v[i] - mean) * rstd;
+}
+
+// x_out[m,:] = (ids ? wte[ids[m]] : inputs_embeds[m]) + wpe[m % T]   (modeling_gpt2.py:463-469)
+// y_out[m,:] = LayerNorm(x_out[m,:])                                  (ln_1 of block 0)
+// With EMBED == false: y = LayerNorm(x_in) only.
+template <bool EMBED>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in, const int64_t* __restrict__ ids,
+                                                 const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                 int vocab, int rows, int T, int d, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float eps, float* __restrict__ x_out,
+                                                 float* __restrict__ y_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = d >> 6;
+    float v[MAXV];
+    if (EMBED) {
+        const float* src;
+        bool bad = false;
+        if (ids) {
+            const long long id = ids[row];
+            bad = id < 0 || id >= vocab;                 // out-of-vocabulary id: poison the row, never fault
+            src = wte + (bad ? 0 : id) * (long long)d;
+        } else {
+            src = x_in + (long long)row * d;
+        }
+        const float* pe = wpe + (long long)(row % T) * d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < nv) {
+                const float e = src[lane + 64 * i] + pe[lane + 64 * i];
+                v[i] = bad ? __builtin_nanf("") : e;
+                x_out[(long long)row * d + lane + 64 * i] = v[i];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x_in[(long long)row * d + lane + 64 * i];
+    }
+    ln_row(v, nv, d, eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) y_out[(long long)row * d + lane + 64 * i] = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
+                     hipStream_t s) {
+    R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "layernorm: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    if (rows <= 0) return R4D_OK;
+    hipLaunchKernelGGL((ln_kernel<false>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, 0, rows,
+                       1, d, w, b, eps, nullptr, y);
+    R4D_CHECK_LAUNCH("layernorm");
+    return R4D_OK;
+}
+
+int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const float* wte, const float* wpe,
+                           int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
+                           float* x_out, float* y_out, hipStream_t s) {
+    R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    if (rows <= 0) return R4D_OK;
+    hipLaunchKernelGGL((ln_kernel<true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, inputs_embeds, ids, wte, wpe, vocab,
+                       rows, T, d, w, b, eps, x_out, y_out);
+    R4D_CHECK_LAUNCH("embed_layernorm");
+    return R4D_OK;
+}
+
+// In-place causal softmax of the scaled scores S[z][i][0..i] (z = batch*head), one wavefront per query
+// row.  The reference masks with w*b - 1e4*(1-b) (modeling_gpt2.py:146) and soft-maxes all T keys (:152):
+// masked terms are exp(-1e4 - max) == 0 in fp32 whenever the row max exceeds -9896, so only keys j <= i
+// are read.  Columns i+1 .. roundup(i+1, row_tile)-1 are zero-filled: the P.V GEMM's causal K-loop
+// covers whole row tiles.
+__global__ __launch_bounds__(256) void causal_softmax_kernel(float* __restrict__ S, int nrows_total, int T, int ld,
+                                                             int row_tile) {
+    const int lane = threadIdx.x & 63;
+    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= nrows_total) return;
+    const int i = (int)(gr % T);
+    float* row = S + (gr / T) * (long long)T * ld + (long long)i * ld;
+    const int n = i + 1;
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = lane + 64 * c;
+        v[c] = (j < n) ? row[j] : -INFINITY;
+        m = fmaxf(m, v[c]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        v[c] = (lane + 64 * c < n) ? expf(v[c] - m) : 0.f;
+        s += v[c];
+    }
+    s = wave_sum(s);
+    const int nfill = min(ld, (n + row_tile - 1) / row_tile * row_tile);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = lane + 64 * c;
+        if (j < nfill) row[j] = v[c] / s;
+    }
+}
+
+int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s) {
+    R4D_REQUIRE(T <= 1024, "attention: T=%d exceeds n_positions cap 1024", T);
+    const long long rows = (long long)nbh * T;
+    hipLaunchKernelGGL(causal_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, (int)rows, T, ld,
+                       row_tile);
+    R4D_CHECK_LAUNCH("causal_softmax");
+    return R4D_OK;
+}
+
+// hidden = ln_f(x) (modeling_gpt2.py:493) and/or pool[b,:] = mean over ALL T padded positions of hidden
+// (train_retriever.py:420).  One workgroup per sequence, 8 wavefronts striding over t; per-wave partial
+// sums are combined in a fixed order through LDS (deterministic).
+__global__ __launch_bounds__(512) void lnf_meanpool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int T, int d, float eps,
+                                                           float* __restrict__ hidden_out, float* __restrict__ pool_out) {
+    extern __shared__ float red[];                     // [8][d]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int bidx = blockIdx.x;
+    const int nv = d >> 6;
+    float acc[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc[i] = 0.f;
+    for (int t = wid; t < T; t += 8) {
+        const long long base = ((long long)bidx * T + t) * d;
+        float v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x[base + lane + 64 * i];
+        ln_row(v, nv, d, eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < nv) {
+                const float y = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
+                if (hidden_out) hidden_out[base + lane + 64 * i] = y;
+                acc[i] += y;
+            }
+    }
+    if (!pool_out) return;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) if (i < nv) red[wid * d + lane + 64 * i] = acc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 512) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k * d + c];
+        pool_out[(long long)bidx * d + c] = s / (float)T;
+    }
+}
+
+int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
+                        float* hidden_out, float* pool_out, hipStream_t s) {
+    R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "ln_f: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    if (B <= 0 || T <= 0) return R4D_OK;
+    hipLaunchKernelGGL(lnf_meanpool_kernel, dim3(B), dim3(512), 8 * d * sizeof(float), s, x, w, b, T, d, eps,
+                       hidden_out, pool_out);
+    R4D_CHECK_LAUNCH("lnf_meanpool");
+    return R4D_OK;
+}
+
+}  // namespace r4d

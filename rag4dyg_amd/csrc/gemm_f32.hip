@@ -1,0 +1,184 @@
+// fp32 MFMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] . B + bias), exact-f32 v_mfma_f32_32x32x2_f32.
+//
+// Serves every dense contraction of the encoder: Conv1D (modeling_utils.py:1267-1271) c_attn / c_proj /
+// c_fc / mlp.c_proj with fused bias (+ gelu_new | + residual), the batched per-head Q.K^T / P.V of
+// Attention._attn (modeling_gpt2.py:141,159) with causal tile skipping, and the tied lm_head (B given
+// as [N,K]).  1e-4-relative-fp32 parity rules out bf16 inputs, so this is the f32-in/f32-acc MFMA
+// (157 TFLOP/s peak == the f32 vector peak, but one VGPR per operand and the VALU left free).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 16, wave tile (BM/2) x (BN/2) built from
+// 32x32 MFMA tiles.  LDS images are k-major ([k][m] and [k][n]) so every fragment read is a
+// conflict-free ds_read_b32 over 32 consecutive banks; A (and B when given as [N,K]) is transposed on
+// the LDS write (2-way conflicts on ds_write_b32 are free).  Double-buffered LDS with the next tile's
+// global loads issued before the MFMA phase (one barrier per k-tile).
+#include "common.h"
+
+namespace r4d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+    // 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))  -- modeling_gpt2.py:25,206
+    const float c = 0.7978845608028654f;
+    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+
+template <int BM, int BN, bool BT>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LDA = BM + 4;
+    constexpr int LDB = BT ? BN + 4 : BN;
+    constexpr int NLA = BM * (BK / 4) / NTHREADS;                    // float4 loads per thread, A tile
+    constexpr int NLB = BN * (BK / 4) / NTHREADS;                    // same count for both B layouts
+    static_assert(NLA >= 1 && NLB >= 1, "tile too small");
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.causal == CAUSAL_QK && n0 > m0 + BM - 1) return;           // tile strictly above the diagonal
+
+    const int z0 = blockIdx.z / g.nb1, z1 = blockIdx.z % g.nb1;
+    const float* __restrict__ A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float* __restrict__ B = g.B + z0 * g.sB0 + z1 * g.sB1;
+    float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
+
+    int kend = g.K;
+    if (g.causal == CAUSAL_PV) kend = min(g.K, m0 + BM);             // keys beyond the tile's last row are masked
+    const int nkt = (kend + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    float4 ra[NLA], rb[NLB];
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int r = 0; r < NLA; ++r) {
+            const int idx = tid + r * NTHREADS, row = idx >> 2, c4 = idx & 3;
+            const int gm = m0 + row;
+            ra[r] = (gm < g.M) ? *reinterpret_cast<const float4*>(A + (long long)gm * g.lda + k0 + 4 * c4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < NLB; ++r) {
+            const int idx = tid + r * NTHREADS;
+            if (BT) {
+                const int row = idx >> 2, c4 = idx & 3, gn = n0 + row;
+                rb[r] = (gn < g.b_rows) ? *reinterpret_cast<const float4*>(B + (long long)gn * g.ldb + k0 + 4 * c4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int krow = idx / (BN / 4), c = idx % (BN / 4);
+                const int gk = k0 + krow, gn = n0 + 4 * c;
+                rb[r] = (gk < g.b_rows && gn < g.N)
+                            ? *reinterpret_cast<const float4*>(B + (long long)gk * g.ldb + gn)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < NLA; ++r) {
+            const int idx = tid + r * NTHREADS, row = idx >> 2, c4 = idx & 3;
+            float* p = &As[buf][(4 * c4) * LDA + row];
+            p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;
+        }
+#pragma unroll
+        for (int r = 0; r < NLB; ++r) {
+            const int idx = tid + r * NTHREADS;
+            if (BT) {
+                const int row = idx >> 2, c4 = idx & 3;
+                float* p = &Bs[buf][(4 * c4) * LDB + row];
+                p[0] = rb[r].x; p[LDB] = rb[r].y; p[2 * LDB] = rb[r].z; p[3 * LDB] = rb[r].w;
+            } else {
+                const int krow = idx / (BN / 4), c = idx % (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[buf][krow * LDB + 4 * c]) = rb[r];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);                        // in flight under the MFMA phase
+        const float* as = &As[cur][wm * WM + li];
+        const float* bs = &Bs[cur][wn * WN + li];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lh) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lh) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + li;
+        if (col >= g.N) continue;
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (g.epilogue == EPI_GELU) v = gelu_new_f(v);
+                else if (g.epilogue == EPI_RESIDUAL) v += g.resid[(long long)row * g.ldr + col];
+                else if (g.epilogue == EPI_SCALE_DIV) v = v / g.scale_div;
+                else if (g.epilogue == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+                C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_variant(const GemmArgs& g, hipStream_t stream) {
+    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+    dim3 grid(tiles, 1, g.nbatch);
+    if (g.b_trans) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true>), grid, dim3(NTHREADS), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false>), grid, dim3(NTHREADS), 0, stream, g);
+    R4D_CHECK_LAUNCH("gemm_f32");
+    return R4D_OK;
+}
+
+int launch_gemm_f32(const GemmArgs& g, hipStream_t stream) {
+    R4D_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+    R4D_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 (got %d,%d)", g.lda, g.ldb);
+    R4D_REQUIRE(g.causal == CAUSAL_PV || g.K % BK == 0, "gemm: K=%d must be a multiple of %d", g.K, BK);
+    R4D_REQUIRE(g.b_trans || g.N % 4 == 0, "gemm: N=%d must be a multiple of 4 for row-major B", g.N);
+    R4D_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: A/B must be 16-byte aligned");
+    // Tile choice: big tiles when they still give >= ~2 waves of workgroups over 256 CUs, else 64x64.
+    const long long big = (long long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.nbatch;
+    if (big >= 512 && g.N >= 128) return launch_variant<128, 128>(g, stream);
+    return launch_variant<64, 64>(g, stream);
+}
+
+}  // namespace r4d

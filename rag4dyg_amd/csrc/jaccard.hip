@@ -1,0 +1,130 @@
+// Jaccard pool annotation on gfx950.  Replaces the pure-python double loop occurrence_matrix /
+// co_occurrence_ratio (retrieval_data_annotation.py:36-41, :5-15): out[i,j] = |A_i & B_j| / |A_i | B_j|
+// as an IEEE double (python float), 0.0 when either set is empty, optional zeroed diagonal (:172-173).
+//
+// The pass is HBM-WRITE bound (8 bytes per pair out, a few bytes per SET in), so it is integer/bit work
+// laid out for coalesced 512-byte row segments -- no GEMM reshaping.  One workgroup owns 64 B-sets (one
+// per lane) and a chunk of A rows.  It first builds, in LDS, the transposed incidence table
+//     mask[token] = 64-bit lane mask of the B-sets in this column tile that contain `token`
+// (ds_or_b64 atomics; 8*vocab bytes, <= 152 KB of the 160 KB LDS).  Then each wavefront takes one A row at
+// a time: its tokens are wave-uniform, every token is ONE broadcast LDS read of mask[token], and lane j
+// adds bit j -- the popcount of the intersection accumulates across the wave's 64 pairs at 3 VALU ops per
+// token.  |A|B| = |A| + |B| - |A&B|; the f64 division is correctly rounded == python's int/int.
+#include "common.h"
+
+namespace r4d {
+
+constexpr int JAC_MAX_VOCAB_LDS = 19456;           // 8 B * 19456 = 152 KB
+
+__global__ __launch_bounds__(256) void jaccard_lds_kernel(const int32_t* __restrict__ a_ptr,
+                                                          const int32_t* __restrict__ a_idx, int na,
+                                                          const int32_t* __restrict__ b_ptr,
+                                                          const int32_t* __restrict__ b_idx, int nb, int vocab,
+                                                          int zero_diag, int rows_per_block, double* __restrict__ out) {
+    extern __shared__ unsigned long long mask[];    // [vocab]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col0 = blockIdx.x * 64;
+    for (int t = tid; t < vocab; t += 256) mask[t] = 0ull;
+    __syncthreads();
+    {   // scatter the 64 B-sets of this tile: 4 threads per set
+        const int j = tid >> 2, sub = tid & 3, col = col0 + j;
+        if (col < nb) {
+            const int s = b_ptr[col], e = b_ptr[col + 1];
+            for (int p = s + sub; p < e; p += 4) {
+                const int tok = b_idx[p];
+                if ((unsigned)tok < (unsigned)vocab) atomicOr(&mask[tok], 1ull << j);
+            }
+        }
+    }
+    __syncthreads();
+    const int col = col0 + lane;
+    const int lb = (col < nb) ? (b_ptr[col + 1] - b_ptr[col]) : 0;
+    const int row_begin = blockIdx.y * rows_per_block;
+    const int row_end = min(na, row_begin + rows_per_block);
+    for (int i = row_begin + wid; i < row_end; i += 4) {
+        const int s = a_ptr[i], e = a_ptr[i + 1];      // wave-uniform
+        const int la = e - s;
+        int cnt = 0;
+        for (int p0 = s; p0 < e; p0 += 64) {
+            const int mytok = (p0 + lane < e) ? a_idx[p0 + lane] : -1;     // coalesced: 64 tokens per load
+            const int m = min(64, e - p0);
+            for (int t = 0; t < m; ++t) {
+                const int tok = __builtin_amdgcn_readlane(mytok, t);        // scalar broadcast
+                if ((unsigned)tok < (unsigned)vocab) {
+                    const unsigned long long bits = mask[tok];              // one LDS address: broadcast read
+                    cnt += (int)((bits >> lane) & 1ull);
+                }
+            }
+        }
+        if (col < nb) {
+            double r = 0.0;
+            if (la > 0 && lb > 0) r = (double)cnt / (double)(la + lb - cnt);
+            if (zero_diag && i == col) r = 0.0;
+            out[(long long)i * nb + col] = r;
+        }
+    }
+}
+
+// Fallback for vocabularies whose incidence table does not fit LDS: one thread per pair, sorted-list merge.
+__global__ __launch_bounds__(256) void jaccard_merge_kernel(const int32_t* __restrict__ a_ptr,
+                                                            const int32_t* __restrict__ a_idx, int na,
+                                                            const int32_t* __restrict__ b_ptr,
+                                                            const int32_t* __restrict__ b_idx, int nb, int zero_diag,
+                                                            double* __restrict__ out) {
+    const int col_blocks = (nb + 255) / 256;
+    const int col = (blockIdx.x % col_blocks) * 256 + threadIdx.x, i = blockIdx.x / col_blocks;
+    if (col >= nb) return;
+    int p = a_ptr[i], pe = a_ptr[i + 1], q = b_ptr[col], qe = b_ptr[col + 1];
+    const int la = pe - p, lb = qe - q;
+    int cnt = 0;
+    while (p < pe && q < qe) {
+        const int x = a_idx[p], y = b_idx[q];
+        cnt += (x == y);
+        p += (x <= y);
+        q += (y <= x);
+    }
+    double r = 0.0;
+    if (la > 0 && lb > 0) r = (double)cnt / (double)(la + lb - cnt);
+    if (zero_diag && i == col) r = 0.0;
+    out[(long long)i * nb + col] = r;
+}
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, const int32_t* b_ptr_d,
+                               const int32_t* b_idx_d, int32_t nb, int32_t vocab, int32_t zero_diag, double* out_d,
+                               void* stream) {
+    R4D_REQUIRE(a_ptr_d && b_ptr_d && out_d, "jaccard: null pointer");
+    R4D_REQUIRE(na >= 0 && nb >= 0 && vocab >= 1, "jaccard: bad sizes na=%d nb=%d vocab=%d", na, nb, vocab);
+    if (na == 0 || nb == 0) return R4D_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (vocab <= JAC_MAX_VOCAB_LDS) {
+        const int col_tiles = cdiv(nb, 64);
+        // enough row chunks for >= ~8 workgroups per CU, but >= 64 rows each so the table build amortises
+        int chunks = max(1, min(cdiv(na, 64), cdiv(2048, col_tiles)));
+        const int rows_per_block = cdiv(na, chunks);
+        chunks = cdiv(na, rows_per_block);
+        const size_t lds = (size_t)vocab * sizeof(unsigned long long);
+        if (lds > 64 * 1024) {
+            static bool raised = false;     // opt in to > 64 KB dynamic LDS once
+            if (!raised) {
+                if (hipFuncSetAttribute((const void*)jaccard_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        JAC_MAX_VOCAB_LDS * 8) != hipSuccess) {
+                    set_error("jaccard: cannot raise dynamic LDS limit");
+                    return R4D_ERR_HIP;
+                }
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL(jaccard_lds_kernel, dim3(col_tiles, chunks), dim3(256), lds, s, a_ptr_d, a_idx_d, na,
+                           b_ptr_d, b_idx_d, nb, vocab, zero_diag, rows_per_block, out_d);
+        R4D_CHECK_LAUNCH("jaccard_lds");
+    } else {
+        hipLaunchKernelGGL(jaccard_merge_kernel, dim3((unsigned)((long long)cdiv(nb, 256) * na)), dim3(256), 0, s, a_ptr_d, a_idx_d, na, b_ptr_d,
+                           b_idx_d, nb, zero_diag, out_d);
+        R4D_CHECK_LAUNCH("jaccard_merge");
+    }
+    return R4D_OK;
+}

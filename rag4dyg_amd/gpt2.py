@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's GPT-2 call surface, running on the gfx950 kernels.
+
+Same class names, argument meaning, return structure, error behaviour and state-dict / config.json
+layout as the reference (``models/modeling_gpt2.py``, ``models/modeling_rag.py``,
+``models/modeling_utils.py``, ``models/configuration_gpt2.py``) so that reference checkpoints load
+unchanged and the reference call sites (``train/train_retriever.py:419,430``,
+``main_SimpleDyG.py:168``, ``utils/model.py:161,222``) keep working.  The modules only HOLD parameters;
+``forward`` hands their device pointers to ``r4d_gpt2_encode_f32`` -- inference only (no autograd), GPU
+only (CPU tensors raise: there is no fallback).
+"""
+import ctypes
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class GPT2Config:
+    """``models/configuration_gpt2.py:120-162`` defaults + the keys the reference adds (``utils/tokenizer.py:21-26,51``)."""
+
+    model_type = "gpt2"
+
+    def __init__(self, vocab_size=50257, n_positions=1024, n_ctx=1024, n_embd=768, n_layer=12, n_head=12,
+                 resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.1, layer_norm_epsilon=1e-5, initializer_range=0.02,
+                 **kwargs):
+        self.vocab_size = vocab_size
+        self.n_positions = n_positions
+        self.n_ctx = n_ctx
+        self.n_embd = n_embd
+        self.n_layer = n_layer
+        self.n_head = n_head
+        self.resid_pdrop = resid_pdrop
+        self.embd_pdrop = embd_pdrop
+        self.attn_pdrop = attn_pdrop
+        self.layer_norm_epsilon = layer_norm_epsilon
+        self.initializer_range = initializer_range
+        self.output_past = kwargs.pop("output_past", True)           # configuration_utils.py:60-65
+        self.output_hidden_states = kwargs.pop("output_hidden_states", False)
+        self.output_attentions = kwargs.pop("output_attentions", False)
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def to_dict(self):
+        return dict(self.__dict__, model_type=self.model_type)
+
+    def save_pretrained(self, save_directory):
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+    @classmethod
+    def from_pretrained(cls, path, **kwargs):
+        cfg_file = os.path.join(path, "config.json") if os.path.isdir(path) else path
+        if not os.path.isfile(cfg_file):
+            raise OSError(f"config file not found: {cfg_file} (no network: only local paths are supported)")
+        with open(cfg_file) as f:
+            d = json.load(f)
+        d.pop("model_type", None)
+        d.update(kwargs)
+        return cls(**d)
+
+
+class Conv1D(nn.Module):
+    """Parameter holder with the reference layout: weight [nx, nf] (``modeling_utils.py:1255-1265``)."""
+
+    def __init__(self, nf, nx):
+        super().__init__()
+        self.nf = nf
+        self.weight = nn.Parameter(torch.empty(nx, nf).normal_(std=0.02))
+        self.bias = nn.Parameter(torch.zeros(nf))
+
+    def forward(self, x):
+        return ops.conv1d(x.contiguous(), self.weight, self.bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, nx, n_ctx, config):
+        super().__init__()
+        assert nx % config.n_head == 0                                # modeling_gpt2.py:105
+        # causal buffer kept so that state_dict() has the reference's keys (modeling_gpt2.py:106); unused by the kernels
+        self.register_buffer("bias", torch.tril(torch.ones(n_ctx, n_ctx)).view(1, 1, n_ctx, n_ctx))
+        self.n_head = config.n_head
+        self.c_attn = Conv1D(nx * 3, nx)
+        self.c_proj = Conv1D(nx, nx)
+
+
+class MLP(nn.Module):
+    def __init__(self, n_state, config):
+        super().__init__()
+        self.c_fc = Conv1D(n_state, config.n_embd)
+        self.c_proj = Conv1D(config.n_embd, n_state)
+
+
+class Block(nn.Module):
+    def __init__(self, n_ctx, config):
+        super().__init__()
+        nx = config.n_embd
+        self.ln_1 = nn.LayerNorm(nx, eps=config.layer_norm_epsilon)
+        self.attn = Attention(nx, n_ctx, config)
+        self.ln_2 = nn.LayerNorm(nx, eps=config.layer_norm_epsilon)
+        self.mlp = MLP(4 * nx, config)
+
+
+class _PreTrained(nn.Module):
+    config_class = GPT2Config
+    base_model_prefix = "transformer"
+
+    def _init_weights(self, module):
+        """``modeling_gpt2.py:251-262``."""
+        if isinstance(module, (nn.Linear, nn.Embedding, Conv1D)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+            if isinstance(module, (nn.Linear, Conv1D)) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def save_pretrained(self, save_directory):
+        """``modeling_utils.py:277-297``: config.json + pytorch_model.bin (= torch.save(state_dict))."""
+        assert os.path.isdir(save_directory), "Saving path should be a directory where the model and configuration can be saved"
+        self.config.architectures = [self.__class__.__name__]
+        self.config.save_pretrained(save_directory)
+        torch.save({k: v.cpu() for k, v in self.state_dict().items()}, os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kwargs):
+        """Local-directory subset of ``modeling_utils.py:300-582``: loads ``pytorch_model.bin`` and maps the
+        ``transformer.`` prefix either way (base model <- LM-head checkpoint and vice versa, :530-541)."""
+        if config is None:
+            config = cls.config_class.from_pretrained(path)
+        model = cls(config)
+        f = os.path.join(path, "pytorch_model.bin")
+        if not os.path.isfile(f):
+            raise OSError(f"Error no file named pytorch_model.bin found in directory {path}")
+        sd = torch.load(f, map_location="cpu", weights_only=True)
+        own = model.state_dict()
+        has_prefix_ckpt = any(k.startswith("transformer.") for k in sd)
+        has_prefix_own = any(k.startswith("transformer.") for k in own)
+        if has_prefix_ckpt and not has_prefix_own:
+            sd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+        elif has_prefix_own and not has_prefix_ckpt:
+            sd = {"transformer." + k: v for k, v in sd.items()}
+        sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        model.load_state_dict(sd, strict=False)
+        if hasattr(model, "tie_weights"):
+            model.tie_weights()
+        model.eval()
+        return model
+
+
+class GPT2Model(_PreTrained):
+    """``models/modeling_gpt2.py:328-509``."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.output_hidden_states = config.output_hidden_states
+        self.output_past = config.output_past
+        self.wte = nn.Embedding(config.vocab_size, config.n_embd)
+        self.wpe = nn.Embedding(config.n_positions, config.n_embd)
+        self.h = nn.ModuleList([Block(config.n_ctx, config) for _ in range(config.n_layer)])
+        self.ln_f = nn.LayerNorm(config.n_embd, eps=config.layer_norm_epsilon)
+        self.apply(self._init_weights)
+
+    def get_input_embeddings(self):
+        return self.wte
+
+    def set_input_embeddings(self, new_embeddings):
+        self.wte = new_embeddings
+
+    def resize_token_embeddings(self, new_num_tokens=None):
+        """``modeling_utils.py:183-248``: grow/shrink wte keeping the first min(old,new) rows."""
+        old = self.wte
+        if new_num_tokens is None or new_num_tokens == old.num_embeddings:
+            return old
+        new = nn.Embedding(new_num_tokens, old.embedding_dim).to(old.weight.device)
+        new.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        n = min(old.num_embeddings, new_num_tokens)
+        new.weight.data[:n, :] = old.weight.data[:n, :]
+        self.wte = new
+        self.config.vocab_size = new_num_tokens
+        return new
+
+    # ------------------------------------------------------------------ kernel hand-off
+    def _c_structs(self):
+        cfg = self.config
+        c = _lib.GPT2ConfigC(cfg.n_layer, cfg.n_head, cfg.n_embd, self.wte.num_embeddings, self.wpe.num_embeddings,
+                             cfg.layer_norm_epsilon)
+        layers = (_lib.GPT2LayerC * cfg.n_layer)()
+
+        def p(t):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.R4DError("model weights must be contiguous fp32 tensors on the GPU "
+                                    "(call model.to('cuda'); there is no CPU fallback)")
+            return t.data_ptr()
+        for i, blk in enumerate(self.h):
+            layers[i] = _lib.GPT2LayerC(p(blk.ln_1.weight), p(blk.ln_1.bias), p(blk.attn.c_attn.weight),
+                                        p(blk.attn.c_attn.bias), p(blk.attn.c_proj.weight), p(blk.attn.c_proj.bias),
+                                        p(blk.ln_2.weight), p(blk.ln_2.bias), p(blk.mlp.c_fc.weight),
+                                        p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias))
+        w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers)
+        return c, w, layers
+
+    @torch.no_grad()
+    def encode(self, input_ids=None, inputs_embeds=None, want_hidden=True, want_meanpool=False, want_layers=False,
+               want_qkv=False):
+        """One fused encoder pass.  Returns dict(hidden [B,T,d], meanpool [B,d], layers [L,B,T,d], qkv [L,B,T,3d])."""
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        src = input_ids if input_ids is not None else inputs_embeds
+        if not src.is_cuda:
+            raise _lib.R4DError("rag4dyg_amd runs on the GPU only: move inputs to 'cuda' (no CPU fallback)")
+        dev = src.device
+        d = self.config.n_embd
+        if input_ids is not None:
+            input_ids = input_ids.view(-1, input_ids.shape[-1]).to(torch.int64).contiguous()
+            B, T = input_ids.shape
+        else:
+            inputs_embeds = inputs_embeds.to(torch.float32).contiguous()
+            B, T = inputs_embeds.shape[:2]
+        L = self.config.n_layer
+        lib = _lib.load()
+        c, w, _keep = self._c_structs()
+        ws = ops.workspace(lib.r4d_gpt2_workspace_bytes(ctypes.byref(c), B, T), dev, "gpt2")
+        out = {}
+        hidden = torch.empty(B, T, d, dtype=torch.float32, device=dev) if want_hidden else None
+        pool = torch.empty(B, d, dtype=torch.float32, device=dev) if want_meanpool else None
+        layers = torch.empty(L, B, T, d, dtype=torch.float32, device=dev) if want_layers else None
+        qkv = torch.empty(L, B, T, 3 * d, dtype=torch.float32, device=dev) if want_qkv else None
+
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+        _lib.check(lib.r4d_gpt2_encode_f32(ctypes.byref(c), ctypes.byref(w), ptr(input_ids), ptr(inputs_embeds), B, T,
+                                           ptr(hidden), ptr(pool), ptr(layers), ptr(qkv), ws.data_ptr(), ws.numel(),
+                                           torch.cuda.current_stream().cuda_stream), "gpt2_encode")
+        out.update(hidden=hidden, meanpool=pool, layers=layers, qkv=qkv)
+        return out
+
+    def _presents(self, qkv):
+        """``present = stack(k^T^T, v)`` per layer, [2,B,H,T,hd] (``modeling_gpt2.py:187``), as views of c_attn output."""
+        L, B, T, d3 = qkv.shape
+        d, H = d3 // 3, self.config.n_head
+        k = qkv[..., d:2 * d].view(L, B, T, H, d // H).permute(0, 1, 3, 2, 4)
+        v = qkv[..., 2 * d:].view(L, B, T, H, d // H).permute(0, 1, 3, 2, 4)
+        return tuple(torch.stack((k[i], v[i])) for i in range(L))
+
+    def forward(self, input_ids=None, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None):
+        """Same outputs as ``modeling_gpt2.py:357-509``: (last_hidden_state, presents?, all_hidden_states?)."""
+        for name, val in (("past", past), ("attention_mask", attention_mask), ("token_type_ids", token_type_ids),
+                          ("position_ids", position_ids), ("head_mask", head_mask)):
+            if val is not None:
+                raise NotImplementedError(f"{name} is never passed on the encode-and-retrieve path "
+                                          "(train_retriever.py:419,430; utils/model.py:222) and is not built")
+        r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states,
+                        want_qkv=self.output_past)
+        outputs = (r["hidden"],)
+        if self.output_past:
+            outputs = outputs + (self._presents(r["qkv"]),)
+        if self.output_hidden_states:
+            outputs = outputs + (tuple(r["layers"][i] for i in range(self.config.n_layer)) + (r["hidden"],),)
+        return outputs
+
+
+class _LMHeadBase(_PreTrained):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.transformer = GPT2Model(config)
+        self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
+        self.apply(self._init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        """``modeling_utils.py:155-181``: lm_head.weight is the wte Parameter."""
+        self.lm_head.weight = self.transformer.wte.weight
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def resize_token_embeddings(self, new_num_tokens=None):
+        emb = self.transformer.resize_token_embeddings(new_num_tokens)
+        self.lm_head = nn.Linear(self.config.n_embd, emb.num_embeddings, bias=False).to(emb.weight.device)
+        self.config.vocab_size = emb.num_embeddings
+        self.tie_weights()
+        return emb
+
+    def _lm(self, input_ids, labels, inputs_embeds, **unsupported):
+        tr = self.transformer(input_ids, inputs_embeds=inputs_embeds, **unsupported)
+        hidden = tr[0]
+        lm_logits = ops.lm_logits(hidden, self.transformer.wte.weight)
+        outputs = (lm_logits,) + tr[1:]
+        if labels is not None:                     # shifted CE, modeling_gpt2.py:604-615 (metric only; torch op on device)
+            shift_logits = lm_logits[..., :-1, :].contiguous()
+            shift_labels = labels[..., 1:].contiguous()
+            loss = nn.functional.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.view(-1))
+            outputs = (loss,) + outputs
+        return outputs, hidden
+
+
+class GPT2LMHeadModel(_LMHeadBase):
+    """SimpleDyG flavour, ``models/modeling_gpt2.py:517-617``: returns ``(loss?), lm_logits, presents, ...``."""
+
+    def forward(self, input_ids=None, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, labels=None):
+        outputs, _ = self._lm(input_ids, labels, inputs_embeds, past=past, attention_mask=attention_mask,
+                              token_type_ids=token_type_ids, position_ids=position_ids, head_mask=head_mask)
+        return outputs
+
+
+class GPT2LMHeadModelRAG(_LMHeadBase):
+    """Retriever / generator flavour, ``models/modeling_rag.py:569-687``: returns ``(outputs, hidden_states)``.
+
+    ``encode_meanpool`` is the retrieve-path entry: it skips the lm_head GEMM the retriever computes and throws
+    away (``train_retriever.py:419-420``; 31-48 % of the reference forward).
+    """
+
+    def forward(self, input_ids=None, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, labels=None):
+        return self._lm(input_ids, labels, inputs_embeds, past=past, attention_mask=attention_mask,
+                        token_type_ids=token_type_ids, position_ids=position_ids, head_mask=head_mask)
+
+    @torch.no_grad()
+    def encode_meanpool(self, input_ids):
+        """``_, h = model(input_ids); torch.mean(h, dim=1)`` (``train_retriever.py:419-420``) fused on device."""
+        return self.transformer.encode(input_ids, want_hidden=False, want_meanpool=True)["meanpool"]

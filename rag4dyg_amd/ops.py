@@ -1,0 +1,147 @@
+"""torch-tensor front end of the C ABI: pointer/shape checks, workspace and stream plumbing only.
+
+Every function requires CUDA(HIP) tensors and raises otherwise -- there is no CPU path here.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.R4DError(f"{name}: expected a tensor on the GPU (no CPU fallback in rag4dyg_amd)")
+    if t.dtype != dtype:
+        raise _lib.R4DError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.R4DError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+_WS = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag); the library itself never allocates."""
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def layernorm(x, w, b, eps=1e-5):
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    rows = x.numel() // d
+    check(_lib.load().r4d_layernorm_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
+                                        _dev(b, torch.float32, "b"), rows, d, eps, y.data_ptr(), _stream()), "layernorm")
+    return y
+
+
+def conv1d(x, w, bias, epilogue="none", residual=None):
+    """y = epilogue(x @ W[K,N] + bias); epilogue in {'none','gelu','residual'} (Conv1D, modeling_utils.py:1267-1271)."""
+    K, N = w.shape
+    M = x.numel() // K
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
+    rp = _dev(residual, torch.float32, "residual") if residual is not None else None
+    bp = _dev(bias, torch.float32, "bias") if bias is not None else None
+    check(_lib.load().r4d_conv1d_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"), bp, rp, M, K, N, epi,
+                                     y.data_ptr(), _stream()), "conv1d")
+    return y
+
+
+def attention(qkv, n_head):
+    """Causal MHA over packed c_attn output [B,T,3d] -> [B,T,d] (modeling_gpt2.py:140-175)."""
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    lib = _lib.load()
+    nbytes = lib.r4d_attention_workspace_bytes(B, n_head, T)
+    ws = workspace(nbytes, qkv.device, "attn")
+    a = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+    check(lib.r4d_attention_f32(_dev(qkv, torch.float32, "qkv"), B, T, n_head, d, a.data_ptr(), ws.data_ptr(),
+                                ws.numel(), _stream()), "attention")
+    return a
+
+
+def lm_logits(hidden, wte):
+    V, d = wte.shape
+    M = hidden.numel() // d
+    out = torch.empty(hidden.shape[:-1] + (V,), dtype=torch.float32, device=hidden.device)
+    check(_lib.load().r4d_lm_logits_f32(_dev(hidden, torch.float32, "hidden"), _dev(wte, torch.float32, "wte"), M, V, d,
+                                        out.data_ptr(), _stream()), "lm_logits")
+    return out
+
+
+def normalize_rows(x):
+    n, d = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().r4d_normalize_rows_f32(_dev(x, torch.float32, "x"), n, d, out.data_ptr(), _stream()),
+          "normalize_rows")
+    return out
+
+
+def score_topk(q_hat, pool_hat, k, index_offset=0, want_scores=False):
+    """(S+1)/2 cosine scan of one pool shard + canonical top-k.  Returns (vals [Q,k], idx int64 [Q,k], scores|None)."""
+    Q, d = q_hat.shape
+    N = pool_hat.shape[0]
+    lib = _lib.load()
+    ws = workspace(lib.r4d_score_topk_workspace_bytes(Q, N, k), q_hat.device, "score")
+    vals = torch.empty(Q, k, dtype=torch.float32, device=q_hat.device)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=q_hat.device)
+    scores = torch.empty(Q, N, dtype=torch.float32, device=q_hat.device) if want_scores else None
+    check(lib.r4d_score_topk_f32(_dev(q_hat, torch.float32, "q_hat"), _dev(pool_hat, torch.float32, "pool_hat"), Q, N, d,
+                                 k, int(index_offset), vals.data_ptr(), idx.data_ptr(),
+                                 scores.data_ptr() if want_scores else None, ws.data_ptr(), ws.numel(), _stream()),
+          "score_topk")
+    return vals, idx, scores
+
+
+def merge_topk(vals, idx):
+    """[G,Q,k] per-shard candidates -> [Q,k] global top-k (same canonical order)."""
+    G, Q, k = vals.shape
+    ov = torch.empty(Q, k, dtype=torch.float32, device=vals.device)
+    oi = torch.empty(Q, k, dtype=torch.int64, device=vals.device)
+    check(_lib.load().r4d_merge_topk_f32(_dev(vals, torch.float32, "vals"), _dev(idx, torch.int64, "idx"), G, Q, k,
+                                         ov.data_ptr(), oi.data_ptr(), _stream()), "merge_topk")
+    return ov, oi
+
+
+def argsort_desc(scores):
+    """Stable argsort of -scores per row (== np.argsort(-S, axis=1, kind='stable')), int32 [rows,n]."""
+    rows, n = scores.shape
+    perm = torch.empty(rows, n, dtype=torch.int32, device=scores.device)
+    lib = _lib.load()
+    if scores.dtype == torch.float64:
+        rc = lib.r4d_argsort_desc_f64(_dev(scores, torch.float64, "scores"), rows, n, perm.data_ptr(), _stream())
+    else:
+        rc = lib.r4d_argsort_desc_f32(_dev(scores, torch.float32, "scores"), rows, n, perm.data_ptr(), _stream())
+    check(rc, "argsort_desc")
+    return perm
+
+
+def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False):
+    """f64 [na,nb] Jaccard matrix of CSR sets (occurrence_matrix, retrieval_data_annotation.py:36-41)."""
+    na, nb = a_ptr.numel() - 1, b_ptr.numel() - 1
+    out = torch.empty(na, nb, dtype=torch.float64, device=a_ptr.device)
+    check(_lib.load().r4d_jaccard_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na,
+                                      _dev(b_ptr, torch.int32, "b_ptr"), _dev(b_idx, torch.int32, "b_idx"), nb,
+                                      int(vocab), int(bool(zero_diag)), out.data_ptr(), _stream()), "jaccard")
+    return out
+
+
+def topk_f64(m, k):
+    rows, n = m.shape
+    lib = _lib.load()
+    ws = workspace(lib.r4d_topk_f64_workspace_bytes(rows, n, k), m.device, "topk64")
+    vals = torch.empty(rows, k, dtype=torch.float64, device=m.device)
+    idx = torch.empty(rows, k, dtype=torch.int32, device=m.device)
+    check(lib.r4d_topk_f64(_dev(m, torch.float64, "m"), rows, n, k, vals.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+                           ws.numel(), _stream()), "topk_f64")
+    return vals, idx
