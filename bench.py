@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: query-sequences/sec, encode + top-k over the full (sharded) pool.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A STEP is one pass of the hot path over one batch of synthetic input, per rank:
+  one query batch of 32 UCI_13-shaped sequences (reference batching: right-padded to the batch max,
+  train_retriever.py:425-432) -> GPT-2 encoder (L4 H2 d512, fp32) + fused ln_f/mean-pool -> row normalise ->
+  [N>1: RCCL all-gather of the query embeddings] -> (S+1)/2 cosine scan of the rank's resident pool shard ->
+  canonical top-10 -> [N>1: RCCL all-gather of the per-shard top-k + merge].
+Inputs (token ids, the pre-encoded pool shard) are resident in HBM before the timed region.  Weak scaling:
+every rank owns a fixed 12,500-row pool shard and encodes its own query batch, so N=8 is the north-star
+100k-sequence pool.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from rag4dyg_amd import _lib, ops, synth                      # noqa: E402
+from rag4dyg_amd.dist import all_gather_cat, sharded_topk      # noqa: E402
+from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG    # noqa: E402
+from rag4dyg_amd.retrieval import PoolIndex, encode_batches, right_pad_batches   # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+QB = 32                          # per_gpu_eval_batch_size, utils/args_parser_retriever.py:225
+
+
+def build_model(shape, device):
+    torch.manual_seed(1234)      # N(0, 0.02) weights, zero biases, LN 1/0 (modeling_gpt2.py:251-262); random-init
+    cfg = GPT2Config(vocab_size=shape.vocab, n_positions=1024, n_ctx=1024, n_embd=shape.n_embd,
+                     n_layer=shape.n_layer, n_head=shape.n_head)
+    return GPT2LMHeadModelRAG(cfg).to(device).eval()
+
+
+def f_enc(shape, B, T):
+    """Algorithmic encoder flop of a padded [B,T] batch: L*(24*T*d^2 + 2*T^2*d) per sequence."""
+    d, L = shape.n_embd, shape.n_layer
+    return B * L * (24.0 * T * d * d + 2.0 * T * T * d)
+
+
+def read_profile():
+    import ctypes
+    lib = _lib.load()
+    out = {}
+    for c in range(lib.r4d_profile_num_classes()):
+        ms, n, w = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.r4d_profile_read(c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w)), "profile_read")
+        if n.value:
+            out[lib.r4d_profile_class_name(c).decode()] = dict(ms=ms.value, launches=n.value, work=w.value)
+    return out
+
+
+def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
+    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
+    from oracle import retrieval_ref
+    sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+    pool = pool_emb.cpu()
+    torch.set_num_threads(os.cpu_count() or 1)
+    done, t0 = 0, time.perf_counter()
+    nb = 0
+    while True:
+        chunk = query_seqs[nb * QB:(nb + 1) * QB]
+        if not chunk:
+            break
+        b = retrieval_ref.right_pad_batches(chunk, QB, shape.pad_id)
+        q = retrieval_ref.encode_batches(sd, shape.n_head, b)
+        S = retrieval_ref.score_batch(q, pool).numpy()
+        retrieval_ref.topk_stable(S, k)
+        done += len(chunk)
+        nb += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(done / el, 2), "unit": "query-seqs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nb} query batches of {QB} (same synthetic UCI_13-shape inputs, same pool shard of "
+                      f"{pool.shape[0]} rows), oracle torch-CPU fp32 encode + score + stable top-{k}, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="UCI_13", choices=sorted(synth.SHAPES))
+    ap.add_argument("--pool-per-gpu", type=int, default=12500)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--query-batches", type=int, default=16, help="distinct synthetic query batches cycled over the steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" IS RCCL on ROCm
+    _lib.load()
+
+    shape = synth.SHAPES[args.shape]
+    model = build_model(shape, device)
+    k = args.topk
+
+    # --- resident pool shard: rows [rank*P, (rank+1)*P) of the global pool, encoded with reference batching
+    P = args.pool_per_gpu
+    pool_seqs = synth.sequences(shape, P, "pool", seed=2026 + rank)
+    t0 = time.perf_counter()
+    pool_batches = right_pad_batches(pool_seqs, QB, shape.pad_id, device)
+    pool_emb = encode_batches(model, pool_batches)
+    torch.cuda.synchronize()
+    pool_encode_s = time.perf_counter() - t0
+    index = PoolIndex(pool_emb, index_offset=rank * P)
+    del pool_batches
+
+    # --- query batches resident in HBM
+    q_seqs = synth.sequences(shape, QB * args.query_batches, "query", seed=9000 + rank)
+    q_batches = right_pad_batches(q_seqs, QB, shape.pad_id, device)
+
+    def step(i):
+        ids = q_batches[i % len(q_batches)]
+        emb = model.encode_meanpool(ids)
+        q_hat = ops.normalize_rows(emb)
+        q_all = all_gather_cat(q_hat) if world > 1 else q_hat
+        return sharded_topk(q_all, index.pool_hat, index.index_offset, k,
+                            lambda q, p_, kk, off: ops.score_topk(q, p_, kk, off)[:2], ops.merge_topk)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out[1].shape == (QB * world, k)
+
+    # --- roofline: the same K steps again with per-launch HIP events on the launch stream
+    roofline, kernels = None, {}
+    if not args.no_roofline:
+        lib = _lib.load()
+        lib.r4d_profile_enable(1)
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof = read_profile()
+        lib.r4d_profile_enable(0)
+        tot_ms = sum(v["ms"] for v in prof.values())
+        for name, v in prof.items():
+            is_mfma = name.startswith("gemm")
+            rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+            kernels[name] = {"share": round(v["ms"] / tot_ms, 4), "launches": v["launches"],
+                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                             ("TFLOP/s" if is_mfma else "GB/s"): round(rate / (1e12 if is_mfma else 1e9), 2)}
+        dom = max(prof, key=lambda n: prof[n]["ms"])
+        v = prof[dom]
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+        if dom.startswith("gemm"):
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                        "flop_per_launch": v["work"] / v["launches"]}
+        else:
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                        "bytes_per_launch": v["work"] / v["launches"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, shape, [s.tolist() for s in q_seqs], pool_emb, k)
+
+    if rank == 0:
+        Ts = [int(b.shape[1]) for b in q_batches]
+        steps_T = [Ts[i % len(Ts)] for i in range(args.steps)]
+        enc_flop = sum(f_enc(shape, QB, T) for T in steps_T)
+        line = {
+            "metric": "query-seqs/sec encode+top-k over full pool",
+            "value": round(world * QB * args.steps / elapsed, 2),
+            "unit": "query-seqs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{shape.name}-shape synthetic sequences, SimpleDyG GPT-2 L{shape.n_layer} H{shape.n_head} "
+                                   f"d{shape.n_embd} V{shape.vocab} random-init fp32; per rank and step one query batch of {QB} "
+                                   f"(padded to batch max, mean T={np.mean(Ts):.0f}) encode+mean-pool+normalise, cosine scan of a "
+                                   f"resident {P}-row pool shard, top-{k}; N>1: RCCL all-gather of embeddings and per-shard top-k",
+                       "query_batch": QB, "pool_rows_per_gpu": P, "pool_rows_total": P * world, "topk": k,
+                       "parallelism": f"pool-shard x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extras": {"encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
+                       "pool_encode_seqs_per_s_per_gpu": round(P / pool_encode_s, 1),
+                       "kernels": kernels},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,18 @@ size_t r4d_topk_f64_workspace_bytes(int32_t rows, int32_t n, int32_t k);
 int r4d_topk_f64(const double* m_d, int32_t rows, int32_t n, int32_t k, double* out_val_d,
                  int32_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, every kernel launch is bracketed by HIP events on the
+ * launch stream and accumulated per kernel class together with its ALGORITHMIC work (flop for the
+ * MFMA-bound classes, bytes for the HBM-bound ones; definitions in DESIGN.md).  Off by default;
+ * not graph-capturable while on.
+ * ---------------------------------------------------------------------------------------------- */
+int r4d_profile_enable(int32_t on);          /* also clears the accumulated records */
+int r4d_profile_num_classes(void);
+const char* r4d_profile_class_name(int32_t cls);
+/* Synchronises the recorded events; total_ms / launches / work summed over the launches of `cls`. */
+int r4d_profile_read(int32_t cls, double* total_ms, int64_t* launches, double* work);
+
 #ifdef __cplusplus
 }
 #endif

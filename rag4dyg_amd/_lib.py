@@ -54,6 +54,10 @@ PROTOTYPES = {
     "r4d_jaccard_f64": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "r4d_profile_enable": (c_int32, [c_int32]),
+    "r4d_profile_num_classes": (c_int32, []),
+    "r4d_profile_class_name": (c_char_p, [c_int32]),
+    "r4d_profile_read": (c_int32, [c_int32, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
 }
 
 _LIB = None

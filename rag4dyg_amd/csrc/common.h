@@ -27,6 +27,20 @@ void set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// ------------------------------------------------------------------ launch profiler (profile.hip)
+enum ProfClass {
+    PK_GEMM_128_NN = 0, PK_GEMM_128_NT, PK_GEMM_64_NN, PK_GEMM_64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
+    PK_LNF_MEANPOOL, PK_NORMALIZE, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
+};
+extern bool g_prof_on;
+void prof_begin_impl(int cls, double work, hipStream_t s);
+void prof_end_impl(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(int cls, double work, hipStream_t st) : s(st), on(g_prof_on) { if (on) prof_begin_impl(cls, work, s); }
+    ~ProfScope() { if (on) prof_end_impl(s); }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -79,6 +79,7 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
                      hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "layernorm: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (rows <= 0) return R4D_OK;
+    ProfScope prof(PK_LAYERNORM, 8.0 * rows * d, s);            // bytes: read x + write y
     hipLaunchKernelGGL((ln_kernel<false>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, 0, rows,
                        1, d, w, b, eps, nullptr, y);
     R4D_CHECK_LAUNCH("layernorm");
@@ -90,6 +91,7 @@ int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const
                            float* x_out, float* y_out, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (rows <= 0) return R4D_OK;
+    ProfScope prof(PK_EMBED_LN, 12.0 * rows * d + 8.0 * rows, s);   // bytes: gather row + write x, y (+ ids)
     hipLaunchKernelGGL((ln_kernel<true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, inputs_embeds, ids, wte, wpe, vocab,
                        rows, T, d, w, b, eps, x_out, y_out);
     R4D_CHECK_LAUNCH("embed_layernorm");
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void causal_softmax_kernel(float* __restrict__
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s) {
     R4D_REQUIRE(T <= 1024, "attention: T=%d exceeds n_positions cap 1024", T);
     const long long rows = (long long)nbh * T;
+    ProfScope prof(PK_SOFTMAX, 4.0 * nbh * T * (double)(T + 1), s);   // bytes: causal half read + written
     hipLaunchKernelGGL(causal_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, (int)rows, T, ld,
                        row_tile);
     R4D_CHECK_LAUNCH("causal_softmax");
@@ -185,6 +188,7 @@ int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, i
                         float* hidden_out, float* pool_out, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "ln_f: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (B <= 0 || T <= 0) return R4D_OK;
+    ProfScope prof(PK_LNF_MEANPOOL, 4.0 * B * T * d * (hidden_out ? 2 : 1) + 4.0 * B * d, s);
     hipLaunchKernelGGL(lnf_meanpool_kernel, dim3(B), dim3(512), 8 * d * sizeof(float), s, x, w, b, T, d, eps,
                        hidden_out, pool_out);
     R4D_CHECK_LAUNCH("lnf_meanpool");

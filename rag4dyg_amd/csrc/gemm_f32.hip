@@ -163,6 +163,9 @@ template <int BM, int BN>
 static int launch_variant(const GemmArgs& g, hipStream_t stream) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     dim3 grid(tiles, 1, g.nbatch);
+    // algorithmic flop: 2MNK dense; the causal launches count only the lower-triangular half
+    const double flop = (g.causal ? 1.0 : 2.0) * (double)g.M * g.N * g.K * g.nbatch;
+    ProfScope prof((BM == 128 ? PK_GEMM_128_NN : PK_GEMM_64_NN) + (g.b_trans ? 1 : 0), flop, stream);
     if (g.b_trans) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true>), grid, dim3(NTHREADS), 0, stream, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false>), grid, dim3(NTHREADS), 0, stream, g);
     R4D_CHECK_LAUNCH("gemm_f32");

@@ -100,6 +100,8 @@ extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, i
     R4D_REQUIRE(na >= 0 && nb >= 0 && vocab >= 1, "jaccard: bad sizes na=%d nb=%d vocab=%d", na, nb, vocab);
     if (na == 0 || nb == 0) return R4D_OK;
     hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes (SURVEY 8d B_jac): the f64 matrix out + both CSR inputs read once
+    ProfScope prof(PK_JACCARD, 8.0 * na * (double)nb + 4.0 * (na + nb + 2), s);
     if (vocab <= JAC_MAX_VOCAB_LDS) {
         const int col_tiles = cdiv(nb, 64);
         // enough row chunks for >= ~8 workgroups per CU, but >= 64 rows each so the table build amortises

@@ -148,6 +148,7 @@ static int topk_rows(const T* vals, int rows, int n, long long ld, int k, long l
             ov = (T*)wp; wp += align_up((size_t)rows * nseg * k * sizeof(T), 256);
             oi = (long long*)wp; wp += align_up((size_t)rows * nseg * k * 8, 256);
         }
+        ProfScope prof(PK_TOPK, (double)rows * cur * (sizeof(T) + (ci ? 8 : 0)), s);
         hipLaunchKernelGGL((topk_seg_kernel<T>), dim3(nseg, rows), dim3(256), 0, s, cv, ci, (int)cur, cld, k,
                            index_offset, ov, oi);
         R4D_CHECK_LAUNCH("topk_seg");
@@ -220,6 +221,7 @@ static int argsort_desc(const T* scores, int rows, int n, int32_t* perm, hipStre
     R4D_REQUIRE(scores && perm, "argsort: null pointer");
     R4D_REQUIRE(rows >= 0 && n >= 1 && n <= 65536, "argsort: n=%d out of range [1,65536]", n);
     if (rows == 0) return R4D_OK;
+    ProfScope prof(PK_RANK_COUNT, (double)rows * n * (sizeof(T) + 4), s);
     hipLaunchKernelGGL((rank_count_kernel<T>), dim3(cdiv(n, 256), rows), dim3(256), 0, s, scores, n, perm);
     R4D_CHECK_LAUNCH("rank_count");
     return R4D_OK;
@@ -234,6 +236,7 @@ extern "C" {
 int r4d_normalize_rows_f32(const float* x_d, int32_t n, int32_t d, float* out_d, void* stream) {
     R4D_REQUIRE(x_d && out_d && n >= 0 && d >= 1, "normalize_rows: bad arguments");
     if (n == 0) return R4D_OK;
+    ProfScope prof(PK_NORMALIZE, 8.0 * n * d, (hipStream_t)stream);
     hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x_d, n, d, out_d);
     R4D_CHECK_LAUNCH("normalize_rows");
     return R4D_OK;
@@ -273,6 +276,7 @@ int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int
     R4D_REQUIRE(vals_d && idx_d && out_val_d && out_idx_d, "merge_topk: null pointer");
     R4D_REQUIRE(G >= 1 && Q >= 1 && k >= 1 && k <= 64 && (long long)G * k <= TOPK_SEG,
                 "merge_topk: G=%d k=%d out of range (G*k <= %d)", G, k, TOPK_SEG);
+    ProfScope prof(PK_MERGE_TOPK, 12.0 * G * Q * k, (hipStream_t)stream);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, vals_d, (const long long*)idx_d,
                        G, Q, k, out_val_d, (long long*)out_idx_d);
     R4D_CHECK_LAUNCH("merge_topk");

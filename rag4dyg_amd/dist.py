@@ -1,0 +1,63 @@
+"""Pool sharding across the GPUs of one node and the one collective the path needs.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  The retrieval pool is
+partitioned into contiguous, BATCH-ALIGNED index ranges (multiples of 32 rows): a pool embedding depends
+on the 32-sequence batch it was padded with (train_retriever.py:420 averages over padded positions), so
+only whole reference batches may move between ranks.  Per query batch the data path is
+
+    all-gather query embeddings [Q_b, d]            (64 KB per rank at d=512)
+    local scan of the rank's shard -> top-k          (no communication)
+    all-gather (value f32, global index i64) [Q,k]   (3.8 KB per rank at Q=32, k=10)
+    merge G*k candidates per row, (value desc, index asc)
+
+Both collectives are latency-bound (tens of microseconds over xGMI), nowhere near the 153 GB/s/link
+limit; the merged result is identical to the single-GPU top-k by construction.
+The reference has no analogue (single process; DataParallel replicates the model, train_retriever.py:391-392).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world_size, align=32):
+    """Contiguous [start,end) per rank, starts aligned to `align` rows, sizes as even as the alignment allows."""
+    n_units = (n_rows + align - 1) // align
+    base, rem = divmod(n_units, world_size)
+    bounds, start = [], 0
+    for r in range(world_size):
+        units = base + (1 if r < rem else 0)
+        end = min(n_rows, start + units * align)
+        bounds.append((start, end))
+        start = end
+    return bounds
+
+
+def all_gather_cat(t, group=None):
+    """Concatenate equally-shaped tensors of every rank along dim 0 (one all-gather)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+def sharded_topk(q_hat_all, pool_hat_shard, shard_offset, k, local_topk, merge, group=None):
+    """Global top-k of every query against the sharded pool.
+
+    local_topk(q_hat, pool_hat, k, offset) -> (vals [Q,k] f32, idx [Q,k] i64)   (HIP: ops.score_topk)
+    merge(vals [G,Q,k], idx [G,Q,k]) -> (vals [Q,k], idx [Q,k])               (HIP: ops.merge_topk)
+    Ranks whose shard holds fewer than k rows contribute (-inf, INT64_MAX) padding.
+    """
+    Q = q_hat_all.shape[0]
+    n_local = pool_hat_shard.shape[0]
+    kk = min(k, n_local)
+    vals = torch.full((Q, k), float("-inf"), dtype=torch.float32, device=q_hat_all.device)
+    idx = torch.full((Q, k), torch.iinfo(torch.int64).max, dtype=torch.int64, device=q_hat_all.device)
+    if kk > 0:
+        v, i = local_topk(q_hat_all, pool_hat_shard, kk, shard_offset)
+        vals[:, :kk] = v
+        idx[:, :kk] = i
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return vals, idx
+    gv = all_gather_cat(vals.unsqueeze(0), group)          # [G,Q,k]
+    gi = all_gather_cat(idx.unsqueeze(0), group)
+    return merge(gv, gi)

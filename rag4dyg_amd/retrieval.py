@@ -1,0 +1,49 @@
+"""Encode -> score -> rank on the GPU: the device half of the retriever's ``test()``.
+
+Reference: ``train/train_retriever.py:414-443`` (pool / query encode loops, normalise, dot, (x+1)/2) and
+``:357-358,461-467`` (ranking).  All arithmetic runs in the HIP library; this module only batches.
+"""
+import torch
+
+from . import ops
+
+
+def right_pad_batches(examples, batch_size, pad_id, device):
+    """Sequential batches right-padded to the batch max with [PAD], drop_last=False
+    (``dataloader/retriever.py:153-166``).  Returns a list of int64 [b,T] device tensors."""
+    out = []
+    for s in range(0, len(examples), batch_size):
+        chunk = examples[s:s + batch_size]
+        T = max(len(e) for e in chunk)
+        b = torch.full((len(chunk), T), int(pad_id), dtype=torch.int64)
+        for i, e in enumerate(chunk):
+            b[i, :len(e)] = torch.as_tensor(e, dtype=torch.int64)
+        out.append(b.to(device, non_blocking=True))
+    return out
+
+
+@torch.no_grad()
+def encode_batches(model, batches):
+    """HOT LOOP 1/2: mean-pooled embeddings of every batch, concatenated (``train_retriever.py:414-422,430-432``)."""
+    return torch.cat([model.encode_meanpool(b) for b in batches], dim=0)
+
+
+class PoolIndex:
+    """Row-normalised pool shard resident in HBM (the reference re-normalises and re-uploads the pool for
+    every query batch, ``train_retriever.py:435-436``; the values are identical)."""
+
+    def __init__(self, pool_emb, index_offset=0):
+        self.pool_hat = ops.normalize_rows(pool_emb.contiguous())
+        self.index_offset = int(index_offset)
+
+    def __len__(self):
+        return self.pool_hat.shape[0]
+
+    def search(self, q_emb, k, want_scores=False):
+        """-> (vals [Q,k], global idx int64 [Q,k], scores [Q,N] | None); canonical (score desc, index asc) order."""
+        q_hat = ops.normalize_rows(q_emb.contiguous())
+        return ops.score_topk(q_hat, self.pool_hat, k, self.index_offset, want_scores)
+
+    def search_hat(self, q_hat, k, offset=None):
+        v, i, _ = ops.score_topk(q_hat, self.pool_hat, k, self.index_offset if offset is None else offset)
+        return v, i
