@@ -125,6 +125,10 @@ size_t r4d_score_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k);
 int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q, int32_t N, int32_t d,
                        int32_t k, int64_t index_offset, float* out_val_d, int64_t* out_idx_d,
                        float* out_scores_d, void* workspace_d, size_t workspace_bytes, void* stream);
+/* Per-row top-k of an f32 matrix with the same canonical order (e.g. the ground-truth top-3 of the float32
+ * Jaccard rows, train_retriever.py:461-462).  Workspace: r4d_score_topk_workspace_bytes(rows, n, k). */
+int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* out_val_d, int64_t* out_idx_d,
+                 void* workspace_d, size_t workspace_bytes, void* stream);
 /* Merge G per-shard candidate lists (after the RCCL all-gather): vals_d [G,Q,k], idx_d [G,Q,k]
  * -> out [Q,k], same canonical order; result == single-GPU top-k by construction. */
 int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k,

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference ``main_SimpleDyG.py`` (flags of ``utils/args_parser_SimpleDyG.py``): the SimpleDyG
+GPT-2 FORWARD on the MI355X -- LM loss of a checkpoint over ``--eval_data_file`` (``evaluate``,
+``main_SimpleDyG.py:345-372``).  LM training (``train``/``train_epoch`` :148-343, backward pass) and the greedy
+generation metrics (``utils/Evaluation_SimpleDyG.py``) are not part of this build and raise."""
+import glob
+import os
+
+import torch
+
+from rag4dyg_amd.cli_args import SIMPLEDYG, parse
+from rag4dyg_amd.dataloader import LineByLineTextDataset, get_dataloader
+from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+from rag4dyg_amd.tokenizer import WordLevelTokenizer, get_model_tokenizer
+
+WEIGHTS_NAME = "pytorch_model.bin"
+MODEL_CLASSES = {"gpt2": (GPT2Config, GPT2LMHeadModel, WordLevelTokenizer)}
+
+
+@torch.no_grad()
+def evaluate(args, model, tokenizer, prefix=""):
+    """``main_SimpleDyG.py:345-372``: mean over batches of the shifted-CE LM loss, labels == inputs."""
+    eval_dataset = LineByLineTextDataset(tokenizer, args, file_path=args.eval_data_file, block_size=args.block_size)
+    os.makedirs(args.output_dir, exist_ok=True)
+    eval_dataloader, args = get_dataloader(eval_dataset, tokenizer, args, split='eval')
+    print("***** Running evaluation {} *****".format(prefix))
+    print("  Num examples = {}".format(len(eval_dataset)))
+    print("  Batch size = {}".format(args.eval_batch_size))
+    eval_loss, nb_eval_steps = 0.0, 0
+    model.eval()
+    for batch in eval_dataloader:
+        inputs = batch.to(args.device)
+        outputs = model(inputs, labels=inputs)
+        eval_loss += outputs[0].mean().item()
+        nb_eval_steps += 1
+    return eval_loss / nb_eval_steps
+
+
+def main(argv=None):
+    args = parse(SIMPLEDYG, "main_SimpleDyG.py", argv)
+    args.with_mask_token = False                     # SimpleDyG tokenizer has no [MASK] (main_SimpleDyG.py:91-95)
+    if args.eval_data_file is None and args.do_eval:
+        raise ValueError("--eval_data_file should be specified when do_eval is true")
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("main_SimpleDyG: needs the MI355X (rag4dyg_amd has no CPU fallback)")
+    torch.cuda.set_device(max(args.local_rank, 0))
+    args.device = torch.device("cuda", max(args.local_rank, 0))
+    args.n_gpu = 1
+    torch.manual_seed(args.seed)
+    model, tokenizer, model_class, args = get_model_tokenizer(args, MODEL_CLASSES)
+    if args.do_train:
+        raise NotImplementedError("SimpleDyG LM training (backward pass) is outside the encode-and-retrieve hot path")
+    results = {}
+    if args.do_eval:
+        checkpoints = [args.output_dir]
+        if args.eval_all_checkpoints:
+            checkpoints = list(os.path.dirname(c) for c in
+                               sorted(glob.glob(args.output_dir + "/**/" + WEIGHTS_NAME, recursive=True)))
+        print("Evaluate the following checkpoints: {}".format(checkpoints))
+        for checkpoint in checkpoints:
+            model = model_class.from_pretrained(checkpoint).to(args.device)
+            results[checkpoint] = evaluate(args, model, tokenizer, prefix=os.path.basename(checkpoint))
+            print(f"eval_loss[{checkpoint}] = {results[checkpoint]:.6f}")
+    return results
+
+
+if __name__ == "__main__":
+    main()

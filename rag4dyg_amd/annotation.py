@@ -1,0 +1,195 @@
+"""Jaccard pool annotation (``retrieval_data_annotation.py``) with the N x N work on the MI355X.
+
+Host side: the reference's string parsing (J1/J2), the token -> dense-id map, CSR packing and the text file
+writers in the reference's formats.  Device side: ``r4d_jaccard_f64`` (all four matrices), ``r4d_topk_f64``
+(train top-10), ``r4d_argsort_desc_f64`` (full rankings, canonical stable order).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+
+ROW_CHUNK = 2048           # A-rows per device pass: bounds the f64 slab to ROW_CHUNK x N
+
+
+def get_input_seq(seq):
+    """``retrieval_data_annotation.py:17-20`` -- keeps the ego id and the <|timeK|> tokens."""
+    seq = seq.split('<|history|>')[1].split('<|endofhistory|>')[0].split(' ')
+    return list(filter(lambda x: x != '', seq))
+
+
+def get_output_seq(seq):
+    """``retrieval_data_annotation.py:22-26`` -- drops anything containing 'time'."""
+    seq = seq.split('<|pre|>')[1].split('<|endofpre|>')[0].split(' ')
+    seq = list(filter(lambda x: x != '', seq))
+    return list(filter(lambda x: 'time' not in x, seq))
+
+
+def get_inout_list(data, gt):
+    """``retrieval_data_annotation.py:28-34``."""
+    return [get_input_seq(d) for d in data], [get_output_seq(g) for g in gt]
+
+
+class SetTable:
+    """Token-string lists -> device CSR (sorted unique dense ids).  One shared token map per annotation run."""
+
+    def __init__(self):
+        self.vocab = {}
+
+    def pack(self, seqs, device):
+        ptr = np.zeros(len(seqs) + 1, dtype=np.int32)
+        rows = []
+        for i, s in enumerate(seqs):
+            row = sorted({self.vocab.setdefault(t, len(self.vocab)) for t in s})
+            rows.append(row)
+            ptr[i + 1] = ptr[i] + len(row)
+        idx = np.fromiter((x for r in rows for x in r), dtype=np.int32, count=int(ptr[-1]))
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.int32)
+        return torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)
+
+
+def _slice_csr(ptr, idx, r0, r1):
+    p = ptr[r0:r1 + 1]
+    base = int(p[0].item())
+    end = int(p[-1].item())
+    sub_idx = idx[base:max(end, base + 1)].contiguous()
+    return (p - base).contiguous(), sub_idx
+
+
+def occurrence_matrix(target_csr, source_csr, vocab, zero_diag=False):
+    """Device f64 [len(target), len(source)] == ``occurrence_matrix`` (``retrieval_data_annotation.py:36-41``)
+    (+ ``np.fill_diagonal(.., 0)`` :172-173 when ``zero_diag``)."""
+    return ops.jaccard(target_csr[0], target_csr[1], source_csr[0], source_csr[1], vocab, zero_diag)
+
+
+def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CHUNK):
+    """Yield (row0, f64 slab [rows, N]) so that an N x N matrix never has to exist at once.
+
+    With ``zero_diag`` the slab is computed against the full source and the diagonal entries of the global
+    matrix (row0+i, row0+i) are zeroed on device.
+    """
+    n = target_csr[0].numel() - 1
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        p, ix = _slice_csr(target_csr[0], target_csr[1], r0, r1)
+        m = ops.jaccard(p, ix, source_csr[0], source_csr[1], vocab, False)
+        if zero_diag:
+            ar = torch.arange(r1 - r0, device=m.device)
+            m[ar, ar + r0] = 0.0
+        yield r0, m
+
+
+def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_file):
+    """``retrieval_data_annotation.py:88-93``: full ranking (canonical stable order) + every score, as text."""
+    with open(save_index_file, 'w') as f, open(save_score_file, 'w') as g:
+        for _r0, m in iter_row_chunks(target_csr, source_csr, vocab):
+            indices = ops.argsort_desc(m).cpu().numpy()
+            mh = m.cpu().numpy()
+            for i in range(mh.shape[0]):
+                f.write(' '.join([str(x) for x in indices[i]]) + '\n')
+                g.write(' '.join([str(x) for x in mh[i]]) + '\n')
+
+
+def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk=10):
+    """``retrieval_data_annotation.py:97-103``: top-10 GT demonstrations of train x train (diag zeroed)."""
+    with open(save_file_index, 'w') as f_index, open(save_file_score, 'w') as f_score:
+        for _r0, m in iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True):
+            vals, idx = ops.topk_f64(m, min(topk, m.shape[1]))
+            vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+            for i in range(idx.shape[0]):
+                f_index.write(' '.join(map(str, idx[i])) + '\n')
+                f_score.write(' '.join(map(str, vals[i])) + '\n')
+
+
+def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False):
+    """Per anchor row: (i, positives, negative candidates, out-score row) following
+    ``retrieval_data_annotation.py:52-74``; candidate order = canonical stable ranking of the input-set
+    similarities (the reference's order is tie-dependent)."""
+    gen_in = iter_row_chunks(in_csr, in_csr, vocab, zero_diag=True)
+    for (r0, m_out), (_r0b, m_in) in zip(iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True), gen_in):
+        has_pos = (m_out > threshold).any(dim=1)
+        rows = torch.nonzero(has_pos).flatten()
+        if rows.numel() == 0:
+            continue
+        order = ops.argsort_desc(m_in[rows].contiguous()).cpu().numpy()
+        mo = m_out[rows].cpu().numpy()
+        for r, i_local in enumerate(rows.tolist()):
+            row = mo[r]
+            pos = np.where(row > threshold)[0].tolist()
+            pos_set = set(pos)
+            negs = []
+            for idx in order[r]:
+                if idx not in pos_set and row[idx] > 0:
+                    negs.append(int(idx))
+                if len(negs) == neg_num:
+                    break
+            if len(negs) < neg_num:
+                for idx in order[r]:
+                    if idx not in pos_set and row[idx] == 0:
+                        negs.append(int(idx))
+                    if len(negs) == neg_num:
+                        break
+            if dialog:
+                pos = pos[:4]
+            yield r0 + i_local, pos, negs, row
+
+
+def save_train_annotation(out_csr, in_csr, vocab, save_file, save_file_score, threshold=0.8, neg_num=5, dataset=""):
+    """``retrieval_data_annotation.py:43-85``: ``i pos neg`` triples; the negative is ``np.random.choice`` of the
+    candidates exactly as upstream (unseeded there, so column 3 is not reproducible by design)."""
+    cnt, n = 0, out_csr[0].numel() - 1
+    with open(save_file, 'w') as f, open(save_file_score, 'w') as g:
+        for i, pos, negs, row in train_annotation_rows(out_csr, in_csr, vocab, threshold, neg_num, 'dialog' in dataset):
+            for pos_ind in pos:
+                neg_i = np.random.choice(negs)
+                f.write(f"{i} {pos_ind} {neg_i}\n")
+                g.write(f"{i} {row[pos_ind]} {row[neg_i]}\n")
+                cnt += 1
+    print("Number of original instances:", n)
+    print('Number of positive samples:', cnt)
+
+
+def read_lines(path):
+    with open(path, 'r') as f:
+        return [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
+
+
+def main(argv):
+    """``python retrieval_data_annotation.py <dataset> <timestamp> <threshold>`` (``:109-200``), cwd-relative paths."""
+    dataset, timestamp = argv[1], argv[2]
+    threshold = float(argv[3])
+    if not torch.cuda.is_available():
+        raise SystemExit("retrieval_data_annotation: needs the MI355X (no CPU fallback in rag4dyg_amd)")
+    device = torch.device("cuda")
+    save_path = os.path.join('./resources/', dataset, str(timestamp), 'train_retrieval')
+    os.makedirs(save_path, exist_ok=True)
+    save_path_gen = os.path.join('./resources/train_generator', dataset, str(timestamp), "train_gt_topk")
+    os.makedirs(save_path_gen, exist_ok=True)
+    base = os.path.join('resources', dataset, timestamp)
+    train_data = read_lines(os.path.join(base, 'train.link_prediction'))
+    test_data = read_lines(os.path.join(base, 'test.link_prediction'))
+    test_gt = read_lines(os.path.join(base, 'test_gt.link_prediction'))
+    val_data = read_lines(os.path.join(base, 'val.link_prediction'))
+    val_gt = read_lines(os.path.join(base, 'val_gt.link_prediction'))
+    train_in, train_out = get_inout_list(train_data, train_data)
+    _, test_out = get_inout_list(test_data, test_gt)
+    _, val_out = get_inout_list(val_data, val_gt)
+    table = SetTable()
+    tr_out = table.pack(train_out, device)
+    tr_in = table.pack(train_in, device)
+    te_out = table.pack(test_out, device)
+    va_out = table.pack(val_out, device)
+    vocab = len(table.vocab)
+    save_train_annotation(tr_out, tr_in, vocab, os.path.join(save_path, 'train_index.retrieval'),
+                          os.path.join(save_path, 'train_score.retrieval'), threshold=threshold, neg_num=5,
+                          dataset=dataset)
+    save_index_score(te_out, tr_out, vocab, os.path.join(save_path, 'test_index.retrieval'),
+                     os.path.join(save_path, 'test_score.retrieval'))
+    save_index_score(va_out, tr_out, vocab, os.path.join(save_path, 'val_index.retrieval'),
+                     os.path.join(save_path, 'val_score.retrieval'))
+    save_score_file_train(tr_out, vocab, os.path.join(save_path_gen, 'train_index.gen'),
+                          os.path.join(save_path_gen, 'train_score.gen'), topk=10)
+    print("Done!")

@@ -271,6 +271,14 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
                             workspace_bytes - align_up((size_t)Q * N * sizeof(float), 256), s);
 }
 
+int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* out_val_d, int64_t* out_idx_d,
+                 void* workspace_d, size_t workspace_bytes, void* stream) {
+    R4D_REQUIRE(m_d && out_val_d && out_idx_d && workspace_d, "topk_f32: null pointer");
+    R4D_REQUIRE(rows >= 1 && n >= 1, "topk_f32: empty input");
+    return topk_rows<float>(m_d, rows, n, n, k, 0, out_val_d, (long long*)out_idx_d, workspace_d, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
 int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k, float* out_val_d,
                        int64_t* out_idx_d, void* stream) {
     R4D_REQUIRE(vals_d && idx_d && out_val_d && out_idx_d, "merge_topk: null pointer");

@@ -1,0 +1,70 @@
+"""Line datasets and the sequential eval loader of the retriever (``dataloader/retriever.py``), host side.
+
+Batching semantics are parity-critical: file order, blank lines dropped, left-truncation to
+the last ``block_size`` tokens, batches of ``per_gpu_eval_batch_size * max(1, n_gpu)`` right-padded with
+[PAD] to the batch max, ``drop_last=False``.
+"""
+import os
+
+import torch
+from torch.nn.utils.rnn import pad_sequence
+from torch.utils.data import DataLoader, Dataset, SequentialSampler
+
+
+def read_nonblank_lines(file_path):
+    assert os.path.isfile(file_path)
+    with open(file_path, encoding="utf-8") as f:
+        return [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
+
+
+class LineByLineTextDataset(Dataset):
+    """Full line per example -- ``dataloader/retriever.py:12-35`` (queries: val/test files are history-only)."""
+
+    def __init__(self, tokenizer, args, file_path, block_size=512):
+        lines = read_nonblank_lines(file_path)
+        self.examples = tokenizer.batch_encode_plus(lines, add_special_tokens=True, max_length=block_size,
+                                                    truncation='longest_first')["input_ids"]
+
+    def __len__(self):
+        return len(self.examples)
+
+    def __getitem__(self, i):
+        return torch.tensor(self.examples[i], dtype=torch.long)
+
+
+class LineByLineTextDatasetHistory(LineByLineTextDataset):
+    """Text before ``<|pre|>`` only -- ``dataloader/retriever.py:37-65`` (pool side)."""
+
+    def __init__(self, tokenizer, args, file_path, block_size=512):
+        lines = [line.split('<|pre|>')[0].strip() for line in read_nonblank_lines(file_path)]
+        print('line0: ', lines[0])
+        self.examples = tokenizer.batch_encode_plus(lines, add_special_tokens=True, max_length=block_size,
+                                                    truncation='longest_first')["input_ids"]
+
+
+def load_and_cache_examples(args, tokenizer, evaluate=False, test=False, pair=True):
+    """``dataloader/retriever.py:113-125``; the (anchor, positive, negative) training triples are out of scope."""
+    if evaluate:
+        file_path = args.eval_data_file
+    elif test:
+        file_path = args.test_data_file
+    else:
+        raise NotImplementedError("PairSequenceDataset feeds retriever TRAINING (backward pass), which is outside "
+                                  "the encode-and-retrieve path (SURVEY.md 8f-4)")
+    return LineByLineTextDataset(tokenizer, args, file_path=file_path, block_size=args.block_size)
+
+
+def get_dataloader(dataset, tokenizer, args, split='eval'):
+    """Eval branch of ``dataloader/retriever.py:128-168``."""
+    if split == 'train':
+        raise NotImplementedError("training loader: outside the encode-and-retrieve path (SURVEY.md 8f-4)")
+
+    def collate(examples):
+        if tokenizer.pad_token is None:
+            return pad_sequence(examples, batch_first=True)
+        return pad_sequence(examples, batch_first=True, padding_value=tokenizer.pad_token_id)
+
+    args.eval_batch_size = args.per_gpu_eval_batch_size * max(1, args.n_gpu)
+    loader = DataLoader(dataset, sampler=SequentialSampler(dataset), batch_size=args.eval_batch_size,
+                        collate_fn=collate, drop_last=False)
+    return loader, args

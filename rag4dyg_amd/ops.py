@@ -103,6 +103,18 @@ def score_topk(q_hat, pool_hat, k, index_offset=0, want_scores=False):
     return vals, idx, scores
 
 
+def topk_f32(m, k):
+    """Canonical per-row top-k of an f32 matrix -> (vals [rows,k], idx int64 [rows,k])."""
+    rows, n = m.shape
+    lib = _lib.load()
+    ws = workspace(lib.r4d_score_topk_workspace_bytes(rows, n, k), m.device, "score")
+    vals = torch.empty(rows, k, dtype=torch.float32, device=m.device)
+    idx = torch.empty(rows, k, dtype=torch.int64, device=m.device)
+    check(lib.r4d_topk_f32(_dev(m, torch.float32, "m"), rows, n, k, vals.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+                           ws.numel(), _stream()), "topk_f32")
+    return vals, idx
+
+
 def merge_topk(vals, idx):
     """[G,Q,k] per-shard candidates -> [Q,k] global top-k (same canonical order)."""
     G, Q, k = vals.shape

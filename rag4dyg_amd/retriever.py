@@ -1,0 +1,135 @@
+"""Drop-in for the retriever's evaluation entry ``test()`` (``train/train_retriever.py:376-524``).
+
+Same signature, same files (``resources/retrieval_result/<ds>/{val,test}_{index,score}.gen`` + results CSV),
+same metric definitions; the arithmetic (encode, normalise, cosine scan, ranking) runs in the HIP library.
+Differences, all documented in DESIGN.md:
+  * ranking uses the canonical stable order (score desc, pool index asc) where the reference's
+    ``np.argsort(-x)`` is unstable (SURVEY.md section 7 hard-part 1);
+  * the pool is normalised once and stays in HBM (the reference redoes it per query batch, :435-436);
+  * the lm_head GEMM whose result the reference discards (:419) is skipped;
+  * ``args.rank_output``: "full" (default, reference-compatible full permutation rows) or "topk" (first
+    ``args.topK`` indices per row -- what the generator actually consumes, ``dataloader/generator.py:46-48``).
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import ops
+from .dataloader import LineByLineTextDatasetHistory, get_dataloader, load_and_cache_examples
+from .retrieval import PoolIndex
+
+
+def hit_rate_at_k(predictions, targets, k=1):
+    """``train/train_retriever.py:31-38``."""
+    gt = set(int(t) for t in targets)
+    for i in set(int(p) for p in predictions[:k]):
+        if i in gt:
+            return 1
+    return 0
+
+
+def save_index_score(index_rows, score_matrix, save_index_file, save_score_file, steps):
+    """Text layout of ``train/train_retriever.py:357-368`` (truncate at step 0, append afterwards, ``%.4f`` scores)."""
+    mode = 'w' if steps == 0 else 'a'
+    with open(save_index_file, mode) as f, open(save_score_file, mode) as g:
+        for i in range(score_matrix.shape[0]):
+            f.write(' '.join([str(x) for x in index_rows[i]]) + '\n')
+            g.write(' '.join([f"{x:.4f}" for x in score_matrix[i]]) + '\n')
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+@torch.no_grad()
+def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
+    test_mode = False if evaluate else True
+    eval_dataset = load_and_cache_examples(args, tokenizer, evaluate=evaluate, test=test_mode)
+    if args.local_rank in [-1, 0]:
+        os.makedirs(args.output_dir, exist_ok=True)
+    eval_dataloader, args = get_dataloader(eval_dataset, tokenizer, args, split='eval')
+    train_dataset = LineByLineTextDatasetHistory(tokenizer, args, file_path=args.train_data_file,
+                                                 block_size=args.block_size)
+    train_dataloader, args = get_dataloader(train_dataset, tokenizer, args, split='eval')
+    model = _unwrap(model)
+    print("Num examples = {}".format(len(eval_dataset)))
+    print("Batch size = {}".format(args.eval_batch_size))
+    hit_1, hit_3 = 0.0, 0.0
+    nb_eval_steps = 0
+    eval_loss = 0
+    model.eval()
+    device = args.device
+    rank_output = getattr(args, "rank_output", "full")
+
+    score_file = args.eval_data_gt_file if evaluate else args.test_data_gt_file
+    with open(score_file, encoding="utf-8") as f:
+        rows = [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
+    scores = torch.Tensor([list(map(float, item.split())) for item in rows])      # float32, as the reference (:409-410)
+    scores = DataLoader(scores, batch_size=args.eval_batch_size, shuffle=False, num_workers=0, drop_last=False)
+
+    # HOT LOOP 1 (:414-422): pool embeddings, then one resident normalised index
+    train_embeddings = torch.cat([model.encode_meanpool(batch.to(device)) for batch in train_dataloader], dim=0)
+    print('size of train_embeddings: ', train_embeddings.size())
+    index = PoolIndex(train_embeddings)
+    n_pool = len(index)
+    topk = min(max(3, int(getattr(args, "topK", 5))), n_pool)
+
+    save_file_path = f'resources/retrieval_result/{args.dataset}/'
+    os.makedirs(save_file_path, exist_ok=True)
+    stem = 'val' if evaluate else 'test'
+    save_index_file = os.path.join(save_file_path, f'{stem}_index.gen')
+    save_score_file = os.path.join(save_file_path, f'{stem}_score.gen')
+
+    # HOT LOOP 2 (:425-474)
+    for batch, score in zip(eval_dataloader, scores):
+        h_egos = model.encode_meanpool(batch.to(device))
+        score = score.to(device)
+        _vals, top_idx, dot_products = index.search(h_egos, topk, want_scores=True)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(dot_products, score)      # metric only (:439-441)
+        eval_loss += loss
+        if prefix == "best":
+            if rank_output == "full":
+                index_rows = ops.argsort_desc(dot_products).cpu().numpy()
+            else:
+                index_rows = top_idx.cpu().numpy()
+            save_index_score(index_rows, dot_products.cpu().numpy(), save_index_file, save_score_file, nb_eval_steps)
+        # hit@1 / hit@3 against the top-3 of the float32 Jaccard rows (:458-474), canonical tie-break on both sides
+        _, gt3 = ops.topk_f32(score.contiguous(), min(3, n_pool))
+        gt3, pred = gt3.cpu().numpy(), top_idx.cpu().numpy()
+        n = score.shape[0]
+        hit_batch_1 = sum(hit_rate_at_k(pred[i], gt3[i], 1) for i in range(n))
+        hit_batch_3 = sum(hit_rate_at_k(pred[i], gt3[i], 3) for i in range(n))
+        hit_1 += hit_batch_1 / n
+        hit_3 += hit_batch_3 / n
+        nb_eval_steps += 1
+
+    eval_loss = eval_loss / len(eval_dataset)                   # as the reference (:477)
+    hit_1 = round(hit_1 / nb_eval_steps, 4)
+    hit_3 = round(hit_3 / nb_eval_steps, 4)
+    eval_metrics = {'hit@1': hit_1, 'hit@3': hit_3}
+
+    result_save_file = os.path.join(save_file_path, "val_results.csv" if evaluate else "test_results.csv")
+    if prefix == "best":
+        with open(result_save_file, "w") as f:                  # :485-495
+            f.write(f"{'epoch'}, ")
+            for param in args.para_names:
+                f.write(f"{param}, ")
+            f.write("Hit@1, Hit@3\n")
+            f.write(f"{epoch}, ")
+            for param in args.para_values:
+                f.write(f"{param}, ")
+            f.write(f"{hit_1},{hit_3}\n")
+            f.write('\n')
+    if evaluate:
+        return eval_metrics, eval_loss
+    if prefix == "best":                                        # :499-515 accumulate across runs
+        save_folder = 'topk_scores_seed_retrieval' if getattr(args, "run_seed", False) else 'topk_scores_finetune'
+        os.makedirs(save_folder, exist_ok=True)
+        result_save_test = os.path.join(save_folder, args.dataset + '_retrieval.csv')
+        with open(result_save_file) as f:
+            lines = [ln for ln in f.read().splitlines() if ln.strip()]
+        with open(result_save_test, 'a' if os.path.exists(result_save_test) else 'w') as g:
+            g.write('\n'.join(lines[1:] if os.path.getsize(result_save_test) > 0 else lines) + '\n')
+    return eval_metrics

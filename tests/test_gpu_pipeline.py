@@ -1,0 +1,183 @@
+"""GPU end-to-end tests: real UCI_13 token ids against the reference's golden embeddings/scores, and the two
+drop-in CLIs on a synthetic dataset written in the reference's file grammar, checked against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model_from_sd(sd, L, H, d, V, P, dev):
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    return m.to(dev).eval()
+
+
+def _unragged(flat, off):
+    return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+
+def test_uci13_real_ids_match_reference_embeddings_scores_ranks(dev):
+    """BASELINE config 2 on the real UCI_13/12 pool (1708) and test queries (110): A0-A10 end to end."""
+    from oracle import gpt2_ref, retrieval_ref
+    from rag4dyg_amd.retrieval import PoolIndex, encode_batches, right_pad_batches
+    g, k = load_golden("g4_uci_retrieval"), load_golden("g6_uci_tokens")
+    pad = int(k["pad_id"])
+    sd = gpt2_ref.make_state_dict(4, 512, 1801, seed=int(g["seed"]), random_affine=True)
+    m = _model_from_sd(sd, 4, 2, 512, 1801, 1024, dev)
+    pool = encode_batches(m, right_pad_batches(_unragged(k["pool_flat"], k["pool_off"]), 32, pad, dev))
+    q = encode_batches(m, right_pad_batches(_unragged(k["test_flat"], k["test_off"]), 32, pad, dev))
+    assert rel_err(pool[:64].cpu().numpy(), g["pool_emb_head"]) < TOL
+    assert rel_err(pool[-52:].cpu().numpy(), g["pool_emb_tail"]) < TOL
+    assert rel_err(pool.norm(dim=1).cpu().numpy(), g["pool_emb_norms"]) < TOL
+    assert rel_err(pool.double().sum(0).cpu().numpy(), g["pool_emb_colsum"]) < TOL
+    assert rel_err(q.cpu().numpy(), g["query_emb"]) < TOL
+    vals, idx, S = PoolIndex(pool).search(q, 10, want_scores=True)
+    assert rel_err(S.cpu().numpy(), g["scores"]) < TOL
+    assert retrieval_ref.topk_matches_modulo_ties(g["scores"], idx.cpu().numpy(), 10, 2e-5)
+    exact = (idx.cpu().numpy() == g["top10_stable"]).all(axis=1).mean()
+    assert exact > 0.9, exact                     # identical ranked top-10 lists except at sub-1e-5 score gaps
+
+
+# ------------------------------------------------------------------------------------------- synthetic dataset
+def _write_dataset(root, ds="toy", t=4, v0=60, n_train=150, n_val=40, n_test=37, seed=0):
+    rng = np.random.default_rng(seed)
+    base = os.path.join(root, "resources", ds, str(t))
+    os.makedirs(base)
+    os.makedirs(os.path.join(root, "vocabs", ds, str(t)))
+    json.dump({str(i): i for i in range(v0)}, open(os.path.join(root, "vocabs", ds, str(t), "vocab.json"), "w"))
+
+    def hist(ego):
+        parts = [f"<|endoftext|> <|history|> {ego}"]
+        for s in range(int(rng.integers(1, t))):
+            parts.append(f"<|time{s}|> " + " ".join(str(int(x)) for x in rng.integers(0, v0, rng.integers(0, 9))))
+        return " ".join(parts).replace("  ", " ").strip() + " <|endofhistory|>"
+
+    def pre():
+        ys = rng.integers(0, 12, rng.integers(1, 4))          # small id range -> many exact Jaccard ties / positives
+        return f"<|pre|> <|time{t}|> " + " ".join(str(int(y)) for y in ys) + " <|endofpre|> <|endoftext|>"
+    train = [hist(int(rng.integers(0, v0))) + " " + pre() for _ in range(n_train)]
+    open(os.path.join(base, "train.link_prediction"), "w").write("\n".join(train) + "\n")
+    for split, n in (("val", n_val), ("test", n_test)):
+        open(os.path.join(base, f"{split}.link_prediction"), "w").write(
+            "\n".join(hist(int(rng.integers(0, v0))) for _ in range(n)) + "\n")
+        open(os.path.join(base, f"{split}_gt.link_prediction"), "w").write("\n".join(pre() for _ in range(n)) + "\n")
+    return base
+
+
+def _read_matrix(path, dtype=float):
+    return [list(map(dtype, ln.split())) for ln in open(path).read().splitlines() if ln.strip()]
+
+
+def test_annotation_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch):
+    from oracle import jaccard_ref
+    from rag4dyg_amd import annotation
+    base = _write_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(0)
+    annotation.main(["retrieval_data_annotation.py", "toy", "4", "0.8"])
+    rd = jaccard_ref.read_lines
+    train = rd(os.path.join(base, "train.link_prediction"))
+    tr_in, tr_out = jaccard_ref.get_inout_list(train, train)
+    out_dir = tmp_path / "resources" / "toy" / "4" / "train_retrieval"
+    for split in ("test", "val"):
+        _, s_out = jaccard_ref.get_inout_list(rd(os.path.join(base, f"{split}.link_prediction")),
+                                              rd(os.path.join(base, f"{split}_gt.link_prediction")))
+        ref = jaccard_ref.occurrence_matrix(s_out, tr_out)
+        got_scores = np.array(_read_matrix(out_dir / f"{split}_score.retrieval"))
+        assert np.array_equal(got_scores, ref)                          # str(float64) round-trips exactly
+        got_idx = np.array(_read_matrix(out_dir / f"{split}_index.retrieval", int))
+        assert np.array_equal(got_idx, jaccard_ref.rank_rows(ref))       # full permutation, canonical order
+        # text identical to the reference writer's (retrieval_data_annotation.py:92-93)
+        first = open(out_dir / f"{split}_score.retrieval").readline().rstrip("\n")
+        assert first == ' '.join(str(x) for x in ref[0])
+    m_out = jaccard_ref.occurrence_matrix(tr_out, tr_out); np.fill_diagonal(m_out, 0)
+    m_in = jaccard_ref.occurrence_matrix(tr_in, tr_in); np.fill_diagonal(m_in, 0)
+    gen_dir = tmp_path / "resources" / "train_generator" / "toy" / "4" / "train_gt_topk"
+    top = np.array(_read_matrix(gen_dir / "train_index.gen", int))
+    assert np.array_equal(top, jaccard_ref.rank_rows(m_out)[:, :10])
+    assert np.array_equal(np.array(_read_matrix(gen_dir / "train_score.gen")),
+                          np.take_along_axis(m_out, jaccard_ref.rank_rows(m_out)[:, :10], axis=1))
+    pos = jaccard_ref.train_positives(m_out, 0.8)
+    cands = jaccard_ref.train_negative_candidates(m_out, m_in, 0.8)
+    triples = _read_matrix(out_dir / "train_index.retrieval", int)
+    assert len(triples) == sum(len(p) for p in pos) > 0
+    seen = {}
+    for i, p, n in triples:
+        seen.setdefault(i, []).append(p)
+        assert n in cands[i]
+    assert all(seen.get(i, []) == p for i, p in enumerate(pos))
+    sc = _read_matrix(out_dir / "train_score.retrieval")
+    assert all(s[1] == m_out[int(t_[0]), t_[1]] and s[2] == m_out[int(t_[0]), t_[2]] for s, t_ in zip(sc, triples))
+
+
+def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch):
+    import main_retriever
+    from oracle import gpt2_ref, jaccard_ref, retrieval_ref
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    base = _write_dataset(str(tmp_path), seed=3)
+    monkeypatch.chdir(tmp_path)
+    rd = jaccard_ref.read_lines
+    train = rd(os.path.join(base, "train.link_prediction"))
+    _, tr_out = jaccard_ref.get_inout_list(train, train)
+    gt = {}
+    for split in ("test", "val"):
+        _, s_out = jaccard_ref.get_inout_list(rd(os.path.join(base, f"{split}.link_prediction")),
+                                              rd(os.path.join(base, f"{split}_gt.link_prediction")))
+        gt[split] = jaccard_ref.occurrence_matrix(s_out, tr_out)
+        open(os.path.join(base, f"{split}_score.retrieval"), "w").write(
+            "\n".join(' '.join(str(x) for x in row) for row in gt[split]) + "\n")
+    L, H, d = 2, 2, 64                               # len(tok) = V0 + 8 + t = 60 + 12
+    tok, _ = build_tokenizer("toy", 4)
+    assert len(tok) == 72
+    sd = gpt2_ref.make_state_dict(L, d, len(tok), seed=77, random_affine=True)
+    ck = tmp_path / "out" / "checkpoint-0"
+    ck.mkdir(parents=True)
+    full_sd = dict(sd)
+    for i in range(L):                               # reference checkpoints carry the causal buffers (strict load)
+        full_sd[f"transformer.h.{i}.attn.bias"] = torch.tril(torch.ones(1024, 1024)).view(1, 1, 1024, 1024)
+    torch.save(full_sd, ck / "pytorch_model.bin")
+    argv = (f"--dataset toy --timestamp 4 --output_dir {tmp_path}/out --model_type gpt2 --model_name_or_path gpt2 "
+            f"--train_data_file {base}/train.link_prediction --do_eval --eval_all_checkpoints "
+            f"--eval_data_file {base}/val.link_prediction --eval_data_gt_file {base}/val_score.retrieval "
+            f"--test_data_file {base}/test.link_prediction --test_data_gt_file {base}/test_score.retrieval "
+            f"--block_size 512 --n_layer {L} --n_head {H} --n_embed {d} --topK 5").split()
+    main_retriever.main(argv)
+    res = tmp_path / "resources" / "retrieval_result" / "toy"
+    idx_rows = np.array(_read_matrix(res / "test_index.gen", int))
+    score_rows = np.array(_read_matrix(res / "test_score.gen"))
+    # oracle pipeline on the same text
+    pool_ids = tok([ln.split('<|pre|>')[0].strip() for ln in train], max_length=512)["input_ids"]
+    q_ids = tok(rd(os.path.join(base, "test.link_prediction")), max_length=512)["input_ids"]
+    pool = retrieval_ref.encode_batches(sd, H, retrieval_ref.right_pad_batches(pool_ids, 32, tok.pad_token_id))
+    q = retrieval_ref.encode_batches(sd, H, retrieval_ref.right_pad_batches(q_ids, 32, tok.pad_token_id))
+    S = retrieval_ref.score_batch(q, pool).numpy()
+    assert score_rows.shape == S.shape == (37, 150)
+    assert np.abs(score_rows - S).max() < 1e-4 + 5e-5                   # %.4f text
+    assert all(sorted(r) == list(range(150)) for r in idx_rows.tolist())   # full permutations
+    assert retrieval_ref.topk_matches_modulo_ties(S, idx_rows, 5, 1e-5)
+    assert (idx_rows[:, :5] == retrieval_ref.rank_full(S)[:, :5]).all(axis=1).mean() > 0.9
+    csv = open(res / "test_results.csv").read()
+    assert "Hit@1, Hit@3" in csv
+    hits = [float(x) for x in csv.strip().splitlines()[1].split(",")[-2:]]
+    sb = [S[i:i + 32] for i in range(0, 37, 32)]
+    gb = [gt["test"][i:i + 32] for i in range(0, 37, 32)]
+    ref_hits = retrieval_ref.hit_metrics(sb, gb)
+    assert abs(hits[0] - ref_hits[0]) <= 0.03 and abs(hits[1] - ref_hits[1]) <= 0.03
+    # tokenizer files written in the reference layout
+    assert (tmp_path / "tokenizers" / "toy" / "4" / "tokenizer.json").exists()

@@ -1,0 +1,278 @@
+"""CPU-only tests of the host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+REF = "/root/reference"
+has_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+
+
+# ------------------------------------------------------------------------------------------- C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    from rag4dyg_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "r4d.h")).read()
+    declared = set(re.findall(r"\b(r4d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.r4d_abi_version() == 1
+    assert lib.r4d_last_error() == b""
+    assert lib.r4d_profile_num_classes() > 0 and lib.r4d_profile_class_name(0).startswith(b"gemm")
+    # size queries are pure host arithmetic
+    from rag4dyg_amd._lib import GPT2ConfigC
+    import ctypes
+    cfg = GPT2ConfigC(4, 2, 512, 1801, 1024, 1e-5)
+    M = 32 * 128
+    need = lib.r4d_gpt2_workspace_bytes(ctypes.byref(cfg), 32, 128)
+    assert need >= 4 * (M * 512 * 10 + 32 * 2 * 128 * 128)
+    assert lib.r4d_attention_workspace_bytes(2, 2, 129) == 2 * 2 * 129 * 256 * 4
+    assert lib.r4d_score_topk_workspace_bytes(32, 100000, 10) >= 32 * 100000 * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    from rag4dyg_amd import ops
+    from rag4dyg_amd._lib import R4DError
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=20, n_positions=16, n_ctx=16, n_embd=64, n_layer=1, n_head=2))
+    with pytest.raises(R4DError):
+        m(input_ids=torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(R4DError):
+        ops.normalize_rows(torch.ones(2, 64))
+    with pytest.raises(R4DError):
+        ops.jaccard(torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32),
+                    torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), 4)
+    src = "".join(open(os.path.join(REPO, "rag4dyg_amd", f)).read() for f in os.listdir(os.path.join(REPO, "rag4dyg_amd"))
+                  if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src        # the product never touches the oracle
+
+
+# ------------------------------------------------------------------------------------------- model layout
+def test_state_dict_layout_matches_reference_checkpoint_keys():
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel, GPT2LMHeadModelRAG, GPT2Model
+    cfg = GPT2Config(vocab_size=40, n_positions=32, n_ctx=32, n_embd=64, n_layer=2, n_head=2)
+    m = GPT2LMHeadModelRAG(cfg)
+    sd = m.state_dict()
+    ref = gpt2_ref.make_state_dict(2, 64, 40, n_positions=32)
+    buf = {f"transformer.h.{i}.attn.bias" for i in range(2)}           # causal buffers, modeling_gpt2.py:106
+    assert set(sd) == set(ref) | buf
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    assert sd["transformer.h.0.attn.bias"].shape == (1, 1, 32, 32)
+    assert sd["lm_head.weight"].data_ptr() == sd["transformer.wte.weight"].data_ptr()    # tied
+    m.resize_token_embeddings(48)
+    assert m.state_dict()["lm_head.weight"].shape == (48, 64) and m.config.vocab_size == 48
+    assert torch.equal(m.transformer.wte.weight[:40], sd["transformer.wte.weight"])
+
+
+def test_save_and_load_pretrained_roundtrip(tmp_path):
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel, GPT2Model
+    cfg = GPT2Config(vocab_size=40, n_positions=32, n_ctx=32, n_embd=64, n_layer=1, n_head=2)
+    cfg.max_token_id = 33
+    m = GPT2LMHeadModel(cfg)
+    d = tmp_path / "checkpoint-0"
+    d.mkdir()
+    m.save_pretrained(str(d))
+    j = json.load(open(d / "config.json"))
+    for key in ("n_ctx", "n_embd", "n_head", "n_layer", "n_positions", "vocab_size", "layer_norm_epsilon",
+                "max_token_id", "output_past", "architectures"):
+        assert key in j
+    assert j["architectures"] == ["GPT2LMHeadModel"]
+    m2 = GPT2LMHeadModel.from_pretrained(str(d))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    base = GPT2Model.from_pretrained(str(d))            # strips the "transformer." prefix (modeling_utils.py:530-541)
+    assert torch.equal(base.wte.weight, m.transformer.wte.weight)
+    assert torch.equal(base.h[0].mlp.c_fc.weight, m.transformer.h[0].mlp.c_fc.weight)
+    with pytest.raises(OSError):
+        GPT2LMHeadModel.from_pretrained(str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------- tokenizer
+def _uci_tokenizer():
+    from rag4dyg_amd.tokenizer import WordLevelTokenizer
+    g = load_golden("g6_uci_tokens")
+    v0 = int(g["vocab_size"])
+    tok = WordLevelTokenizer({str(i): i for i in range(v0)})
+    tok.add_special_tokens({'bos_token': '<|endoftext|>'})
+    tok.add_special_tokens({'eos_token': '<|endoftext|>'})
+    tok.add_special_tokens({'additional_special_tokens': ['<|history|>', '<|endofhistory|>', '<|pre|>', '<|endofpre|>'] +
+                            [f'<|time{i}|>' for i in range(13)]})
+    tok.add_special_tokens({'pad_token': '[PAD]'})
+    tok.add_special_tokens({'mask_token': '[MASK]'})
+    return tok, g
+
+
+def test_tokenizer_id_layout_and_truncation_match_reference():
+    tok, g = _uci_tokenizer()
+    assert len(tok) == int(g["len_tok"]) == 1801 and tok.vocab_size == 1781
+    assert tok.pad_token_id == int(g["pad_id"]) == 1799 and tok.mask_token_id == 1800 and tok.bos_token_id == 1781
+    for name, i in zip(g["special_names"], g["special_ids"]):
+        assert tok.convert_tokens_to_ids(str(name)) == int(i)
+    long_line = "<|endoftext|> <|history|> 3 " + " ".join(str(i % 1700) for i in range(596)) + " <|endofhistory|>"
+    ids = tok.batch_encode_plus([long_line], max_length=512, truncation="longest_first")["input_ids"][0]
+    assert ids == g["trunc_ids"].tolist()                              # keeps the LAST 512 tokens
+    assert tok("<|endoftext|> <|history|> 1 <|time0|> 0 <|time1|> 670 <|endofhistory|>")["input_ids"] == \
+        [1781, 1782, 1, 1786, 0, 1787, 670, 1783]
+    with pytest.raises(ValueError):
+        tok("<|history|> 999999")                                      # no UNK: OOV raises
+    assert tok.decode([1781, 5, 1799]) == "<|endoftext|> 5 [PAD]"
+
+
+def test_tokenizer_files_roundtrip(tmp_path):
+    from rag4dyg_amd.tokenizer import WordLevelTokenizer
+    tok, _ = _uci_tokenizer()
+    tok.save_pretrained(str(tmp_path))
+    for f in ("tokenizer.json", "special_tokens_map.json", "tokenizer_config.json"):
+        assert (tmp_path / f).exists()
+    t2 = WordLevelTokenizer.from_pretrained(str(tmp_path))
+    line = "<|endoftext|> <|history|> 7 <|time3|> 12 13 <|endofhistory|>"
+    assert t2(line)["input_ids"] == tok(line)["input_ids"] and len(t2) == len(tok) and t2.pad_token_id == 1799
+    import tokenizers                                                   # the HF library reads our file identically
+    hf = tokenizers.Tokenizer.from_file(str(tmp_path / "tokenizer.json"))
+    assert hf.encode(line).ids == tok(line)["input_ids"]
+
+
+@has_ref
+def test_tokenizer_on_shipped_files_matches_reference_ids():
+    from rag4dyg_amd.tokenizer import WordLevelTokenizer, build_tokenizer
+    g = load_golden("g6_uci_tokens")
+    tok, _ = build_tokenizer("UCI_13", 12, root=REF)
+    shipped = WordLevelTokenizer.from_pretrained(os.path.join(REF, "tokenizers/UCI_13/12"))
+    assert shipped.added[:19] == tok.added[:19]                        # shipped tokenizer.json: same ids
+    for split, key, hist in (("train", "pool", True), ("test", "test", False), ("val", "val", False)):
+        lines = [l for l in open(f"{REF}/resources/UCI_13/12/{split}.link_prediction").read().splitlines() if l.strip()]
+        if hist:
+            lines = [l.split('<|pre|>')[0].strip() for l in lines]
+        ids = tok(lines, max_length=512)["input_ids"]
+        assert np.array_equal(np.concatenate([np.asarray(x) for x in ids]), g[key + "_flat"])
+        assert np.array_equal(np.cumsum([0] + [len(x) for x in ids]), g[key + "_off"])
+
+
+# ------------------------------------------------------------------------------------------- data / parsing / synth
+def test_dataset_classes_and_eval_batching(tmp_path):
+    from types import SimpleNamespace
+    from rag4dyg_amd.dataloader import LineByLineTextDataset, LineByLineTextDatasetHistory, get_dataloader
+    tok, _ = _uci_tokenizer()
+    lines = [f"<|endoftext|> <|history|> {i} <|time0|> " + " ".join(str(j) for j in range(i % 7)) +
+             f" <|endofhistory|> <|pre|> <|time1|> {i + 1} <|endofpre|> <|endoftext|>" for i in range(70)]
+    p = tmp_path / "train.link_prediction"
+    p.write_text("\n".join(lines[:35]) + "\n\n   \n" + "\n".join(lines[35:]) + "\n")
+    full = LineByLineTextDataset(tok, None, str(p), block_size=512)
+    hist = LineByLineTextDatasetHistory(tok, None, str(p), block_size=512)
+    assert len(full) == len(hist) == 70                                # blank lines dropped
+    assert hist[3].tolist()[-1] == 1783 and full[3].tolist()[-1] == 1781
+    args = SimpleNamespace(per_gpu_eval_batch_size=32, n_gpu=1, local_rank=-1)
+    loader, args = get_dataloader(hist, tok, args, split="eval")
+    batches = list(loader)
+    assert [b.shape[0] for b in batches] == [32, 32, 6] and args.eval_batch_size == 32
+    b0 = batches[0]
+    assert b0.shape[1] == max(len(hist[i]) for i in range(32))
+    assert (b0[0, len(hist[0]):] == 1799).all()                        # right-padded with [PAD]
+    with pytest.raises(NotImplementedError):
+        get_dataloader(hist, tok, args, split="train")
+
+
+def test_annotation_parsing_matches_oracle():
+    from oracle import jaccard_ref
+    from rag4dyg_amd import annotation
+    line = ("<|endoftext|> <|history|> 5 <|time0|> 4  7 <|time1|> <|time2|> 9 <|endofhistory|> "
+            "<|pre|> <|time3|> 789 5 789 <|endofpre|> <|endoftext|>")
+    assert annotation.get_input_seq(line) == jaccard_ref.get_input_seq(line)
+    assert annotation.get_output_seq(line) == jaccard_ref.get_output_seq(line) == ['789', '5', '789']
+    t = annotation.SetTable()
+    ptr, idx = t.pack([['a', 'b', 'a'], [], ['b', 'c']], torch.device("cpu"))
+    assert ptr.tolist() == [0, 2, 2, 4] and idx.tolist() == [0, 1, 1, 2] and len(t.vocab) == 3
+
+
+def test_synth_sequences_follow_grammar_and_shape():
+    from rag4dyg_amd import synth
+    sh = synth.UCI_13
+    assert sh.vocab == 1801 and sh.pad_id == 1799
+    seqs = synth.sequences(sh, 2000, "pool", seed=1)
+    lens = np.array([len(s) for s in seqs])
+    assert 10 <= np.median(lens) <= 17 and lens.max() <= 329 and lens.min() >= 6
+    for s in seqs[:50]:
+        assert s[0] == sh.v0 and s[1] == sh.v0 + 1 and s[-1] == sh.v0 + 2 and s[2] < sh.v0
+        assert s.max() < sh.pad_id
+    q = synth.sequences(sh, 2000, "query", seed=2)
+    assert 50 <= np.median([len(s) for s in q]) <= 68
+    ptr, idx = synth.output_sets(sh, 500)
+    assert ptr[-1] == len(idx) and (np.diff(ptr) >= 1).all() and idx.max() < sh.v0
+
+
+def test_cli_flag_surface_accepts_reference_scripts():
+    from rag4dyg_amd.cli_args import GENERATOR, RETRIEVER, SIMPLEDYG, parse
+    argv = ("--dataset UCI_13 --eta 0.8 --gamma 0.4 --temperature=0.1 --alpha 1 --lambda_decay=0.0001 --lrdecay 1 "
+            "--warmup_steps 0 --output_dir=out --model_type gpt2 --model_name_or_path gpt2 --train_data_file=tr "
+            "--train_pair_data_file=tp --do_eval --eval_data_file=v --eval_data_gt_file=vg --test_data_file=t "
+            "--test_data_gt_file=tg --save_steps 250 --logging_steps 500 --per_gpu_train_batch_size=64 "
+            "--num_train_epochs 50 --block_size 512 --eval_all_checkpoints --timestamp 12 --patience 10 --n_layer=4 "
+            "--n_head=2 --n_embed=512 --learning_rate=1e-5 --seed=42 --run_seed").split()
+    a = parse(RETRIEVER, "main_retriever.py", argv)          # scripts/train_retriever/eval_retriever_UCI_13.sh:24-55
+    assert a.n_layer == 4 and a.per_gpu_eval_batch_size == 32 and a.topK == 5 and a.do_eval and a.rank_output == "full"
+    g = parse(GENERATOR, "main_generator.py", "--timestamp 11 --dataset reddit --train_data_file x --output_dir o "
+              "--model_type gpt2 --gnn_layer 2".split())     # scripts pass --gnn_layer (prefix of --gnn_layers)
+    assert g.gnn_layers == 2 and g.topK == 7
+    with pytest.raises(SystemExit):
+        parse(SIMPLEDYG, "main_SimpleDyG.py", ["--dataset", "x"])     # required flags enforced
+
+
+# ------------------------------------------------------------------------------------------- multi-GPU logic
+def test_shard_bounds_are_batch_aligned_and_cover():
+    from rag4dyg_amd.dist import shard_bounds
+    for n, w in ((1708, 8), (100000, 8), (31, 4), (8556, 3), (64, 2)):
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(s % 32 == 0 or s == e for s, e in b)       # empty trailing shards start at n
+        sizes = [e - s for s, e in b]
+        assert max(sizes) - min(sizes) <= 64
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rag4dyg_amd.dist import shard_bounds, sharded_topk
+from oracle import retrieval_ref
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+g = torch.Generator().manual_seed(0)
+Q, N, d, k = 8, 200, 16, 5
+q = torch.randn(Q, d, generator=g); p = torch.randn(N, d, generator=g); p[150] = p[7]
+qh = q / q.norm(dim=1, keepdim=True); ph = p / p.norm(dim=1, keepdim=True)
+s, e = shard_bounds(N, world)[rank]
+def local_topk(qq, pp, kk, off):          # CPU stand-ins for the HIP kernels: same canonical order
+    S = ((qq @ pp.t()) + 1) / 2
+    v, i = retrieval_ref.topk_stable(S.numpy(), kk)
+    return torch.from_numpy(v.copy()), torch.from_numpy(i + off)
+def merge(gv, gi):
+    G, Q_, k_ = gv.shape
+    v = gv.permute(1, 0, 2).reshape(Q_, G * k_).numpy(); i = gi.permute(1, 0, 2).reshape(Q_, G * k_).numpy()
+    order = np.lexsort((i, -v), axis=1)[:, :k_]
+    return torch.from_numpy(np.take_along_axis(v, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1))
+vals, idx = sharded_topk(qh, ph[s:e], s, k, local_topk, merge)
+ref_v, ref_i = local_topk(qh, ph, k, 0)
+assert torch.equal(idx, ref_i) and torch.equal(vals, ref_v), (rank, idx, ref_i)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_topk_world_size_2_gloo(tmp_path, world):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29600 + world + os.getpid() % 200)
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, port],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), OMP_NUM_THREADS="1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
