@@ -6,8 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 A STEP is one pass of the hot path over one batch of synthetic input, per rank:
-  one query batch of 32 UCI_13-shaped sequences (reference batching: right-padded to the batch max,
-  train_retriever.py:425-432) -> GPT-2 encoder (L4 H2 d512, fp32) + fused ln_f/mean-pool -> row normalise ->
+  G (default 4) query batches of 32 UCI_13-shaped sequences (reference batching: each right-padded to its
+  own batch max, train_retriever.py:425-432) -> GPT-2 encoder (L4 H2 d512, fp32; the row-wise kernels run
+  over the concatenated rows of the G batches) + fused ln_f/mean-pool -> row normalise ->
   [N>1: RCCL all-gather of the query embeddings] -> (S+1)/2 cosine scan of the rank's resident pool shard ->
   canonical top-10 -> [N>1: RCCL all-gather of the per-shard top-k + merge].
 Inputs (token ids, the pre-encoded pool shard) are resident in HBM before the timed region.  Weak scaling:
@@ -62,12 +63,24 @@ def read_profile():
     return out
 
 
+def host_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
     """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
     from oracle import retrieval_ref
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
     pool = pool_emb.cpu()
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     done, t0 = 0, time.perf_counter()
     nb = 0
     while True:
@@ -96,8 +109,14 @@ def main():
     ap.add_argument("--shape", default="UCI_13", choices=sorted(synth.SHAPES))
     ap.add_argument("--pool-per-gpu", type=int, default=12500)
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--batches-per-step", type=int, default=4,
+                    help="reference query batches (32 sequences each, padded independently) handed to the library per step "
+                         "as one fused launch sequence")
     ap.add_argument("--query-batches", type=int, default=16, help="distinct synthetic query batches cycled over the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--random-pool", action="store_true",
+                    help="profiling aid: fill the resident pool shard with N(0,1) embeddings instead of encoding the "
+                         "synthetic pool, so that a rocprofv3 trace holds the timed-step kernels only")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -120,22 +139,30 @@ def main():
 
     # --- resident pool shard: rows [rank*P, (rank+1)*P) of the global pool, encoded with reference batching
     P = args.pool_per_gpu
-    pool_seqs = synth.sequences(shape, P, "pool", seed=2026 + rank)
-    t0 = time.perf_counter()
-    pool_batches = right_pad_batches(pool_seqs, QB, shape.pad_id, device)
-    pool_emb = encode_batches(model, pool_batches)
-    torch.cuda.synchronize()
-    pool_encode_s = time.perf_counter() - t0
+    if args.random_pool:
+        pool_emb = torch.randn(P, shape.n_embd, generator=torch.Generator().manual_seed(2026 + rank)).to(device)
+        pool_encode_s = float("nan")
+    else:
+        pool_seqs = synth.sequences(shape, P, "pool", seed=2026 + rank)
+        pool_batches = right_pad_batches(pool_seqs, QB, shape.pad_id, device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pool_emb = encode_batches(model, pool_batches)
+        torch.cuda.synchronize()
+        pool_encode_s = time.perf_counter() - t0
+        del pool_batches
     index = PoolIndex(pool_emb, index_offset=rank * P)
-    del pool_batches
 
     # --- query batches resident in HBM
     q_seqs = synth.sequences(shape, QB * args.query_batches, "query", seed=9000 + rank)
     q_batches = right_pad_batches(q_seqs, QB, shape.pad_id, device)
 
+    G = args.batches_per_step
+    nqb = len(q_batches)
+
     def step(i):
-        ids = q_batches[i % len(q_batches)]
-        emb = model.encode_meanpool(ids)
+        group = [q_batches[(i * G + j) % nqb] for j in range(G)]
+        emb = model.encode_groups_meanpool(group)
         q_hat = ops.normalize_rows(emb)
         q_all = all_gather_cat(q_hat) if world > 1 else q_hat
         return sharded_topk(q_all, index.pool_hat, index.index_offset, k,
@@ -159,7 +186,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert out[1].shape == (QB * world, k)
+    assert out[1].shape == (QB * G * world, k)
 
     # --- roofline: the same K steps again with per-launch HIP events on the launch stream
     roofline, kernels = None, {}
@@ -203,26 +230,28 @@ def main():
 
     if rank == 0:
         Ts = [int(b.shape[1]) for b in q_batches]
-        steps_T = [Ts[i % len(Ts)] for i in range(args.steps)]
+        steps_T = [Ts[(i * G + j) % len(Ts)] for i in range(args.steps) for j in range(G)]
         enc_flop = sum(f_enc(shape, QB, T) for T in steps_T)
         line = {
             "metric": "query-seqs/sec encode+top-k over full pool",
-            "value": round(world * QB * args.steps / elapsed, 2),
+            "value": round(world * QB * G * args.steps / elapsed, 2),
             "unit": "query-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape.name}-shape synthetic sequences, SimpleDyG GPT-2 L{shape.n_layer} H{shape.n_head} "
-                                   f"d{shape.n_embd} V{shape.vocab} random-init fp32; per rank and step one query batch of {QB} "
-                                   f"(padded to batch max, mean T={np.mean(Ts):.0f}) encode+mean-pool+normalise, cosine scan of a "
+                                   f"d{shape.n_embd} V{shape.vocab} random-init fp32; per rank and step {G} reference query batches of {QB} "
+                                   f"(each padded to its own batch max, mean T={np.mean(Ts):.0f}; one fused launch sequence) "
+                                   f"encode+mean-pool+normalise, cosine scan of a "
                                    f"resident {P}-row pool shard, top-{k}; N>1: RCCL all-gather of embeddings and per-shard top-k",
-                       "query_batch": QB, "pool_rows_per_gpu": P, "pool_rows_total": P * world, "topk": k,
+                       "query_batch": QB, "query_batches_per_step": G, "queries_per_step_per_gpu": QB * G,
+                       "pool_rows_per_gpu": P, "pool_rows_total": P * world, "topk": k,
                        "parallelism": f"pool-shard x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extras": {"encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
-                       "pool_encode_seqs_per_s_per_gpu": round(P / pool_encode_s, 1),
+                       "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),
                        "kernels": kernels},
         }
         print(json.dumps(line))

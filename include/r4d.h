@@ -87,6 +87,21 @@ int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w,
                         float* out_hidden_d, float* out_meanpool_d, float* out_layers_d, float* out_qkv_d,
                         void* workspace_d, size_t workspace_bytes, void* stream);
 
+/*
+ * Several right-padded batches in ONE launch sequence (throughput form of the call above; same values).
+ * The reference encodes one 32-sequence batch per model call (train_retriever.py:414-432); a batch's
+ * embeddings depend on its own padding (mean over padded positions, :420), so batches are NOT merged -- but
+ * the row-wise work (LayerNorm, Conv1D GEMMs) of all batches runs over their concatenated rows, while the
+ * embedding/positions, attention and mean-pool stay per batch.
+ *   ids_d  HOST array [n_groups] of device int64 [Bs[g], Ts[g]] pointers;  Bs, Ts HOST arrays
+ *   out_meanpool_d device f32 [sum(Bs), d], batches in order
+ */
+size_t r4d_gpt2_groups_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs,
+                                       const int32_t* Ts);
+int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
+                               const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
+                               float* out_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
+
 /* lm_logits = hidden @ wte^T  (tied lm_head, modeling_gpt2.py:585; modeling_rag.py:675).
  * hidden_d [M,d], wte_d [V,d] -> logits_d [M,V]. */
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d,

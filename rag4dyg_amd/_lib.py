@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "librag4dyg_hip.so")
+LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: A/B tuning only
 
 R4D_ABI_VERSION = 1
 
@@ -39,6 +39,9 @@ PROTOTYPES = {
     "r4d_gpt2_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, c_int32]),
     "r4d_gpt2_encode_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), _P, _P, c_int32, c_int32,
                                       _P, _P, _P, _P, _P, c_size_t, _P]),
+    "r4d_gpt2_groups_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "r4d_gpt2_encode_groups_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), c_int32, POINTER(_P),
+                                             POINTER(c_int32), POINTER(c_int32), _P, _P, c_size_t, _P]),
     "r4d_lm_logits_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_layernorm_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),
     "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),

@@ -29,8 +29,9 @@ void set_error(const char* fmt, ...);
 
 // ------------------------------------------------------------------ launch profiler (profile.hip)
 enum ProfClass {
-    PK_GEMM_128_NN = 0, PK_GEMM_128_NT, PK_GEMM_64_NN, PK_GEMM_64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
-    PK_LNF_MEANPOOL, PK_NORMALIZE, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
+    PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
+    PK_GEMM_64x64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
+    PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
 void prof_begin_impl(int cls, double work, hipStream_t s);
@@ -56,6 +57,7 @@ struct GemmArgs {
     int lda, ldb, ldc, ldr;
     int b_trans;            // 0: B is [K,N] (ldb >= N)   1: B is [N,K] (ldb >= K)
     int b_rows;             // valid rows of B (guards loads): K for NN, N for NT
+    int a_cols;             // valid columns of A (guards loads); 0 -> K
     int nbatch, nb1;        // batch z = z0 * nb1 + z1
     long long sA0, sA1, sB0, sB1, sC0, sC1;   // element strides per batch index
     int epilogue; float scale_div;
@@ -70,7 +72,9 @@ int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const
                            int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
                            float* x_out, float* y_out, hipStream_t s);
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
+constexpr int LNF_ROWS_PER_CHUNK = 16;
+size_t lnf_meanpool_scratch_floats(int B, int T, int d);
 int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
-                        float* hidden_out, float* pool_out, hipStream_t s);
+                        float* hidden_out, float* pool_out, float* scratch, hipStream_t s);
 
 }  // namespace r4d

@@ -2,6 +2,7 @@
 // everything enqueued on the caller's stream (graph-capturable).  See include/r4d.h for the contract.
 #include <math.h>
 #include <string.h>
+#include <vector>
 #include "common.h"
 
 namespace r4d {
@@ -52,16 +53,20 @@ static int attention(const float* qkv, int B, int T, int H, int d, float* a_out,
     g.b_trans = 0; g.b_rows = T; g.nbatch = B * H; g.nb1 = H;
     g.sA0 = (long long)H * T * ld; g.sA1 = (long long)T * ld;
     g.sB0 = (long long)T * 3 * d; g.sB1 = hd; g.sC0 = (long long)T * d; g.sC1 = hd;
+    g.a_cols = ld;
     g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_PV;
     return launch_gemm_f32(g, s);
 }
 
+struct Group {                 // one right-padded reference batch inside a fused launch sequence
+    const int64_t* ids; const float* emb; int B, T; size_t row0, seq0;
+};
+
 struct Workspace {
-    float *x, *ln, *qkv, *att, *fc, *scores;
+    float *x, *ln, *qkv, *att, *fc, *scores, *pool;
     size_t bytes;
 };
-static Workspace carve(void* base, int B, int T, int H, int d) {
-    const size_t M = (size_t)B * T;
+static Workspace carve(void* base, size_t M, size_t score_floats, size_t pool_floats, int d) {
     size_t off = 0;
     auto take = [&](size_t nfloat) {
         float* p = base ? (float*)((char*)base + off) : nullptr;
@@ -70,10 +75,12 @@ static Workspace carve(void* base, int B, int T, int H, int d) {
     };
     Workspace w;
     w.x = take(M * d); w.ln = take(M * d); w.qkv = take(M * 3 * d); w.att = take(M * d); w.fc = take(M * 4 * d);
-    w.scores = take((size_t)B * H * T * tpad(T));
+    w.scores = take(score_floats);
+    w.pool = take(pool_floats);
     w.bytes = off;
     return w;
 }
+static size_t score_floats(int B, int H, int T) { return (size_t)B * H * T * tpad(T); }
 
 static int check_cfg(const r4d_gpt2_config* c) {
     R4D_REQUIRE(c != nullptr, "gpt2: null config");
@@ -96,36 +103,75 @@ const char* r4d_last_error(void) { return g_err; }
 
 size_t r4d_gpt2_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B, int32_t T) {
     if (!cfg || B <= 0 || T <= 0) return 0;
-    return carve(nullptr, B, T, cfg->n_head, cfg->n_embd).bytes;
+    return carve(nullptr, (size_t)B * T, score_floats(B, cfg->n_head, T), lnf_meanpool_scratch_floats(B, T, cfg->n_embd),
+                 cfg->n_embd).bytes;
 }
 
-int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
-                        const float* inputs_embeds_d, int32_t B, int32_t T, float* out_hidden_d,
-                        float* out_meanpool_d, float* out_layers_d, float* out_qkv_d, void* workspace_d,
-                        size_t workspace_bytes, void* stream) {
+size_t r4d_gpt2_groups_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs,
+                                       const int32_t* Ts) {
+    if (!cfg || n_groups <= 0 || !Bs || !Ts) return 0;
+    size_t M = 0, sc = 0, pl = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (Bs[g] <= 0 || Ts[g] <= 0) return 0;
+        M += (size_t)Bs[g] * Ts[g];
+        const size_t f = score_floats(Bs[g], cfg->n_head, Ts[g]);
+        if (f > sc) sc = f;
+        const size_t p = lnf_meanpool_scratch_floats(Bs[g], Ts[g], cfg->n_embd);
+        if (p > pl) pl = p;
+    }
+    return carve(nullptr, M, sc, pl, cfg->n_embd).bytes;
+}
+
+}  // extern "C"
+
+namespace r4d {
+
+// The whole encoder over G right-padded batches.  Row-wise work (LayerNorm, the four Conv1D GEMMs per block)
+// runs ONCE over the concatenated rows of all batches -- a mean-pooled embedding depends on its own batch's
+// padding only through the attention / position / pooling steps, which stay per batch -- so a launch sees
+// G times more tiles and the GEMM tail (a CU holds ~3 tiles of a single 32 x T batch) amortises.
+static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const Group* groups, int n_groups,
+                       float* out_hidden_d, float* out_meanpool_d, float* out_layers_d, float* out_qkv_d,
+                       void* workspace_d, size_t workspace_bytes, hipStream_t s) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     R4D_REQUIRE(w && w->wte && w->wpe && w->ln_f_w && w->ln_f_b && w->layers, "gpt2: null weights");
-    R4D_REQUIRE((ids_d != nullptr) != (inputs_embeds_d != nullptr),
-                "gpt2: specify exactly one of input_ids and inputs_embeds");         // modeling_gpt2.py:400-401,409
-    R4D_REQUIRE(B >= 1 && T >= 1, "gpt2: empty batch B=%d T=%d", B, T);
-    R4D_REQUIRE(T <= cfg->n_positions && T <= 1024, "gpt2: T=%d exceeds n_positions=%d", T, cfg->n_positions);
     R4D_REQUIRE(out_hidden_d || out_meanpool_d, "gpt2: no output requested");
-    const int d = cfg->n_embd, H = cfg->n_head, M = B * T;
-    Workspace ws = carve(workspace_d, B, T, H, d);
+    const int d = cfg->n_embd, H = cfg->n_head;
+    size_t Mtot = 0, sc = 0, pl = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const Group& G = groups[g];
+        R4D_REQUIRE((G.ids != nullptr) != (G.emb != nullptr),
+                    "gpt2: specify exactly one of input_ids and inputs_embeds");     // modeling_gpt2.py:400-401,409
+        R4D_REQUIRE(G.B >= 1 && G.T >= 1, "gpt2: empty batch B=%d T=%d", G.B, G.T);
+        R4D_REQUIRE(G.T <= cfg->n_positions && G.T <= 1024, "gpt2: T=%d exceeds n_positions=%d", G.T, cfg->n_positions);
+        Mtot += (size_t)G.B * G.T;
+        const size_t f = score_floats(G.B, H, G.T);
+        if (f > sc) sc = f;
+        const size_t p = lnf_meanpool_scratch_floats(G.B, G.T, d);
+        if (p > pl) pl = p;
+    }
+    R4D_REQUIRE(Mtot <= 0x7fffffff / (size_t)(4 * d), "gpt2: %zu rows in one call is too many", Mtot);
+    const int M = (int)Mtot;
+    Workspace ws = carve(workspace_d, Mtot, sc, pl, d);
     if (!workspace_d || workspace_bytes < ws.bytes) {
         set_error("gpt2: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
         return R4D_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
     for (int l = 0; l < cfg->n_layer; ++l) {
         const r4d_gpt2_layer& L = w->layers[l];
         R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
                     "gpt2: null weight in layer %d", l);
-        if (l == 0) rc = launch_embed_layernorm(ids_d, inputs_embeds_d, w->wte, w->wpe, cfg->vocab, M, T, d, L.ln_1_w,
-                                                L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s);
-        else rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s);
-        if (rc) return rc;
+        if (l == 0) {
+            for (int g = 0; g < n_groups; ++g) {
+                const Group& G = groups[g];
+                rc = launch_embed_layernorm(G.ids, G.emb, w->wte, w->wpe, cfg->vocab, G.B * G.T, G.T, d, L.ln_1_w,
+                                            L.ln_1_b, cfg->ln_eps, ws.x + G.row0 * d, ws.ln + G.row0 * d, s);
+                if (rc) return rc;
+            }
+        } else if ((rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s))) {
+            return rc;
+        }
         if (out_layers_d &&
             hipMemcpyAsync(out_layers_d + (size_t)l * M * d, ws.x, (size_t)M * d * sizeof(float),
                            hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -134,13 +180,51 @@ int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, c
         }
         float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
         if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
-        if ((rc = attention(qkv, B, T, H, d, ws.att, ws.scores, s))) return rc;
+        for (int g = 0; g < n_groups; ++g) {
+            const Group& G = groups[g];
+            if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
+        }
         if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
         if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
         if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
     }
-    return launch_lnf_meanpool(ws.x, w->ln_f_w, w->ln_f_b, B, T, d, cfg->ln_eps, out_hidden_d, out_meanpool_d, s);
+    for (int g = 0; g < n_groups; ++g) {
+        const Group& G = groups[g];
+        rc = launch_lnf_meanpool(ws.x + G.row0 * d, w->ln_f_w, w->ln_f_b, G.B, G.T, d, cfg->ln_eps,
+                                 out_hidden_d ? out_hidden_d + G.row0 * d : nullptr,
+                                 out_meanpool_d ? out_meanpool_d + G.seq0 * d : nullptr, ws.pool, s);
+        if (rc) return rc;
+    }
+    return R4D_OK;
+}
+
+}  // namespace r4d
+
+extern "C" {
+
+int r4d_gpt2_encode_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                        const float* inputs_embeds_d, int32_t B, int32_t T, float* out_hidden_d,
+                        float* out_meanpool_d, float* out_layers_d, float* out_qkv_d, void* workspace_d,
+                        size_t workspace_bytes, void* stream) {
+    Group G = {ids_d, inputs_embeds_d, B, T, 0, 0};
+    return encode_impl(cfg, w, &G, 1, out_hidden_d, out_meanpool_d, out_layers_d, out_qkv_d, workspace_d,
+                       workspace_bytes, (hipStream_t)stream);
+}
+
+int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
+                               const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
+                               float* out_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream) {
+    R4D_REQUIRE(n_groups >= 1 && n_groups <= 4096 && ids_d && Bs && Ts, "gpt2 groups: bad arguments");
+    R4D_REQUIRE(out_meanpool_d, "gpt2 groups: out_meanpool_d is null");
+    std::vector<Group> gs((size_t)n_groups);
+    size_t row0 = 0, seq0 = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        gs[g] = Group{ids_d[g], nullptr, Bs[g], Ts[g], row0, seq0};
+        if (Bs[g] > 0 && Ts[g] > 0) { row0 += (size_t)Bs[g] * Ts[g]; seq0 += (size_t)Bs[g]; }
+    }
+    return encode_impl(cfg, w, gs.data(), n_groups, nullptr, out_meanpool_d, nullptr, nullptr, workspace_d,
+                       workspace_bytes, (hipStream_t)stream);
 }
 
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d, float* logits_d,

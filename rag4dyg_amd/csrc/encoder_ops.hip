@@ -146,19 +146,23 @@ int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStr
 }
 
 // hidden = ln_f(x) (modeling_gpt2.py:493) and/or pool[b,:] = mean over ALL T padded positions of hidden
-// (train_retriever.py:420).  One workgroup per sequence, 8 wavefronts striding over t; per-wave partial
-// sums are combined in a fixed order through LDS (deterministic).
-__global__ __launch_bounds__(512) void lnf_meanpool_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ b, int T, int d, float eps,
-                                                           float* __restrict__ hidden_out, float* __restrict__ pool_out) {
-    extern __shared__ float red[];                     // [8][d]
+// (train_retriever.py:420).  Two deterministic stages: (1) grid (S chunks of T, B): each workgroup layer-norms
+// its rows (one wavefront per row), sums them per wave in registers, combines its 4 waves through LDS in a
+// fixed order and writes one partial row; (2) one workgroup per sequence adds the S partials in order and
+// divides by T.  No atomics -> bitwise reproducible.
+__global__ __launch_bounds__(256) void lnf_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, int T, int d, float eps,
+                                                          int rows_per_chunk, float* __restrict__ hidden_out,
+                                                          float* __restrict__ partial) {
+    extern __shared__ float red[];                     // [4][d]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int bidx = blockIdx.x;
+    const int chunk = blockIdx.x, bidx = blockIdx.y, S = gridDim.x;
     const int nv = d >> 6;
+    const int t0 = chunk * rows_per_chunk, t1 = min(T, t0 + rows_per_chunk);
     float acc[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) acc[i] = 0.f;
-    for (int t = wid; t < T; t += 8) {
+    for (int t = t0 + wid; t < t1; t += 4) {
         const long long base = ((long long)bidx * T + t) * d;
         float v[MAXV];
 #pragma unroll
@@ -172,26 +176,43 @@ __global__ __launch_bounds__(512) void lnf_meanpool_kernel(const float* __restri
                 acc[i] += y;
             }
     }
-    if (!pool_out) return;
+    if (!partial) return;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) if (i < nv) red[wid * d + lane + 64 * i] = acc[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 512) {
+    for (int c = threadIdx.x; c < d; c += 256)
+        partial[((long long)bidx * S + chunk) * d + c] = (red[c] + red[d + c]) + (red[2 * d + c] + red[3 * d + c]);
+}
+
+__global__ __launch_bounds__(256) void meanpool_reduce_kernel(const float* __restrict__ partial, int S, int T, int d,
+                                                              float* __restrict__ pool_out) {
+    const int bidx = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k * d + c];
+        for (int k = 0; k < S; ++k) s += partial[((long long)bidx * S + k) * d + c];
         pool_out[(long long)bidx * d + c] = s / (float)T;
     }
 }
 
+size_t lnf_meanpool_scratch_floats(int B, int T, int d) { return (size_t)B * cdiv(T, LNF_ROWS_PER_CHUNK) * d; }
+
 int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
-                        float* hidden_out, float* pool_out, hipStream_t s) {
+                        float* hidden_out, float* pool_out, float* scratch, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "ln_f: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    R4D_REQUIRE(!pool_out || scratch, "ln_f: mean-pool needs scratch");
     if (B <= 0 || T <= 0) return R4D_OK;
-    ProfScope prof(PK_LNF_MEANPOOL, 4.0 * B * T * d * (hidden_out ? 2 : 1) + 4.0 * B * d, s);
-    hipLaunchKernelGGL(lnf_meanpool_kernel, dim3(B), dim3(512), 8 * d * sizeof(float), s, x, w, b, T, d, eps,
-                       hidden_out, pool_out);
-    R4D_CHECK_LAUNCH("lnf_meanpool");
+    const int S = cdiv(T, LNF_ROWS_PER_CHUNK);
+    {
+        ProfScope prof(PK_LNF_MEANPOOL, 4.0 * B * T * d * (hidden_out ? 2 : 1) + 4.0 * B * S * d, s);
+        hipLaunchKernelGGL(lnf_partial_kernel, dim3(S, B), dim3(256), 4 * d * sizeof(float), s, x, w, b, T, d, eps,
+                           LNF_ROWS_PER_CHUNK, hidden_out, pool_out ? scratch : nullptr);
+        R4D_CHECK_LAUNCH("lnf_partial");
+    }
+    if (pool_out) {
+        ProfScope prof(PK_MEANPOOL_REDUCE, 4.0 * B * S * d + 4.0 * B * d, s);
+        hipLaunchKernelGGL(meanpool_reduce_kernel, dim3(B), dim3(256), 0, s, scratch, S, T, d, pool_out);
+        R4D_CHECK_LAUNCH("meanpool_reduce");
+    }
     return R4D_OK;
 }
 

@@ -2,22 +2,26 @@
 //
 // Serves every dense contraction of the encoder: Conv1D (modeling_utils.py:1267-1271) c_attn / c_proj /
 // c_fc / mlp.c_proj with fused bias (+ gelu_new | + residual), the batched per-head Q.K^T / P.V of
-// Attention._attn (modeling_gpt2.py:141,159) with causal tile skipping, and the tied lm_head (B given
-// as [N,K]).  1e-4-relative-fp32 parity rules out bf16 inputs, so this is the f32-in/f32-acc MFMA
-// (157 TFLOP/s peak == the f32 vector peak, but one VGPR per operand and the VALU left free).
+// Attention._attn (modeling_gpt2.py:141,159) with causal tile skipping, the tied lm_head and the
+// query-vs-pool cosine scan (B given as [N,K]).  1e-4-relative-fp32 parity rules out bf16 inputs, so this
+// is the f32-in/f32-acc MFMA (157 TFLOP/s peak == the f32 vector peak, but one VGPR per operand and the
+// VALU left free for the epilogue).
 //
-// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 16, wave tile (BM/2) x (BN/2) built from
-// 32x32 MFMA tiles.  LDS images are k-major ([k][m] and [k][n]) so every fragment read is a
-// conflict-free ds_read_b32 over 32 consecutive banks; A (and B when given as [N,K]) is transposed on
-// the LDS write (2-way conflicts on ds_write_b32 are free).  Double-buffered LDS with the next tile's
-// global loads issued before the MFMA phase (one barrier per k-tile).
+// Tiling: 256 threads = 4 wavefronts (2x2); block tile BM x BN x BK, wave tile (BM/2) x (BN/2) made of
+// TM x TN 32x32 MFMA tiles.  LDS images are k-major ([k][m], [k][n]).  The rows (columns) of a wave tile
+// are INTERLEAVED over its MFMA tiles -- MFMA tile t owns rows TM*i + t -- so one lane's TM (TN) operands
+// for a k-step are adjacent in LDS and come from ONE conflict-free ds_read_b32/b64/b128, and the
+// epilogue stores TN adjacent columns per lane (256-512 B contiguous per row segment).  A (and B when
+// given as [N,K]) is transposed on the LDS write (2-way conflicts on ds_write_b32 are free).  LDS is
+// double-buffered and the next k-tile's global loads are issued before the MFMA phase (one barrier per
+// k-tile).  Tile shape is picked per launch by a wave-quantisation cost model (launch_gemm_f32).
+#include <stdlib.h>
 #include "common.h"
 
 namespace r4d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float gelu_new_f(float x) {
@@ -26,26 +30,64 @@ __device__ __forceinline__ float gelu_new_f(float x) {
     return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
 }
 
-template <int BM, int BN, bool BT>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BT ? BN + 4 : BN;
-    constexpr int NLA = BM * (BK / 4) / NTHREADS;                    // float4 loads per thread, A tile
-    constexpr int NLB = BN * (BK / 4) / NTHREADS;                    // same count for both B layouts
-    static_assert(NLA >= 1 && NLB >= 1, "tile too small");
-    __shared__ float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
+template <int N>
+struct FragLoad;
+template <>
+struct FragLoad<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = p[0]; }
+};
+template <>
+struct FragLoad<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct FragLoad<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
 
+// Shape / stride block passed by value; the POINTERS are separate kernel arguments so that the compiler
+// knows they are global (pointers inside a by-value struct are treated as generic -> flat_load, whose
+// out-of-order return couples every LDS wait to the global loads in flight).
+struct GemmShape {
+    int M, N, K, lda, ldb, ldc, ldr, b_rows, a_cols, nb1, epilogue, causal;
+    long long sA0, sA1, sB0, sB1, sC0, sC1;
+    float scale_div;
+};
+
+template <int BM, int BN, int BK, bool BT>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
+                                                            float* __restrict__ Cg, const float* __restrict__ biasg,
+                                                            const float* __restrict__ residg, const GemmShape g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LDA = BM + 2;                                      // even: keeps ds_read_b64 aligned
+    constexpr int LDB = BT ? BN + 2 : BN;
+    constexpr int KV = BK / 4;                                       // float4 per tile row
+    constexpr int NLA = BM * KV / NTHREADS;                          // float4 loads per thread, A tile
+    constexpr int NLB = BN * KV / NTHREADS;
+    static_assert(NLA >= 1 && NLB >= 1 && (TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4), "tile");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (bid % 8 = XCD group), each with
+    // its own 4 MB L2.  Remap so that an XCD walks a CONTIGUOUS range of tiles (n fastest): the workgroups
+    // that share one A row-panel then hit the same L2 instead of fetching it 8 times.  Bijective for any grid.
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.causal == CAUSAL_QK && n0 > m0 + BM - 1) return;           // tile strictly above the diagonal
 
     const int z0 = blockIdx.z / g.nb1, z1 = blockIdx.z % g.nb1;
-    const float* __restrict__ A = g.A + z0 * g.sA0 + z1 * g.sA1;
-    const float* __restrict__ B = g.B + z0 * g.sB0 + z1 * g.sB1;
-    float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
+    const float* __restrict__ A = Ag + z0 * g.sA0 + z1 * g.sA1;
+    const float* __restrict__ B = Bg + z0 * g.sB0 + z1 * g.sB1;
+    float* __restrict__ C = Cg + z0 * g.sC0 + z1 * g.sC1;
 
     int kend = g.K;
     if (g.causal == CAUSAL_PV) kend = min(g.K, m0 + BM);             // keys beyond the tile's last row are masked
@@ -55,52 +97,75 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmArgs g) {
     const int wm = wid >> 1, wn = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
 
+    // per-thread staging coordinates (loop-invariant).  Out-of-range rows/columns are CLAMPED to a valid
+    // address and the loaded value is zeroed afterwards: a `cond ? *p : 0` select makes hipcc pick between
+    // the global pointer and a zero constant in scratch, i.e. flat_load + vmcnt(0) right after the load.
+    const float* a_src[NLA]; bool a_ok[NLA]; int a_dst[NLA], a_k[NLA];
+#pragma unroll
+    for (int r = 0; r < NLA; ++r) {
+        const int idx = tid + r * NTHREADS, row = idx / KV, c4 = idx % KV;
+        a_ok[r] = (m0 + row) < g.M;
+        a_k[r] = 4 * c4;
+        a_src[r] = A + (long long)min(m0 + row, g.M - 1) * g.lda + 4 * c4;
+        a_dst[r] = (4 * c4) * LDA + row;
+    }
+    const float* b_src[NLB]; bool b_ok[NLB]; int b_dst[NLB], b_k[NLB];
+#pragma unroll
+    for (int r = 0; r < NLB; ++r) {
+        const int idx = tid + r * NTHREADS;
+        if (BT) {
+            const int row = idx / KV, c4 = idx % KV;
+            b_ok[r] = (n0 + row) < g.b_rows;
+            b_k[r] = 4 * c4;
+            b_src[r] = B + (long long)min(n0 + row, g.b_rows - 1) * g.ldb + 4 * c4;
+            b_dst[r] = (4 * c4) * LDB + row;
+        } else {
+            const int krow = idx / (BN / 4), c = idx % (BN / 4);
+            b_ok[r] = (n0 + 4 * c) < g.N;
+            b_k[r] = krow;
+            b_src[r] = B + (b_ok[r] ? n0 + 4 * c : 0);
+            b_dst[r] = krow * LDB + 4 * c;
+        }
+    }
     float4 ra[NLA], rb[NLB];
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int r = 0; r < NLA; ++r) {
-            const int idx = tid + r * NTHREADS, row = idx >> 2, c4 = idx & 3;
-            const int gm = m0 + row;
-            ra[r] = (gm < g.M) ? *reinterpret_cast<const float4*>(A + (long long)gm * g.lda + k0 + 4 * c4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int r = 0; r < NLB; ++r) {
-            const int idx = tid + r * NTHREADS;
-            if (BT) {
-                const int row = idx >> 2, c4 = idx & 3, gn = n0 + row;
-                rb[r] = (gn < g.b_rows) ? *reinterpret_cast<const float4*>(B + (long long)gn * g.ldb + k0 + 4 * c4)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int krow = idx / (BN / 4), c = idx % (BN / 4);
-                const int gk = k0 + krow, gn = n0 + 4 * c;
-                rb[r] = (gk < g.b_rows && gn < g.N)
-                            ? *reinterpret_cast<const float4*>(B + (long long)gk * g.ldb + gn)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < NLA; ++r) {
-            const int idx = tid + r * NTHREADS, row = idx >> 2, c4 = idx & 3;
-            float* p = &As[buf][(4 * c4) * LDA + row];
-            p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;
-        }
-#pragma unroll
-        for (int r = 0; r < NLB; ++r) {
-            const int idx = tid + r * NTHREADS;
-            if (BT) {
-                const int row = idx >> 2, c4 = idx & 3;
-                float* p = &Bs[buf][(4 * c4) * LDB + row];
-                p[0] = rb[r].x; p[LDB] = rb[r].y; p[2 * LDB] = rb[r].z; p[3 * LDB] = rb[r].w;
-            } else {
-                const int krow = idx / (BN / 4), c = idx % (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[buf][krow * LDB + 4 * c]) = rb[r];
-            }
-        }
-    };
+
+#define R4D_ZERO_UNLESS(V, OK) { if (!(OK)) { V.x = 0.f; V.y = 0.f; V.z = 0.f; V.w = 0.f; } }
+#define R4D_LOAD_TILES(KT)                                                                                         \
+    {                                                                                                              \
+        const int k0_ = (KT) * BK;                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
+            const bool ok_ = a_ok[r] && (k0_ + a_k[r] < g.a_cols);                                                 \
+            ra[r] = *reinterpret_cast<const float4*>(a_src[r] + ((k0_ + a_k[r] < g.a_cols) ? k0_ : 0));            \
+            R4D_ZERO_UNLESS(ra[r], ok_)                                                                            \
+        }                                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
+            if (BT) {                                                                                              \
+                const bool ok_ = b_ok[r] && (k0_ + b_k[r] < g.K);                                                  \
+                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + ((k0_ + b_k[r] < g.K) ? k0_ : 0));             \
+                R4D_ZERO_UNLESS(rb[r], ok_)                                                                        \
+            } else {                                                                                               \
+                const int gk_ = k0_ + b_k[r];                                                                      \
+                const bool ok_ = b_ok[r] && (gk_ < g.b_rows);                                                      \
+                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (long long)min(gk_, g.b_rows - 1) * g.ldb);    \
+                R4D_ZERO_UNLESS(rb[r], ok_)                                                                        \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+#define R4D_STORE_TILES(BUF)                                                                                       \
+    {                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
+            float* p = &As[BUF][a_dst[r]];                                                                         \
+            p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;                          \
+        }                                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
+            if (BT) {                                                                                              \
+                float* p = &Bs[BUF][b_dst[r]];                                                                     \
+                p[0] = rb[r].x; p[LDB] = rb[r].y; p[2 * LDB] = rb[r].z; p[3 * LDB] = rb[r].w;                      \
+            } else {                                                                                               \
+                *reinterpret_cast<float4*>(&Bs[BUF][b_dst[r]]) = rb[r];                                            \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -110,78 +175,169 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
+    R4D_LOAD_TILES(0)
+    R4D_STORE_TILES(0)
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kt + 1);                        // in flight under the MFMA phase
-        const float* as = &As[cur][wm * WM + li];
-        const float* bs = &Bs[cur][wn * WN + li];
+        const bool more = kt + 1 < nkt;
+        if (more) R4D_LOAD_TILES(kt + 1)                             // in flight under the MFMA phase
+        const float* as = &As[cur][wm * WM + TM * li];
+        const float* bs = &Bs[cur][wn * WN + TN * li];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lh) * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lh) * LDB + j * 32];
+            FragLoad<TM>::ld(as + (2 * kk + lh) * LDA, a);
+            FragLoad<TN>::ld(bs + (2 * kk + lh) * LDB, b);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+        if (more) R4D_STORE_TILES(cur ^ 1)
         __syncthreads();
     }
+#undef R4D_LOAD_TILES
+#undef R4D_ZERO_UNLESS
+#undef R4D_STORE_TILES
 
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue.  MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); with the interleave
+    // the wave-tile row is TM*row + i and the wave-tile column TN*col + j.
+    const int col0 = n0 + wn * WN + TN * li;
+    float bias[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + li;
-        if (col >= g.N) continue;
-        const float bias = g.bias ? g.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j) bias[j] = (biasg && col0 + j < g.N) ? biasg[col0 + j] : 0.f;
+    const bool full_cols = col0 + TN - 1 < g.N;
+    const bool vec_ok = (TN > 1) && full_cols && (g.ldc % TN == 0) && (g.epilogue != EPI_RESIDUAL || g.ldr % TN == 0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+        float res[16][TN];
+        if (g.epilogue == EPI_RESIDUAL) {
+            // all 16 residual loads issued back to back from clamped (always valid) addresses
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (g.epilogue == EPI_GELU) v = gelu_new_f(v);
-                else if (g.epilogue == EPI_RESIDUAL) v += g.resid[(long long)row * g.ldr + col];
-                else if (g.epilogue == EPI_SCALE_DIV) v = v / g.scale_div;
-                else if (g.epilogue == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
-                C[(long long)row * g.ldc + col] = v;
+                const int row = min(m0 + wm * WM + TM * ((r & 3) + 8 * (r >> 2) + 4 * lh) + i, g.M - 1);
+                const float* rp = residg + (long long)row * g.ldr;
+                if (TN == 2 && vec_ok) {
+                    const float2 t = *reinterpret_cast<const float2*>(rp + col0);
+                    res[r][0] = t.x; res[r][1 % TN] = t.y;
+                } else if (TN == 4 && vec_ok) {
+                    const float4 t = *reinterpret_cast<const float4*>(rp + col0);
+                    res[r][0] = t.x; res[r][1 % TN] = t.y; res[r][2 % TN] = t.z; res[r][3 % TN] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) res[r][j] = rp[min(col0 + j, g.N - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WM + TM * ((r & 3) + 8 * (r >> 2) + 4 * lh) + i;
+            float v[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r] + bias[j];
+            if (g.epilogue == EPI_GELU) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = gelu_new_f(v[j]);
+            } else if (g.epilogue == EPI_RESIDUAL) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] += res[r][j];
+            } else if (g.epilogue == EPI_SCALE_DIV) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = v[j] / g.scale_div;
+            } else if (g.epilogue == EPI_HALF_PLUS) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = (v[j] + 1.0f) / 2.0f;
+            }
+            if (row < g.M) {
+                float* cp = C + (long long)row * g.ldc + col0;
+                if (TN == 2 && vec_ok) *reinterpret_cast<float2*>(cp) = make_float2(v[0], v[1 % TN]);
+                else if (TN == 4 && vec_ok) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1 % TN], v[2 % TN], v[3 % TN]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) if (col0 + j < g.N) cp[j] = v[j];
+                }
             }
         }
     }
 }
 
-template <int BM, int BN>
-static int launch_variant(const GemmArgs& g, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------- dispatch
+struct TileCfg { int bm, bn, cls, blocks_per_cu; double eff; };
+// eff = steady-state fraction of the f32 MFMA peak measured for the tile on a saturating grid
+// (tools/gemm_bench.py, MI355X); used only to rank tiles in the cost model below.  All tiles use BK = 32:
+// half the barriers of BK = 16 and full 128-byte lines per A row (+3-5 % measured).
+static const TileCfg kTiles[] = {
+    {128, 128, PK_GEMM_128x128_NN, 2, 0.80},
+    {128, 64, PK_GEMM_128x64_NN, 4, 0.76},
+    {64, 64, PK_GEMM_64x64_NN, 6, 0.72},
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+constexpr int BKT = 32;
+
+template <int BM, int BN, int BK>
+static int launch_variant(const GemmArgs& g, int cls, hipStream_t stream) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     dim3 grid(tiles, 1, g.nbatch);
     // algorithmic flop: 2MNK dense; the causal launches count only the lower-triangular half
     const double flop = (g.causal ? 1.0 : 2.0) * (double)g.M * g.N * g.K * g.nbatch;
-    ProfScope prof((BM == 128 ? PK_GEMM_128_NN : PK_GEMM_64_NN) + (g.b_trans ? 1 : 0), flop, stream);
-    if (g.b_trans) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true>), grid, dim3(NTHREADS), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false>), grid, dim3(NTHREADS), 0, stream, g);
+    ProfScope prof(cls + (g.b_trans ? 1 : 0), flop, stream);
+    GemmShape sh;
+    sh.M = g.M; sh.N = g.N; sh.K = g.K; sh.lda = g.lda; sh.ldb = g.ldb; sh.ldc = g.ldc; sh.ldr = g.ldr;
+    sh.b_rows = g.b_rows; sh.a_cols = g.a_cols; sh.nb1 = g.nb1; sh.epilogue = g.epilogue; sh.causal = g.causal;
+    sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
+    sh.scale_div = g.scale_div;
+    if (g.b_trans)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
+                           g.resid, sh);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
+                           g.resid, sh);
     R4D_CHECK_LAUNCH("gemm_f32");
     return R4D_OK;
 }
 
-int launch_gemm_f32(const GemmArgs& g, hipStream_t stream) {
+// Cost model.  Every CU executes ceil(blocks/256) tiles, `conc` of them concurrently; a SIMD needs about three
+// resident wavefronts to keep its MFMA pipe fed (measured: one 4-wave workgroup alone on a CU reaches about a
+// third of the steady-state rate), hence the occupancy factor.
+static int pick_tile(const GemmArgs& g) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("R4D_GEMM_TILE");      // tuning aid: 0..2 forces a tile shape
+        forced = e ? atoi(e) : -1;
+    }
+    if (forced >= 0 && forced < kNumTiles) return forced;
+    int best = kNumTiles - 1;
+    double best_cost = 1e300;
+    for (int t = 0; t < kNumTiles; ++t) {
+        const TileCfg& c = kTiles[t];
+        long long blocks = (long long)cdiv(g.M, c.bm) * cdiv(g.N, c.bn) * g.nbatch;
+        if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(g.M, c.bm) * g.nbatch / 2;   // lower triangle
+        const long long per_cu = (blocks + 255) / 256;
+        const double conc = (double)(per_cu < c.blocks_per_cu ? per_cu : c.blocks_per_cu);
+        const double eff = c.eff * (conc >= 3.0 ? 1.0 : conc / 3.0);
+        const double cost = (double)per_cu * c.bm * c.bn / eff;
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
+int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {
+    GemmArgs g = g0;
     R4D_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
     R4D_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 (got %d,%d)", g.lda, g.ldb);
-    R4D_REQUIRE(g.causal == CAUSAL_PV || g.K % BK == 0, "gemm: K=%d must be a multiple of %d", g.K, BK);
+    R4D_REQUIRE(g.causal == CAUSAL_PV || g.K % 4 == 0, "gemm: K=%d must be a multiple of 4", g.K);
     R4D_REQUIRE(g.b_trans || g.N % 4 == 0, "gemm: N=%d must be a multiple of 4 for row-major B", g.N);
     R4D_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: A/B must be 16-byte aligned");
-    // Tile choice: big tiles when they still give >= ~2 waves of workgroups over 256 CUs, else 64x64.
-    const long long big = (long long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.nbatch;
-    if (big >= 512 && g.N >= 128) return launch_variant<128, 128>(g, stream);
-    return launch_variant<64, 64>(g, stream);
+    if (g.a_cols <= 0) g.a_cols = g.K;
+    const int t = pick_tile(g);
+    switch (t) {
+        case 0: return launch_variant<128, 128, BKT>(g, kTiles[0].cls, stream);
+        case 1: return launch_variant<128, 64, BKT>(g, kTiles[1].cls, stream);
+        default: return launch_variant<64, 64, BKT>(g, kTiles[2].cls, stream);
+    }
 }
 
 }  // namespace r4d

@@ -240,6 +240,31 @@ class GPT2Model(_PreTrained):
         out.update(hidden=hidden, meanpool=pool, layers=layers, qkv=qkv)
         return out
 
+    @torch.no_grad()
+    def encode_groups_meanpool(self, batches):
+        """Mean-pooled embeddings of several right-padded batches in one fused launch sequence
+        (``r4d_gpt2_encode_groups_f32``): values identical to encoding each batch on its own."""
+        if not batches:
+            raise ValueError("encode_groups_meanpool: no batches")
+        ids = []
+        for b in batches:
+            if not b.is_cuda:
+                raise _lib.R4DError("rag4dyg_amd runs on the GPU only: move inputs to 'cuda' (no CPU fallback)")
+            ids.append(b.view(-1, b.shape[-1]).to(torch.int64).contiguous())
+        n = len(ids)
+        dev = ids[0].device
+        lib = _lib.load()
+        c, w, _keep = self._c_structs()
+        Bs = (ctypes.c_int32 * n)(*[int(t.shape[0]) for t in ids])
+        Ts = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in ids])
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ids])
+        ws = ops.workspace(lib.r4d_gpt2_groups_workspace_bytes(ctypes.byref(c), n, Bs, Ts), dev, "gpt2")
+        out = torch.empty(sum(int(t.shape[0]) for t in ids), self.config.n_embd, dtype=torch.float32, device=dev)
+        _lib.check(lib.r4d_gpt2_encode_groups_f32(ctypes.byref(c), ctypes.byref(w), n, ptrs, Bs, Ts, out.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "gpt2_encode_groups")
+        return out
+
     def _presents(self, qkv):
         """``present = stack(k^T^T, v)`` per layer, [2,B,H,T,hd] (``modeling_gpt2.py:187``), as views of c_attn output."""
         L, B, T, d3 = qkv.shape
@@ -323,6 +348,11 @@ class GPT2LMHeadModelRAG(_LMHeadBase):
                 head_mask=None, inputs_embeds=None, labels=None):
         return self._lm(input_ids, labels, inputs_embeds, past=past, attention_mask=attention_mask,
                         token_type_ids=token_type_ids, position_ids=position_ids, head_mask=head_mask)
+
+    @torch.no_grad()
+    def encode_groups_meanpool(self, batches):
+        """Several reference batches in one fused launch sequence; same values as ``encode_meanpool`` per batch."""
+        return self.transformer.encode_groups_meanpool(batches)
 
     @torch.no_grad()
     def encode_meanpool(self, input_ids):

@@ -22,10 +22,26 @@ def right_pad_batches(examples, batch_size, pad_id, device):
     return out
 
 
+MAX_FUSED_ROWS = 65536          # token rows per fused launch sequence (bounds the workspace: ~20 KB per row at d=512)
+
+
 @torch.no_grad()
-def encode_batches(model, batches):
-    """HOT LOOP 1/2: mean-pooled embeddings of every batch, concatenated (``train_retriever.py:414-422,430-432``)."""
-    return torch.cat([model.encode_meanpool(b) for b in batches], dim=0)
+def encode_batches(model, batches, max_rows=MAX_FUSED_ROWS):
+    """HOT LOOP 1/2: mean-pooled embeddings of every batch, concatenated (``train_retriever.py:414-422,430-432``).
+
+    Consecutive batches are handed to the library in fused groups of up to ``max_rows`` token rows; every batch
+    keeps its own padding, so the values equal the one-batch-per-call reference loop."""
+    out, group, rows = [], [], 0
+    for b in batches:
+        r = b.shape[0] * b.shape[1]
+        if group and rows + r > max_rows:
+            out.append(model.encode_groups_meanpool(group))
+            group, rows = [], 0
+        group.append(b)
+        rows += r
+    if group:
+        out.append(model.encode_groups_meanpool(group))
+    return torch.cat(out, dim=0)
 
 
 class PoolIndex:

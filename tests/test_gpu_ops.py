@@ -157,6 +157,20 @@ def test_encoder_g3_config_shapes(dev, name):
         assert rel_err(logits[:, [0, T - 1], :256].cpu().numpy(), g["logits_rows"]) < TOL
 
 
+def test_fused_groups_equal_one_batch_per_call(dev):
+    """r4d_gpt2_encode_groups_f32 == r4d_gpt2_encode_f32 per batch, bit for bit (batches keep their own padding)."""
+    from oracle import gpt2_ref
+    sd = gpt2_ref.make_state_dict(2, 128, 50, n_positions=64, seed=5, random_affine=True)
+    m = build_model(sd, 2, 2, 128, 50, 64, dev)
+    g = torch.Generator().manual_seed(2)
+    batches = [torch.randint(0, 50, (B, T), generator=g).to(dev) for B, T in ((32, 17), (32, 64), (5, 3), (1, 1), (32, 40))]
+    fused = m.encode_groups_meanpool(batches)
+    single = torch.cat([m.encode_meanpool(b) for b in batches], dim=0)
+    assert fused.shape == (102, 128) and torch.equal(fused, single)
+    ref = torch.cat([gpt2_ref.gpt2_forward(sd, b.cpu(), 2, want_logits=False)["hidden"].mean(dim=1) for b in batches])
+    assert rel_err(fused.cpu().numpy(), ref.numpy()) < 1e-5
+
+
 def test_encoder_errors_are_loud(dev):
     from oracle import gpt2_ref
     from rag4dyg_amd._lib import R4DError
