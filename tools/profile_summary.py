@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense tools/profile_bench.sh output into the small files committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(repo, "gpurun_out", f"profiles_{tag}")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "").replace("r4d::", "")
+    return name.split("(")[0][:70]
+
+
+stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats[0]))) if stats else []
+with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline\n")
+    f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+    for r in rows:
+        f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
+                f"{r['MinNs']},{r['MaxNs']}\n")
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc_*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as f:
+    f.write("# per-dispatch means; FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+            "(gfx950: FETCH_SIZE reads half of a wide coalesced stream, MI355X_MICROARCH.md section HBM)\n")
+    f.write("kernel,counter,mean,dispatches\n")
+    for k, cs in sorted(agg.items()):
+        for c, v in sorted(cs.items()):
+            f.write(f"\"{k}\",{c},{sum(v) / len(v):.1f},{len(v)}\n")
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+            traffic[k] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_kib_raw": fe, "write_kib": wr}
+            if "TCC_HIT_sum" in cs:
+                h, m = sum(cs["TCC_HIT_sum"]), sum(cs["TCC_MISS_sum"])
+                traffic[k]["l2_hit_rate"] = h / max(h + m, 1)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
+                busy = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])
+                act = sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
+                traffic[k]["mfma_pipe_util"] = busy / 1024.0 / (act / 8.0)       # 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
+
+
+def bench_class(k):
+    """rocprof kernel name -> bench.py / r4d_profile_class_name class."""
+    import re
+    m = re.match(r"gemm_f32_kernel<(\d+), (\d+), \d+, (false|true)>", k)
+    if m:
+        return f"gemm_f32_{m.group(1)}x{m.group(2)}_{'nt' if m.group(3) == 'true' else 'nn'}"
+    return {"ln_kernel<false>": "layernorm", "ln_kernel<true>": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
+            "lnf_partial_kernel": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce",
+            "normalize_rows_kernel": "normalize_rows", "topk_seg_kernel<float>": "topk_seg",
+            "merge_topk_kernel": "merge_topk", "jaccard_lds_kernel": "jaccard"}.get(k, k)
+
+
+traffic = {bench_class(k): v for k, v in traffic.items() if not k.startswith(("at::", "__amd"))}
+json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
+print(json.dumps(traffic, indent=1)[:3000])
