@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
     PK_GEMM_64x64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
-    PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
+    PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
 void prof_begin_impl(int cls, double work, hipStream_t s);

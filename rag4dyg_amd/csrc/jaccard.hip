@@ -16,7 +16,7 @@ namespace r4d {
 
 constexpr int JAC_MAX_VOCAB_LDS = 19456;           // 8 B * 19456 = 152 KB
 
-__global__ __launch_bounds__(256) void jaccard_lds_kernel(const int32_t* __restrict__ a_ptr,
+__global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __restrict__ a_ptr,
                                                           const int32_t* __restrict__ a_idx, int na,
                                                           const int32_t* __restrict__ b_ptr,
                                                           const int32_t* __restrict__ b_idx, int nb, int vocab,
@@ -24,9 +24,10 @@ __global__ __launch_bounds__(256) void jaccard_lds_kernel(const int32_t* __restr
     extern __shared__ unsigned long long mask[];    // [vocab]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col0 = blockIdx.x * 64;
-    for (int t = tid; t < vocab; t += 256) mask[t] = 0ull;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    for (int t = tid; t < vocab; t += nthreads) mask[t] = 0ull;
     __syncthreads();
-    {   // scatter the 64 B-sets of this tile: 4 threads per set
+    if (tid < 256) {   // scatter the 64 B-sets of this tile: 4 threads per set
         const int j = tid >> 2, sub = tid & 3, col = col0 + j;
         if (col < nb) {
             const int s = b_ptr[col], e = b_ptr[col + 1];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void jaccard_lds_kernel(const int32_t* __restr
     const int lb = (col < nb) ? (b_ptr[col + 1] - b_ptr[col]) : 0;
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(na, row_begin + rows_per_block);
-    for (int i = row_begin + wid; i < row_end; i += 4) {
+    for (int i = row_begin + wid; i < row_end; i += nwaves) {
         const int s = a_ptr[i], e = a_ptr[i + 1];      // wave-uniform
         const int la = e - s;
         int cnt = 0;
@@ -120,7 +121,9 @@ extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, i
                 raised = true;
             }
         }
-        hipLaunchKernelGGL(jaccard_lds_kernel, dim3(col_tiles, chunks), dim3(256), lds, s, a_ptr_d, a_idx_d, na,
+        // a big table leaves room for one workgroup per CU only: give it 16 wavefronts instead of 4
+        const int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
+        hipLaunchKernelGGL(jaccard_lds_kernel, dim3(col_tiles, chunks), dim3(threads), lds, s, a_ptr_d, a_idx_d, na,
                            b_ptr_d, b_idx_d, nb, vocab, zero_diag, rows_per_block, out_d);
         R4D_CHECK_LAUNCH("jaccard_lds");
     } else {

@@ -22,6 +22,110 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     for (int c = lane; c < d; c += 64) out[(long long)row * d + c] = p[c] / nrm;
 }
 
+// ------------------------------------------------------------------------------------ pool scan (Q <= 64)
+// S[q, n] = (q_hat[q] . pool_hat[n] + 1) / 2 for one block of <= 32 queries against the whole pool shard:
+// train_retriever.py:437-438 at the reference's query batch (32).  At Q_b = 32 the scan is HBM-READ bound
+// (16 flop per pool byte), so the kernel is built around streaming pool_hat exactly once:
+//   * the 32 normalised queries sit in LDS k-major (Qs[k][q], d*132 B) for the whole kernel; an MFMA A operand
+//     is one conflict-free ds_read_b32 (row stride 33 floats; 12 % of the LDS read rate at full MFMA issue);
+//   * every wavefront owns whole 32-row pool tiles and the full d, so there is no cross-wave reduction and no
+//     barrier in the loop; lane (j, h) streams row j of its tile with 16-byte global loads (k permuted
+//     identically on both operands: component c of load s is k = 8s + 4h + c), 8 loads = 8 KB per wave in flight;
+//   * exact-f32 MFMA 32x32x2 accumulates S[32 q x 32 rows]; the epilogue applies (x+1)/2 and writes 128-byte
+//     row segments of the score matrix, from which topk_seg_kernel selects.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+constexpr int SCAN_U = 8;
+
+constexpr int SCAN_LDQ = 33;                          // Qs row stride: conflict-free fill AND fragment reads
+
+__global__ __launch_bounds__(256) void pool_scan_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
+                                                        int Q, int N, int d, float* __restrict__ scores) {
+    extern __shared__ float Qs[];                       // [d][33]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.y * 32;
+    for (int q = 0; q < 32; ++q) {
+        const bool ok = q0 + q < Q;
+        const float* src = qhat + (long long)min(q0 + q, Q - 1) * d;
+        for (int k = tid; k < d; k += 256) {
+            const float v = src[k];
+            Qs[k * SCAN_LDQ + q] = ok ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    const int ntiles = (N + 31) / 32;
+    const int nsteps = d / 8;
+    for (int t = blockIdx.x * 4 + wid; t < ntiles; t += gridDim.x * 4) {
+        const int row = t * 32 + li;
+        const float4* __restrict__ prow =
+            reinterpret_cast<const float4*>(pool + (long long)min(row, N - 1) * d) + lh;     // clamped: always valid
+        f32x16s acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // loads are unconditional from clamped indices (a `cond ? *p : 0` select would become a flat load of a
+        // scratch zero); out-of-range steps are skipped by the wave-uniform guards around the MFMAs
+        float4 b0[SCAN_U], b1[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) b0[u] = prow[2 * min(u, nsteps - 1)];
+        for (int s0 = 0; s0 < nsteps; s0 += 2 * SCAN_U) {
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) b1[u] = prow[2 * min(s0 + SCAN_U + u, nsteps - 1)];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) {
+                if (s0 + u < nsteps) {
+                    const float* qa = Qs + (8 * (s0 + u) + 4 * lh) * SCAN_LDQ + li;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b0[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b0[u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b0[u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[3 * SCAN_LDQ], b0[u].w, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) b0[u] = prow[2 * min(s0 + 2 * SCAN_U + u, nsteps - 1)];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) {
+                if (s0 + SCAN_U + u < nsteps) {
+                    const float* qa = Qs + (8 * (s0 + SCAN_U + u) + 4 * lh) * SCAN_LDQ + li;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b1[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b1[u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b1[u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[3 * SCAN_LDQ], b1[u].w, acc, 0, 0, 0);
+                }
+            }
+        }
+        if (row < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (q < Q) scores[(long long)q * N + row] = (acc[r] + 1.0f) / 2.0f;
+            }
+        }
+    }
+}
+
+static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, int d, float* scores, hipStream_t s) {
+    const size_t lds = (size_t)d * SCAN_LDQ * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)pool_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    140 * 1024) != hipSuccess) {
+                set_error("pool_scan: cannot raise dynamic LDS limit");
+                return R4D_ERR_HIP;
+            }
+            raised = true;
+        }
+    }
+    const int ntiles = cdiv(N, 32);
+    const int blocks_per_cu = lds > 80 * 1024 ? 1 : 2;
+    const int gx = max(1, min(cdiv(ntiles, 4), 256 * blocks_per_cu));
+    // algorithmic bytes (SURVEY 8d B_score): pool read once + queries + score rows out
+    ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
+    hipLaunchKernelGGL(pool_scan_kernel, dim3(gx, cdiv(Q, 32)), dim3(256), lds, s, qhat, pool, Q, N, d, scores);
+    R4D_CHECK_LAUNCH("pool_scan");
+    return R4D_OK;
+}
+
 // ------------------------------------------------------------------------------------ top-k machinery
 // Candidate order == np.argsort(-x, kind='stable'): larger score first, ties by smaller index.  NaN
 // sorts last (as in numpy).
@@ -251,7 +355,7 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
                        int64_t index_offset, float* out_val_d, int64_t* out_idx_d, float* out_scores_d,
                        void* workspace_d, size_t workspace_bytes, void* stream) {
     R4D_REQUIRE(q_hat_d && pool_hat_d && out_val_d && out_idx_d, "score_topk: null pointer");
-    R4D_REQUIRE(Q >= 1 && N >= 1 && d >= 16 && d % 16 == 0, "score_topk: bad shape Q=%d N=%d d=%d", Q, N, d);
+    R4D_REQUIRE(Q >= 1 && N >= 1 && d >= 4 && d % 4 == 0, "score_topk: bad shape Q=%d N=%d d=%d", Q, N, d);
     R4D_REQUIRE(k >= 1 && k <= 64 && k <= N, "score_topk: k=%d must be in [1, min(64, N=%d)]", k, N);
     if (!workspace_d || workspace_bytes < r4d_score_topk_workspace_bytes(Q, N, k)) {
         set_error("score_topk: workspace too small");
@@ -260,12 +364,17 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
     hipStream_t s = (hipStream_t)stream;
     float* scores = out_scores_d ? out_scores_d : (float*)workspace_d;
     char* ws = (char*)workspace_d + align_up((size_t)Q * N * sizeof(float), 256);
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = q_hat_d; g.B = pool_hat_d; g.C = scores;
-    g.M = Q; g.N = N; g.K = d; g.lda = d; g.ldb = d; g.ldc = N;
-    g.b_trans = 1; g.b_rows = N; g.nbatch = 1; g.nb1 = 1; g.epilogue = EPI_HALF_PLUS; g.scale_div = 1.f;
-    int rc = launch_gemm_f32(g, s);
+    int rc;
+    if (Q <= 64 && d % 8 == 0 && d <= 1024) {
+        rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, s);         // HBM-bound regime: stream the pool once
+    } else {
+        GemmArgs g;                                                             // MFMA-bound regime: tiled GEMM
+        memset(&g, 0, sizeof(g));
+        g.A = q_hat_d; g.B = pool_hat_d; g.C = scores;
+        g.M = Q; g.N = N; g.K = d; g.lda = d; g.ldb = d; g.ldc = N;
+        g.b_trans = 1; g.b_rows = N; g.nbatch = 1; g.nb1 = 1; g.epilogue = EPI_HALF_PLUS; g.scale_div = 1.f;
+        rc = launch_gemm_f32(g, s);
+    }
     if (rc) return rc;
     return topk_rows<float>(scores, Q, N, N, k, index_offset, out_val_d, (long long*)out_idx_d, ws,
                             workspace_bytes - align_up((size_t)Q * N * sizeof(float), 256), s);

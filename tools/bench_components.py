@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Secondary measurements (GPU box): the HBM-bound kernels of the path on their own rooflines.
+
+  scan      (S+1)/2 cosine scan at the reference query batch (32) over N pool rows + top-10
+  jaccard   f64 Jaccard matrices: real hepth/11 sets (golden fixture) and a synthetic 20k x 20k scale-up
+  pool      pool-encode sequences/s (reference batching, fused groups)
+Each line: achieved = algorithmic bytes / HIP-event time of the kernel class (r4d_profile_* hooks), peak 8 TB/s.
+CPU baselines: oracle single-thread python-set Jaccard (as retrieval_data_annotation.py:36-41) on a bounded sample.
+"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from rag4dyg_amd import _lib, ops, synth                                   # noqa: E402
+
+PEAK = 8000.0
+dev = torch.device("cuda:0")
+lib = _lib.load()
+
+
+def profile(fn, reps):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    lib.r4d_profile_enable(1)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    out = {}
+    for c in range(lib.r4d_profile_num_classes()):
+        ms, n, w = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        lib.r4d_profile_read(c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
+        if n.value:
+            out[lib.r4d_profile_class_name(c).decode()] = dict(us=1e3 * ms.value / n.value, launches=n.value // reps,
+                                                              gbs=w.value / (ms.value * 1e-3) / 1e9, work=w.value / n.value)
+    lib.r4d_profile_enable(0)
+    return wall, out
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def scan():
+    for N in (12500, 100000):
+        d, Q, k = 512, 32, 10
+        g = torch.Generator().manual_seed(1)
+        q = ops.normalize_rows(torch.randn(Q, d, generator=g).to(dev))
+        p = ops.normalize_rows(torch.randn(N, d, generator=g).to(dev))
+        wall, pr = profile(lambda: ops.score_topk(q, p, k), 50)
+        s = pr["pool_scan"]
+        emit(component="scan", N=N, d=d, Q=Q, k=k, wall_us=round(wall * 1e6, 1), kernel="pool_scan",
+             kernel_us=round(s["us"], 2), algorithmic_bytes=s["work"],
+             roofline={"bound": "hbm", "achieved": round(s["gbs"], 1), "peak": PEAK, "unit": "GB/s",
+                       "frac": round(s["gbs"] / PEAK, 4)},
+             topk_us=round(sum(v["us"] * v["launches"] for n, v in pr.items() if n == "topk_seg"), 2),
+             queries_per_s_scan_only=round(Q / wall, 1))
+
+
+def jaccard():
+    from oracle import jaccard_ref
+    g = np.load(os.path.join(REPO, "tests", "golden", "g5_jaccard_hepth.npz"))
+    vocab = len(g["vocab_tokens"])
+    t = {k: torch.from_numpy(g[k]).to(dev) for k in ("tr_out_ptr", "tr_out_idx", "tr_in_ptr", "tr_in_idx", "te_out_ptr", "te_out_idx")}
+    cases = [("hepth train_out x train_out", "tr_out", "tr_out", True), ("hepth train_in x train_in", "tr_in", "tr_in", True),
+             ("hepth test_out x train_out", "te_out", "tr_out", False)]
+    for name, a, b, zd in cases:
+        na, nb = t[a + "_ptr"].numel() - 1, t[b + "_ptr"].numel() - 1
+        wall, pr = profile(lambda: ops.jaccard(t[a + "_ptr"], t[a + "_idx"], t[b + "_ptr"], t[b + "_idx"], vocab, zd), 20)
+        j = pr["jaccard"]
+        emit(component="jaccard", case=name, pairs=na * nb, kernel_us=round(j["us"], 2), pairs_per_s=round(na * nb / (j["us"] * 1e-6)),
+             roofline={"bound": "hbm", "achieved": round(j["gbs"], 1), "peak": PEAK, "unit": "GB/s", "frac": round(j["gbs"] / PEAK, 4)})
+    # CPU baseline: the reference's single-thread double loop on a bounded sample of the same sets
+    lists = [g["tr_out_idx"][g["tr_out_ptr"][i]:g["tr_out_ptr"][i + 1]].tolist() for i in range(len(g["tr_out_ptr"]) - 1)]
+    t0 = time.perf_counter()
+    jaccard_ref.occurrence_matrix_naive(lists[:600], lists)
+    el = time.perf_counter() - t0
+    emit(component="jaccard_cpu_baseline", kind="port", cores=1, sample="600 x 3965 hepth out-set pairs, python sets per pair",
+         pairs_per_s=round(600 * len(lists) / el))
+    # synthetic scale-up: 20,000 out-sets / in-sets, V0 = 11,901
+    sh = synth.Shape("reddit_like", 11901, 11, 2, 8, 512, (8, 133, 512), (8, 133, 512))
+    for kind, ins in (("out-sets", False), ("in-sets", True)):
+        ptr, idx = synth.output_sets(sh, 20000, in_sets=ins)
+        P, I = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+        wall, pr = profile(lambda: ops.jaccard(P, I, P, I, sh.v0, True), 5)
+        j = pr["jaccard"]
+        emit(component="jaccard", case=f"synthetic 20000 x 20000 {kind} (mean size {idx.size / 20000:.1f})", pairs=4e8,
+             kernel_us=round(j["us"], 1), pairs_per_s=round(4e8 / (j["us"] * 1e-6)),
+             roofline={"bound": "hbm", "achieved": round(j["gbs"], 1), "peak": PEAK, "unit": "GB/s", "frac": round(j["gbs"] / PEAK, 4)})
+
+
+def pool():
+    sys.path.insert(0, REPO)
+    from bench import build_model
+    from rag4dyg_amd.retrieval import encode_batches, right_pad_batches
+    for name in ("UCI_13", "wikiv2"):
+        shape = synth.SHAPES[name]
+        m = build_model(shape, dev)
+        seqs = synth.sequences(shape, 12500, "pool", seed=2026)
+        b = right_pad_batches(seqs, 32, shape.pad_id, dev)
+        encode_batches(m, b[:40]); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        encode_batches(m, b)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        emit(component="pool_encode", shape=name, sequences=12500, padded_tokens=int(sum(x.numel() for x in b)),
+             seqs_per_s=round(12500 / el, 1))
+
+
+if __name__ == "__main__":
+    for part in (sys.argv[1:] or ["scan", "jaccard", "pool"]):
+        {"scan": scan, "jaccard": jaccard, "pool": pool}[part]()
