@@ -156,12 +156,13 @@ int r4d_argsort_desc_f64(const double* scores_d, int32_t rows, int32_t n, int32_
 /* ------------------------------------------------------------------------------------------------
  * Jaccard pool annotation.  Replaces occurrence_matrix / co_occurrence_ratio,
  * retrieval_data_annotation.py:36-41 / :5-15, and np.fill_diagonal :172-173.
- * Sets are CSR: ptr int32 [n+1], idx int32 sorted-unique token ids in [0,vocab).
+ * Sets are CSR: ptr int32 [n+1], idx int32 sorted-unique token ids in [0,vocab); *_nnz = ptr[n] = number of
+ * idx elements (the idx buffers must hold at least one element even when every set is empty).
  * ---------------------------------------------------------------------------------------------- */
 /* out_d f64 [na,nb] row-major: |A_i & B_j| / |A_i | B_j|, 0.0 when either set is empty;
  * zero_diag != 0 additionally writes 0.0 at i == j. */
-int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na,
-                    const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb,
+int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, int32_t a_nnz,
+                    const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz,
                     int32_t vocab, int32_t zero_diag, double* out_d, void* stream);
 /* Per-row top-k (value descending, index ascending) of an f64 matrix: save_score_file_train,
  * retrieval_data_annotation.py:97-103 (topk=10).  ws from r4d_topk_f64_workspace_bytes. */

@@ -7,8 +7,8 @@
 // is the f32-in/f32-acc MFMA (157 TFLOP/s peak == the f32 vector peak, but one VGPR per operand and the
 // VALU left free for the epilogue).
 //
-// Tiling: 256 threads = 4 wavefronts (2x2); block tile BM x BN x BK, wave tile (BM/2) x (BN/2) made of
-// TM x TN 32x32 MFMA tiles.  LDS images are k-major ([k][m], [k][n]).  The rows (columns) of a wave tile
+// Tiling: WGM x WGN wavefronts (2x2, or 4x2 for the 128x128 tile); block tile BM x BN x BK, wave tile
+// (BM/WGM) x (BN/WGN) made of TM x TN 32x32 MFMA tiles.  LDS images are k-major ([k][m], [k][n]).  The rows (columns) of a wave tile
 // are INTERLEAVED over its MFMA tiles -- MFMA tile t owns rows TM*i + t -- so one lane's TM (TN) operands
 // for a k-step are adjacent in LDS and come from ONE conflict-free ds_read_b32/b64/b128, and the
 // epilogue stores TN adjacent columns per lane (256-512 B contiguous per row segment).  A (and B when
@@ -22,7 +22,6 @@ namespace r4d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float gelu_new_f(float x) {
     // 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))  -- modeling_gpt2.py:25,206
@@ -60,11 +59,12 @@ struct GemmShape {
     float scale_div;
 };
 
-template <int BM, int BN, int BK, bool BT>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
+template <int BM, int BN, int BK, int WGM, int WGN, bool BT>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
                                                             float* __restrict__ Cg, const float* __restrict__ biasg,
                                                             const float* __restrict__ residg, const GemmShape g) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int NTHREADS = 64 * WGM * WGN;                          // WGM x WGN wavefronts
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int LDA = BM + 2;                                      // even: keeps ds_read_b64 aligned
     constexpr int LDB = BT ? BN + 2 : BN;
     constexpr int KV = BK / 4;                                       // float4 per tile row
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const float* __restr
     const int nkt = (kend + BK - 1) / BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 31, lh = lane >> 5;
 
     // per-thread staging coordinates (loop-invariant).  Out-of-range rows/columns are CLAMPED to a valid
@@ -265,20 +265,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- dispatch
-struct TileCfg { int bm, bn, cls, blocks_per_cu; double eff; };
+struct TileCfg { int bm, bn, cls, blocks_per_cu, waves_per_block; double eff; };
 // eff = steady-state fraction of the f32 MFMA peak measured for the tile on a saturating grid
 // (tools/gemm_bench.py, MI355X); used only to rank tiles in the cost model below.  All tiles use BK = 32:
-// half the barriers of BK = 16 and full 128-byte lines per A row (+3-5 % measured).
+// half the barriers of BK = 16 and full 128-byte lines per A row (+3-5 % measured).  The 128x128 tile runs
+// 8 wavefronts (4x2, wave tile 32x64): twice the L2->LDS reuse of 128x64 at the same 4 waves per SIMD.
 static const TileCfg kTiles[] = {
-    {128, 128, PK_GEMM_128x128_NN, 2, 0.80},
-    {128, 64, PK_GEMM_128x64_NN, 4, 0.76},
-    {64, 64, PK_GEMM_64x64_NN, 6, 0.72},
+    {128, 128, PK_GEMM_128x128_NN, 2, 8, 0.78},
+    {128, 64, PK_GEMM_128x64_NN, 4, 4, 0.74},
+    {64, 64, PK_GEMM_64x64_NN, 6, 4, 0.70},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 constexpr int BKT = 32;
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WGM = 2, int WGN = 2>
 static int launch_variant(const GemmArgs& g, int cls, hipStream_t stream) {
+    constexpr int NTHREADS = 64 * WGM * WGN;
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     dim3 grid(tiles, 1, g.nbatch);
     // algorithmic flop: 2MNK dense; the causal launches count only the lower-triangular half
@@ -290,10 +292,10 @@ static int launch_variant(const GemmArgs& g, int cls, hipStream_t stream) {
     sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
     sh.scale_div = g.scale_div;
     if (g.b_trans)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WGM, WGN, true>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
                            g.resid, sh);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WGM, WGN, false>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
                            g.resid, sh);
     R4D_CHECK_LAUNCH("gemm_f32");
     return R4D_OK;
@@ -317,7 +319,8 @@ static int pick_tile(const GemmArgs& g) {
         if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(g.M, c.bm) * g.nbatch / 2;   // lower triangle
         const long long per_cu = (blocks + 255) / 256;
         const double conc = (double)(per_cu < c.blocks_per_cu ? per_cu : c.blocks_per_cu);
-        const double eff = c.eff * (conc >= 3.0 ? 1.0 : conc / 3.0);
+        const double wps = conc * c.waves_per_block / 4.0;                 // resident wavefronts per SIMD
+        const double eff = c.eff * (wps >= 3.0 ? 1.0 : wps / 3.0);
         const double cost = (double)per_cu * c.bm * c.bn / eff;
         if (cost < best_cost) { best_cost = cost; best = t; }
     }
@@ -334,7 +337,7 @@ int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {
     if (g.a_cols <= 0) g.a_cols = g.K;
     const int t = pick_tile(g);
     switch (t) {
-        case 0: return launch_variant<128, 128, BKT>(g, kTiles[0].cls, stream);
+        case 0: return launch_variant<128, 128, BKT, 4, 2>(g, kTiles[0].cls, stream);
         case 1: return launch_variant<128, 64, BKT>(g, kTiles[1].cls, stream);
         default: return launch_variant<64, 64, BKT>(g, kTiles[2].cls, stream);
     }

@@ -142,8 +142,13 @@ def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False):
     """f64 [na,nb] Jaccard matrix of CSR sets (occurrence_matrix, retrieval_data_annotation.py:36-41)."""
     na, nb = a_ptr.numel() - 1, b_ptr.numel() - 1
     out = torch.empty(na, nb, dtype=torch.float64, device=a_ptr.device)
+    if a_idx.numel() == 0:                     # contract: idx buffers hold at least one element
+        a_idx = torch.zeros(1, dtype=torch.int32, device=a_ptr.device)
+    if b_idx.numel() == 0:
+        b_idx = torch.zeros(1, dtype=torch.int32, device=b_ptr.device)
     check(_lib.load().r4d_jaccard_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na,
-                                      _dev(b_ptr, torch.int32, "b_ptr"), _dev(b_idx, torch.int32, "b_idx"), nb,
+                                      a_idx.numel(), _dev(b_ptr, torch.int32, "b_ptr"),
+                                      _dev(b_idx, torch.int32, "b_idx"), nb, b_idx.numel(),
                                       int(vocab), int(bool(zero_diag)), out.data_ptr(), _stream()), "jaccard")
     return out
 
