@@ -127,10 +127,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" IS RCCL on ROCm
+    dev_index = local_rank % torch.cuda.device_count()              # == local_rank on a full node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("R4D_BENCH_BACKEND", "nccl")           # "nccl" IS RCCL on ROCm; "gloo" = functional
+    if world > 1:                                                    # rehearsal of the N>1 path on a 1-GPU box only
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
     _lib.load()
 
     shape = synth.SHAPES[args.shape]
@@ -160,11 +165,22 @@ def main():
     G = args.batches_per_step
     nqb = len(q_batches)
 
+    if world > 1 and backend != "nccl":
+        import rag4dyg_amd.dist as rdist                            # rehearsal only: stage the two collectives through
+        _orig = rdist.all_gather_cat                                # host memory, compute stays on the GPU
+
+        def _host_gather(t, group=None):
+            return _orig(t.cpu(), group).to(t.device)
+        rdist.all_gather_cat = _host_gather
+        gather = _host_gather
+    else:
+        gather = all_gather_cat
+
     def step(i):
         group = [q_batches[(i * G + j) % nqb] for j in range(G)]
         emb = model.encode_groups_meanpool(group)
         q_hat = ops.normalize_rows(emb)
-        q_all = all_gather_cat(q_hat) if world > 1 else q_hat
+        q_all = gather(q_hat) if world > 1 else q_hat
         return sharded_topk(q_all, index.pool_hat, index.index_offset, k,
                             lambda q, p_, kk, off: ops.score_topk(q, p_, kk, off)[:2], ops.merge_topk)
 
