@@ -1,0 +1,296 @@
+// Fused causal multi-head attention for gfx950, exact fp32 (Attention._attn + split/merge_heads,
+// models/modeling_gpt2.py:140-175): softmax(Q.K^T / sqrt(hd), causal) . V without materialising the T x T scores.
+//
+// One workgroup = one (batch, head, 32-query tile); its 4 wavefronts SPLIT THE KEYS (wave w takes the 32-key tiles
+// w, w+4, ... up to the diagonal), each keeping a private online-softmax state (running max m, sum l) and a private
+// O^T accumulator, merged once at the end.  Everything per tile stays in registers:
+//   * S^T = K.Q^T ("swapped" product, exact-f32 MFMA 32x32x2): the MFMA result has the QUERY on the lane and 16 keys in
+//     registers, so the row max / row sum of the softmax are 15 in-register ops plus ONE cross-lane exchange with the
+//     other half-wave (__shfl_xor 32) -- no LDS, no serial lane loop.  A operand: each lane streams its own K row with
+//     16-byte global loads (k permuted identically on both operands); B operand: the 32 queries staged k-major in LDS
+//     (stride 33: conflict-free fill and reads).
+//   * logits are DIVIDED by sqrt(hd) like the reference (:143); masked keys (key > query) are skipped, which equals
+//     the reference's `w*b - 1e4*(1-b)` + softmax in fp32 whenever the row max exceeds -9896.
+//   * O^T += V^T.P: the probability registers ARE the B operand of the next MFMA (it sums over the accumulator's row
+//     index = key, no lane movement); A operand = V rows read with coalesced 4..16-byte loads, the head columns
+//     interleaved over the MFMA tiles (tile j owns columns VW*i + j).
+//   * the 4 partial states are merged pairwise through LDS (re-using the query buffer), O is transposed through LDS
+//     and stored as whole 128..1024-byte rows of the merged-head layout [B, T, d].
+#include <math.h>
+#include "common.h"
+
+namespace r4d {
+
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+constexpr int ATT_LDQ = 33;
+
+template <int VW>
+struct VLoad;
+template <>
+struct VLoad<1> { static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { v[0] = p[0]; } };
+template <>
+struct VLoad<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct VLoad<3> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; }
+};
+template <>
+struct VLoad<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+// HD = head_dim in {32, 64, 96, 128, 256}.  VW = floats per lane per V load, NU = V loads per key pair.
+template <int HD>
+__global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(const float* __restrict__ qkv, int T, int d, float scale,
+                                                         float* __restrict__ out) {
+    constexpr int VW = HD >= 128 ? 4 : HD / 32;
+    constexpr int NU = HD >= 128 ? HD / 128 : 1;
+    constexpr int NCB = HD / 32;                       // 32-column blocks of O^T  (= NU * VW)
+    constexpr int NSTEP = HD / 8;                      // 16-byte K loads per key row
+    constexpr int GRP = (HD >= 256) ? 8 : 4, NG = NSTEP / GRP;           // K loads per ping-pong group (NSTEP in {4,8,12,16,32})
+    extern __shared__ float lds[];                     // Q tile [HD][33]; later 2 merge slots; later O tile [32][HD+4]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qt * 32;
+    const long long ld3 = 3LL * d;
+    const float* __restrict__ base = qkv + (long long)b * T * ld3 + (long long)h * HD;
+    const float* __restrict__ Kb = base + d;
+    const float* __restrict__ Vb = base + 2 * d;
+
+    // ---- stage the 32 queries k-major: Qs[k][q].  Each wave owns 8 queries; all of its global loads are issued
+    // back to back (one round trip), then written with conflict-free ds_write_b32 (bank = (k + q) % 32).
+    {
+        constexpr int NQL = (HD + 63) / 64;
+        float qv[8][NQL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = wid * 8 + j;
+            const float* src = base + (long long)min(q0 + q, T - 1) * ld3;
+#pragma unroll
+            for (int i = 0; i < NQL; ++i) qv[j][i] = src[min(lane + 64 * i, HD - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = wid * 8 + j;
+            const bool ok = q0 + q < T;
+#pragma unroll
+            for (int i = 0; i < NQL; ++i) {
+                const int k = lane + 64 * i;
+                if (k < HD) lds[k * ATT_LDQ + q] = ok ? qv[j][i] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16a O[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qidx = q0 + li;
+    const bool pow2_scale = (HD == 64 || HD == 256);
+    const float inv_scale = 1.0f / scale;
+
+    for (int kt = wid; kt <= qt; kt += 4) {
+        const int key0 = kt * 32;
+        // ---- S^T[key][q] = sum_k K[key][k] Q[q][k]
+        const float4* __restrict__ krow =
+            reinterpret_cast<const float4*>(Kb + (long long)min(key0 + li, T - 1) * ld3) + lh;
+        f32x16a S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        // static ping-pong over groups of GRP k-steps: the 16-byte K loads AND the LDS query operands of group g+1
+        // are in flight while group g feeds the MFMAs (one wave per SIMD at hd = 256: nothing else hides latency)
+        float4 kb[2][GRP];
+        float qb[2][GRP][4];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            kb[0][u] = krow[2 * u];
+            const float* qa = lds + (8 * u + 4 * lh) * ATT_LDQ + li;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qb[0][u][c] = qa[c * ATT_LDQ];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    kb[(g + 1) & 1][u] = krow[2 * ((g + 1) * GRP + u)];
+                    const float* qa = lds + (8 * ((g + 1) * GRP + u) + 4 * lh) * ATT_LDQ + li;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) qb[(g + 1) & 1][u][c] = qa[c * ATT_LDQ];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const float4 kv = kb[g & 1][u];
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qb[g & 1][u][0], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qb[g & 1][u][1], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qb[g & 1][u][2], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qb[g & 1][u][3], S, 0, 0, 0);
+            }
+        }
+        // ---- online softmax: this lane = query li; its 16 registers = keys key0 + kappa(r) + 4*lh
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            // the reference DIVIDES by sqrt(hd) (:143); for a power-of-two scale (hd = 64, 256) the reciprocal
+            // multiply is the same value bit for bit and saves a ~12-instruction f32 division per logit
+            const float s = pow2_scale ? S[r] * inv_scale : S[r] / scale;
+            S[r] = (key <= qidx) ? s : -INFINITY;
+            mt = fmaxf(mt, S[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (m_new == -INFINITY) ? 0.f : __expf(S[r] - m_new);    // exp(-inf) = 0 for masked keys
+            S[r] = p;
+            ps += p;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        // wave-uniform: skip the 16*NCB multiplies when no query of this wave moved its running max
+        if (__any(alpha != 1.0f && m_run != -INFINITY)) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        }
+        m_run = m_new;
+        // ---- O^T[c][q] += sum_key V[key][c] P[key][q]; register r of P covers the key pair kappa(r) + 4*{0,1}
+        // ring of VD key-pair loads in flight (8 MFMAs = 512 cycles per pair do not cover an L2 round trip alone)
+        constexpr int VD = (HD >= 256) ? 6 : 4;
+        float vr[VD][NU][4];
+#pragma unroll
+        for (int r = 0; r < VD - 1; ++r) {
+            const int kn = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float* vrow = Vb + (long long)min(kn, T - 1) * ld3 + VW * li;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) VLoad<VW>::ld(vrow + 128 * u, vr[r][u]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r + VD - 1 < 16) {
+                const int rn = r + VD - 1;
+                const int kn = key0 + (rn & 3) + 8 * (rn >> 2) + 4 * lh;
+                const float* vrow = Vb + (long long)min(kn, T - 1) * ld3 + VW * li;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) VLoad<VW>::ld(vrow + 128 * u, vr[rn % VD][u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int j = 0; j < VW; ++j)
+                    O[u * VW + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[r % VD][u][j], S[r], O[u * VW + j], 0, 0, 0);
+        }
+    }
+
+    // ---- merge the 4 partial states: (2,3) -> (0,1), then 1 -> 0.  Slot = NCB*16*64 O values + 64 m + 64 l floats.
+    constexpr int SLOT = NCB * 16 * 64 + 128;
+    __syncthreads();                                    // every wave is done with the query buffer
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+        const int writers_lo = step == 0 ? 2 : 1;       // waves [writers_lo, 2*writers_lo) write, [0, writers_lo) merge
+        if (wid >= writers_lo && wid < 2 * writers_lo) {
+            float* sl = lds + (wid - writers_lo) * SLOT;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sl[(c * 16 + r) * 64 + lane] = O[c][r];
+            sl[NCB * 16 * 64 + lane] = m_run;
+            sl[NCB * 16 * 64 + 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (wid < writers_lo) {
+            const float* sl = lds + wid * SLOT;
+            const float m_b = sl[NCB * 16 * 64 + lane], l_b = sl[NCB * 16 * 64 + 64 + lane];
+            const float m_new = fmaxf(m_run, m_b);
+            const float fa = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+            const float fb = (m_b == -INFINITY) ? 0.f : expf(m_b - m_new);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[c][r] = O[c][r] * fa + sl[(c * 16 + r) * 64 + lane] * fb;
+            l_run = l_run * fa + l_b * fb;
+            m_run = m_new;
+        }
+        __syncthreads();
+    }
+    // ---- wave 0: normalise, transpose O^T -> Ot[q][c] in LDS; all waves: coalesced row stores
+    constexpr int LDO = HD + 1;                        // odd stride: conflict-free transposed writes
+    if (wid == 0) {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = 128 * u + VW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + j;
+                    lds[li * LDO + c] = O[u * VW + j][r] * inv;
+                }
+    }
+    __syncthreads();
+    for (int q = wid; q < 32; q += 4) {
+        if (q0 + q >= T) break;
+        float* dst = out + ((long long)b * T + q0 + q) * d + (long long)h * HD;
+        for (int c = lane * 4; c < HD; c += 256) {
+            const float* sp = &lds[q * LDO + c];
+            *reinterpret_cast<float4*>(dst + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    }
+}
+
+template <int HD>
+static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+    constexpr int NCB = HD / 32;
+    const size_t q_bytes = (size_t)HD * ATT_LDQ * 4, slot_bytes = 2 * ((size_t)NCB * 16 * 64 + 128) * 4,
+                 o_bytes = (size_t)32 * (HD + 1) * 4;
+    size_t lds = q_bytes > slot_bytes ? q_bytes : slot_bytes;
+    if (o_bytes > lds) lds = o_bytes;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)attn_fused_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                set_error("attention: cannot raise dynamic LDS limit");
+                return R4D_ERR_HIP;
+            }
+            raised = true;
+        }
+    }
+    // algorithmic flop: causal half of Q.K^T and P.V = 2 * T^2 * hd per head
+    ProfScope prof(PK_ATTN_FUSED, 2.0 * B * H * (double)T * T * HD, s);
+    hipLaunchKernelGGL((attn_fused_kernel<HD>), dim3(cdiv(T, 32), H, B), dim3(256), lds, s, qkv, T, d,
+                       (float)sqrt((double)HD), out);
+    R4D_CHECK_LAUNCH("attn_fused");
+    return R4D_OK;
+}
+
+// returns R4D_OK, an error, or +1 when the head_dim has no fused instantiation (caller falls back)
+int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+    const int hd = d / H;
+    R4D_REQUIRE(B <= 65535 && H <= 65535, "attention: B=%d / H=%d exceed the grid limits", B, H);
+    switch (hd) {
+        case 32: return launch_hd<32>(qkv, B, T, H, d, out, s);
+        case 64: return launch_hd<64>(qkv, B, T, H, d, out, s);
+        case 96: return launch_hd<96>(qkv, B, T, H, d, out, s);
+        case 128: return launch_hd<128>(qkv, B, T, H, d, out, s);
+        case 256: return launch_hd<256>(qkv, B, T, H, d, out, s);
+        default: return 1;
+    }
+}
+
+}  // namespace r4d

@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
     PK_GEMM_64x64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
-    PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
+    PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
 void prof_begin_impl(int cls, double work, hipStream_t s);
@@ -72,6 +72,9 @@ int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const
                            int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
                            float* x_out, float* y_out, hipStream_t s);
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
+// attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
+int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
+extern int g_attention_fused;        // -1 auto (default), 1 fused, 0 three-launch GEMM form (r4d_set_attention_fused)
 constexpr int LNF_ROWS_PER_CHUNK = 16;
 size_t lnf_meanpool_scratch_floats(int B, int T, int d);
 int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,

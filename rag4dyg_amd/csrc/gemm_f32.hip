@@ -60,7 +60,7 @@ struct GemmShape {
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool BT>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
                                                             float* __restrict__ Cg, const float* __restrict__ biasg,
                                                             const float* __restrict__ residg, const GemmShape g) {
     constexpr int NTHREADS = 64 * WGM * WGN;                          // WGM x WGN wavefronts

@@ -57,6 +57,11 @@ def conv1d(x, w, bias, epilogue="none", residual=None):
     return y
 
 
+def set_attention_fused(mode):
+    """-1 / None: auto by head_dim (default); True: fused flash-style kernel; False: three-launch GEMM form."""
+    _lib.load().r4d_set_attention_fused(-1 if mode is None or mode == -1 else int(bool(mode)))
+
+
 def attention(qkv, n_head):
     """Causal MHA over packed c_attn output [B,T,3d] -> [B,T,d] (modeling_gpt2.py:140-175)."""
     B, T, d3 = qkv.shape

@@ -70,9 +70,17 @@ def test_conv1d_golden(dev):
     assert rel_err(y, g["conv_y"]) < 1e-5
 
 
+@pytest.fixture(params=["fused", "unfused"])
+def attn_mode(request):
+    from rag4dyg_amd import ops
+    ops.set_attention_fused(request.param == "fused")
+    yield request.param
+    ops.set_attention_fused(None)
+
+
 @pytest.mark.parametrize("tag", ["attn_hd32_T40_s1", "attn_hd64_T33_s1", "attn_hd96_T24_s1",
                                  "attn_hd128_T24_s1", "attn_hd256_T20_s1", "attn_hd64_T48_s30"])
-def test_attention_golden(dev, tag):
+def test_attention_golden(dev, tag, attn_mode):
     """Reference Attention._attn vectors (q [B,H,T,hd], k [B,H,hd,T], v) re-packed as c_attn output."""
     from rag4dyg_amd import ops
     g = load_golden("g2_ops")
@@ -86,8 +94,8 @@ def test_attention_golden(dev, tag):
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 32), (2, 129, 2, 256), (2, 339, 2, 256), (1, 1024, 2, 128),
-                                      (4, 128, 8, 96), (2, 200, 8, 64), (2, 257, 6, 128)])
-def test_attention_oracle_shapes(dev, B, T, H, hd):
+                                      (4, 128, 8, 96), (2, 200, 8, 64), (2, 257, 6, 128), (2, 97, 4, 48), (33, 31, 2, 256)])
+def test_attention_oracle_shapes(dev, B, T, H, hd, attn_mode):
     from rag4dyg_amd import ops
     from oracle import gpt2_ref
     g = torch.Generator().manual_seed(T * 7 + hd)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Tuning aid (GPU box): fused vs three-launch attention on the encoder's shapes."""
+import os, sys, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from rag4dyg_amd import ops
+dev = torch.device("cuda:0")
+SHAPES = [(128, 128, 2, 256), (128, 277, 2, 256), (128, 128, 6, 128), (128, 300, 6, 128), (128, 128, 8, 96),
+          (128, 300, 8, 96), (128, 128, 8, 64), (128, 300, 8, 64), (256, 100, 2, 128)]
+if os.environ.get("R4D_SHAPES"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["R4D_SHAPES"].split(",")]
+for (B, T, H, hd) in SHAPES:
+    d = H * hd
+    qkv = torch.randn(B, T, 3 * d, device=dev)
+    res = []
+    for fused in (1, 0):
+        ops.set_attention_fused(fused)
+        for _ in range(3):
+            ops.attention(qkv, H)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.attention(qkv, H)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 20 * 1e3)
+    flop = 2.0 * B * H * T * T * hd
+    print(f"B={B:4d} T={T:4d} H={H} hd={hd:3d}  fused {res[0]:8.1f} us ({flop/res[0]/1e6:6.1f} TF)   unfused {res[1]:8.1f} us ({flop/res[1]/1e6:6.1f} TF)", flush=True)
+ops.set_attention_fused(None)

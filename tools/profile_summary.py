@@ -54,7 +54,7 @@ with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as f:
 def bench_class(k):
     """rocprof kernel name -> bench.py / r4d_profile_class_name class."""
     import re
-    m = re.match(r"gemm_f32_kernel<(\d+), (\d+), \d+, (false|true)>", k)
+    m = re.match(r"gemm_f32_kernel<(\d+), (\d+), \d+, \d+, \d+, (false|true)>", k)
     if m:
         return f"gemm_f32_{m.group(1)}x{m.group(2)}_{'nt' if m.group(3) == 'true' else 'nn'}"
     return {"ln_kernel<false>": "layernorm", "ln_kernel<true>": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
