@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Drop-in for the reference ``main_SimpleDyG.py`` (flags of ``utils/args_parser_SimpleDyG.py``): the SimpleDyG
-GPT-2 FORWARD on the MI355X -- LM loss of a checkpoint over ``--eval_data_file`` (``evaluate``,
-``main_SimpleDyG.py:345-372``).  LM training (``train``/``train_epoch`` :148-343, backward pass) and the greedy
-generation metrics (``utils/Evaluation_SimpleDyG.py``) are not part of this build and raise."""
+GPT-2 FORWARD on the MI355X -- ``--do_eval`` runs the reference's greedy link-prediction evaluation
+(``get_eval_metrics``, ``utils/Evaluation_SimpleDyG.py:53-211``: NDCG@5 / Jaccard, as ``main_SimpleDyG.py:485-487``) for
+every checkpoint and also reports the LM loss over ``--eval_data_file`` (``evaluate``, :345-372).  LM training
+(``train``/``train_epoch`` :148-343, backward pass) is not part of this build and raises."""
 import glob
 import os
 
@@ -10,6 +11,7 @@ import torch
 
 from rag4dyg_amd.cli_args import SIMPLEDYG, parse
 from rag4dyg_amd.dataloader import LineByLineTextDataset, get_dataloader
+from rag4dyg_amd.evaluation import get_eval_metrics
 from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
 from rag4dyg_amd.tokenizer import WordLevelTokenizer, get_model_tokenizer
 
@@ -47,6 +49,9 @@ def main(argv=None):
     args.device = torch.device("cuda", max(args.local_rank, 0))
     args.n_gpu = 1
     torch.manual_seed(args.seed)
+    args.para_names = ['dataset', 'method', 'time', 'nlayer', 'nhead', 'nemb', 'bz', 'lr', 'seed']
+    args.para_values = [args.dataset, 'SimpleDyG', args.timestamp, args.n_layer, args.n_head, args.n_embed,
+                        args.per_gpu_train_batch_size, args.learning_rate, args.seed]
     model, tokenizer, model_class, args = get_model_tokenizer(args, MODEL_CLASSES)
     if args.do_train:
         raise NotImplementedError("SimpleDyG LM training (backward pass) is outside the encode-and-retrieve hot path")
@@ -59,8 +64,10 @@ def main(argv=None):
         print("Evaluate the following checkpoints: {}".format(checkpoints))
         for checkpoint in checkpoints:
             model = model_class.from_pretrained(checkpoint).to(args.device)
-            results[checkpoint] = evaluate(args, model, tokenizer, prefix=os.path.basename(checkpoint))
-            print(f"eval_loss[{checkpoint}] = {results[checkpoint]:.6f}")
+            loss = evaluate(args, model, tokenizer, prefix=os.path.basename(checkpoint))
+            scores = get_eval_metrics(args, model, tokenizer, 0, mode="test")      # main_SimpleDyG.py:487
+            results[checkpoint] = dict(eval_loss=loss, **scores)
+            print(f"[{checkpoint}] eval_loss = {loss:.6f}  NDCG@5 = {scores['NDCG'][0]}  jaccard = {scores['jaccard'][0]}")
     return results
 
 

@@ -160,3 +160,24 @@ def make_state_dict(n_layer, n_embd, vocab, n_positions=1024, seed=1234, std=0.0
     sd["transformer.ln_f.bias"] = nrm(d, s=0.1) if random_affine else torch.zeros(d)
     sd["lm_head.weight"] = sd["transformer.wte.weight"]
     return sd
+
+
+@torch.no_grad()
+def greedy_decode(sd, n_head, indexed_tokens, eos_id, mode="val", max_len=1024, n_spl=0, eps=1e-5):
+    """Batch-1 greedy decode of ``utils/Evaluation_SimpleDyG.py:120-145``: full forward on the growing
+    sequence each step, argmax of the last position, stop rules of val (10 tokens) / test (length cap) / EOS."""
+    toks = list(indexed_tokens)
+    gen_len = 0
+    while True:
+        out = gpt2_forward(sd, torch.tensor([toks]), n_head, eps)
+        nxt = int(torch.argmax(out["logits"][0, -1, :]).item())
+        toks.append(nxt)
+        gen_len += 1
+        if mode == "val":
+            if gen_len > 10:
+                break
+        elif len(toks) >= max_len - n_spl:
+            break
+        if nxt == eos_id:
+            break
+    return toks

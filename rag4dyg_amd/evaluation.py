@@ -1,0 +1,144 @@
+"""SimpleDyG greedy link-prediction evaluation, forward passes on the gfx950 kernels.
+
+Mirrors ``utils/Evaluation_SimpleDyG.py``: ``Evaluation`` (natural-log NDCG@k, Jaccard, recall, precision, MAP) and
+``get_eval_metrics`` -- per test sequence a batch-1 greedy decode that re-runs the FULL forward on the growing
+sequence each step (no KV cache, exactly like the reference, :126-134), stops on ``<|endoftext|>`` (val: after 10
+tokens; test: at ``n_ctx - len(spl_tokens)``), then scores the predicted node list against the ground truth.
+Only the last position's logits are needed, so the tied lm_head GEMM runs on one row per step.
+Reference quirk kept: ``get_eval_metrics`` always reads ``args.eval_data_file`` / ``eval_data_gt_file``, also in
+mode="test" (:57-58).
+"""
+import json
+import math
+import os
+
+import torch
+
+from . import ops
+
+
+class Evaluation:
+    """``utils/Evaluation_SimpleDyG.py:14-51``."""
+
+    def jaccard(self, pred, label):
+        pred, label = set(pred), set(label)
+        return len(pred & label) / len(pred | label)
+
+    def ndcg_k(self, sorted_indices, ground_truth, k):
+        dcg, pdcg = 0, 0
+        for i, item in enumerate(sorted_indices[:k]):
+            if item in ground_truth:
+                dcg += 1 / math.log(i + 2)
+        for i in range(min(len(ground_truth), k)):
+            pdcg += 1 / math.log(i + 2)
+        return dcg / pdcg
+
+    def map_k(self, sort, y, k):
+        sum_precs, hists = 0, 0
+        for n, item in enumerate(sort[:k]):
+            if item in y:
+                hists += 1
+                sum_precs += hists / (n + 1)
+        return sum_precs
+
+    def recall_k(self, sort, y, k):
+        return sum(1 for y_i in y if y_i in sort[:k]) / len(y)
+
+    def precision_k(self, sort, y, k):
+        return sum(1 for y_i in y if y_i in sort[:k]) / k
+
+
+@torch.no_grad()
+def greedy_next_token(model, indexed_tokens, device):
+    """argmax of the last position's logits for one sequence (``outputs[0][0, -1, :]``, :127-129)."""
+    ids = torch.tensor([indexed_tokens], dtype=torch.int64, device=device)
+    hidden = model.transformer.encode(ids, want_hidden=True)["hidden"]
+    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), model.transformer.wte.weight)
+    return int(torch.argmax(logits[0]).item())
+
+
+@torch.no_grad()
+def greedy_decode(model, tokenizer, indexed_tokens, mode, max_len, n_spl, device):
+    """The decode loop of ``get_eval_metrics`` (:120-145) for one sequence; returns the extended id list."""
+    indexed_tokens = list(indexed_tokens)
+    eos = tokenizer.encode("<|endoftext|>")
+    gen_len = 0
+    while True:
+        predicted_index = greedy_next_token(model, indexed_tokens, device)
+        indexed_tokens.append(predicted_index)
+        gen_len += 1
+        if mode == "val":
+            if gen_len > 10:
+                break
+        elif len(indexed_tokens) >= max_len - n_spl:
+            break
+        if predicted_index in eos:                     # == decode(...).endswith('<|endoftext|>') / the while condition
+            break
+    return indexed_tokens
+
+
+def get_eval_metrics(args, model, tokenizer, step, mode="val"):
+    """Drop-in for ``utils/Evaluation_SimpleDyG.get_eval_metrics`` (:53-211): NDCG@5 / Jaccard over the file pair,
+    results CSV + per-sample JSON under ``<output_dir>/results[_seed_jac]/<mode>_score``."""
+    spl_tokens = tokenizer.additional_special_tokens + [tokenizer.bos_token, tokenizer.eos_token, tokenizer.pad_token]
+    with open(args.eval_data_file, encoding="utf-8") as f:
+        data = [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
+    with open(args.eval_data_gt_file, encoding="utf-8") as f:
+        data_gt = [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
+    assert len(data) == len(data_gt)
+    with open(os.path.join('./vocabs', args.dataset, str(args.timestamp), 'vocab.json')) as f:
+        vocab = json.load(f)
+    sub = "results_seed_jac" if getattr(args, "run_seed", False) else "results"
+    save_score_path = os.path.join(args.output_dir, sub, mode + '_score')
+    os.makedirs(save_score_path, exist_ok=True)
+
+    Eval = Evaluation()
+    model.eval()
+    device = next(model.parameters()).device
+    MAX_LEN = model.config.n_ctx
+    topk = [5]
+    metric_terms = ['MAP', 'NDCG', 'jaccard']
+    top_k_scores = {metric: len(topk) * [0] for metric in metric_terms}
+    generated_dict = {}
+    num_user_test = 0
+    for i, (input_text, text_gt) in enumerate(zip(data, data_gt)):
+        generated_dict[i] = {}
+        user_id = input_text.split()[2]
+        target_list = [t for t in text_gt.split()[1:-2] if t != user_id and t in vocab]
+        if len(target_list) == 0:
+            print('text_gt: ', text_gt)
+            continue
+        indexed_tokens = tokenizer.encode(input_text)
+        num_user_test += 1
+        if len(indexed_tokens) > MAX_LEN:
+            print('len_input: ', len(indexed_tokens))
+            indexed_tokens = indexed_tokens[-1000:]
+        len_input = len(indexed_tokens)
+        out_ids = greedy_decode(model, tokenizer, indexed_tokens, mode, MAX_LEN, len(spl_tokens), device)
+        predicted_list = tokenizer.decode(out_ids).split()[len_input:]
+        predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
+        for topi, k in enumerate(topk):
+            try:
+                top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
+            except ZeroDivisionError:
+                pass
+            top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
+        generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
+                                  'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
+                                  'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
+                                  'num_user_test': str(num_user_test)})
+    for metric in metric_terms:
+        for topi, _k in enumerate(topk):
+            top_k_scores[metric][topi] = round(top_k_scores[metric][topi] / max(num_user_test, 1), 4)
+    result_save_file = os.path.join(save_score_path, mode + '_results_epoch.csv')
+    if not os.path.exists(result_save_file):
+        with open(result_save_file, 'w') as f:
+            f.write(''.join(p + ',' for p in args.para_names))
+            f.write(''.join('NDCG@{},'.format(k) for k in topk) + ''.join('jaccard@{},'.format(k) for k in topk) + '\n')
+    with open(result_save_file, 'a') as f:
+        f.write(''.join(str(v) + ',' for v in args.para_values))
+        f.write(''.join(str(top_k_scores['NDCG'][j]) + ',' for j in range(len(topk))))
+        f.write(''.join(str(top_k_scores['jaccard'][j]) + ',' for j in range(len(topk))) + '\n')
+    with open('{}.json'.format(save_score_path + '/eval_results_' + str(step)), 'wt') as f:
+        json.dump(generated_dict, f, indent=4)
+    return top_k_scores

@@ -104,6 +104,7 @@ class WordLevelTokenizer:
         return ids
 
     def __call__(self, lines, add_special_tokens=True, max_length=None, truncation=True, **_):
+        """``tokenizer(lines, ...)["input_ids"]`` (batch) -- ``dataloader/retriever.py:23``."""
         if isinstance(lines, str):
             return {"input_ids": self.encode(lines, max_length, bool(truncation))}
         return {"input_ids": [self.encode(line, max_length, bool(truncation)) for line in lines]}

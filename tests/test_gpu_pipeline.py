@@ -224,3 +224,46 @@ def test_pool_sharded_over_ranks_equals_single_gpu(dev, tmp_path, world):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_simpledyg_greedy_eval_matches_oracle_decode(dev, tmp_path, monkeypatch):
+    """greedy link-prediction eval -- generated token ids equal the oracle's CPU decode, and the CLI
+    writes the reference's result files."""
+    import main_SimpleDyG
+    from oracle import gpt2_ref, jaccard_ref
+    from rag4dyg_amd.evaluation import Evaluation, greedy_decode
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    base = _write_dataset(str(tmp_path), n_train=20, n_val=12, n_test=12, seed=5)
+    monkeypatch.chdir(tmp_path)
+    tok, _ = build_tokenizer("toy", 4, with_mask=False)
+    L, H, d, P = 2, 2, 64, 128
+    sd = gpt2_ref.make_state_dict(L, d, len(tok), n_positions=P, seed=9, random_affine=True)
+    cfg = GPT2Config(vocab_size=len(tok), n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H)
+    m = GPT2LMHeadModel(cfg)
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    ck = tmp_path / "out" / "checkpoint-0"
+    ck.mkdir(parents=True)
+    m.save_pretrained(str(ck))
+    m = m.to(dev).eval()
+    lines = jaccard_ref.read_lines(os.path.join(base, "val.link_prediction"))
+    eos = tok.eos_token_id
+    same = 0
+    for mode in ("val", "test"):
+        for ln in lines[:6]:
+            ids = tok.encode(ln)
+            got = greedy_decode(m, tok, ids, mode, P, 12, dev)
+            ref = gpt2_ref.greedy_decode(sd, H, ids, eos, mode, P, 12)
+            same += got == ref
+            assert got[:len(ids)] == ids and len(got) > len(ids)
+    assert same >= 11                                   # argmax can only differ at sub-1e-6 logit ties
+    argv = (f"--dataset toy --timestamp 4 --output_dir {tmp_path}/out --model_type gpt2 --train_data_file "
+            f"{base}/train.link_prediction --do_eval --eval_all_checkpoints --eval_data_file {base}/val.link_prediction "
+            f"--eval_data_gt_file {base}/val_gt.link_prediction --block_size 128 --n_layer {L} --n_head {H} --n_embed {d}").split()
+    res = main_SimpleDyG.main(argv)
+    r = next(iter(res.values()))
+    assert 0.0 <= r["NDCG"][0] <= 1.0 and 0.0 <= r["jaccard"][0] <= 1.0 and r["eval_loss"] > 0
+    out_dir = tmp_path / "out" / "results" / "test_score"
+    assert (out_dir / "test_results_epoch.csv").exists() and (out_dir / "eval_results_0.json").exists()
+    hdr = open(out_dir / "test_results_epoch.csv").readline()
+    assert hdr.startswith("dataset,method,time,nlayer,nhead,nemb,bz,lr,seed,NDCG@5,jaccard@5")

@@ -276,3 +276,16 @@ def test_sharded_topk_world_size_2_gloo(tmp_path, world):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_evaluation_metrics_natural_log_ndcg():
+    import math
+    from rag4dyg_amd.evaluation import Evaluation
+    E = Evaluation()
+    assert E.jaccard(['1', '2', '2'], ['2', '3']) == 1 / 3
+    # utils/Evaluation_SimpleDyG.py:20-27 -- natural log, ideal DCG over min(len(gt), k)
+    got = E.ndcg_k(['9', '2', '3'], ['2', '3', '4'], 5)
+    want = (1 / math.log(3) + 1 / math.log(4)) / (1 / math.log(2) + 1 / math.log(3) + 1 / math.log(4))
+    assert abs(got - want) < 1e-15
+    assert E.recall_k(['1', '2'], ['2', '5'], 5) == 0.5 and E.precision_k(['1', '2'], ['2', '5'], 5) == 0.2
+    assert E.map_k(['7', '2', '5'], ['2', '5'], 3) == 1 / 2 + 2 / 3
