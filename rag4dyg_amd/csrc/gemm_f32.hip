@@ -79,8 +79,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     // that share one A row-panel then hit the same L2 instead of fetching it 8 times.  Bijective for any grid.
     const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
     const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    // Inside an XCD's range the tiles are walked in groups of GROUP_M row-panels (m fastest inside a group): the
+    // ~64 tiles resident on an XCD then span ~8 row-panels x ~8 column-panels, i.e. ~2 MB of A + ~2 MB of B in its
+    // 4 MB L2, instead of 4 row-panels x every column-panel of B.
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.causal == CAUSAL_QK && n0 > m0 + BM - 1) return;           // tile strictly above the diagonal
 
@@ -129,35 +136,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     }
     float4 ra[NLA], rb[NLB];
 
+    // The validity mask of a staged float4 is computed when the load is ISSUED but applied when the value is
+    // written to LDS (after the MFMA phase): masking right after the load would put the s_waitcnt in front of the
+    // MFMAs and expose the whole global-load latency every k-tile.
+    bool ra_ok[NLA], rb_ok[NLB];
 #define R4D_ZERO_UNLESS(V, OK) { if (!(OK)) { V.x = 0.f; V.y = 0.f; V.z = 0.f; V.w = 0.f; } }
 #define R4D_LOAD_TILES(KT)                                                                                         \
     {                                                                                                              \
         const int k0_ = (KT) * BK;                                                                                 \
         _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
-            const bool ok_ = a_ok[r] && (k0_ + a_k[r] < g.a_cols);                                                 \
-            ra[r] = *reinterpret_cast<const float4*>(a_src[r] + ((k0_ + a_k[r] < g.a_cols) ? k0_ : 0));            \
-            R4D_ZERO_UNLESS(ra[r], ok_)                                                                            \
+            const bool kin_ = k0_ + a_k[r] < g.a_cols;                                                             \
+            ra_ok[r] = a_ok[r] && kin_;                                                                            \
+            ra[r] = *reinterpret_cast<const float4*>(a_src[r] + (kin_ ? k0_ : 0));                                 \
         }                                                                                                          \
         _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
             if (BT) {                                                                                              \
-                const bool ok_ = b_ok[r] && (k0_ + b_k[r] < g.K);                                                  \
-                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + ((k0_ + b_k[r] < g.K) ? k0_ : 0));             \
-                R4D_ZERO_UNLESS(rb[r], ok_)                                                                        \
+                const bool kin_ = k0_ + b_k[r] < g.K;                                                              \
+                rb_ok[r] = b_ok[r] && kin_;                                                                        \
+                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (kin_ ? k0_ : 0));                             \
             } else {                                                                                               \
                 const int gk_ = k0_ + b_k[r];                                                                      \
-                const bool ok_ = b_ok[r] && (gk_ < g.b_rows);                                                      \
+                rb_ok[r] = b_ok[r] && (gk_ < g.b_rows);                                                            \
                 rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (long long)min(gk_, g.b_rows - 1) * g.ldb);    \
-                R4D_ZERO_UNLESS(rb[r], ok_)                                                                        \
             }                                                                                                      \
         }                                                                                                          \
     }
 #define R4D_STORE_TILES(BUF)                                                                                       \
     {                                                                                                              \
         _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
+            R4D_ZERO_UNLESS(ra[r], ra_ok[r])                                                                       \
             float* p = &As[BUF][a_dst[r]];                                                                         \
             p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;                          \
         }                                                                                                          \
         _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
+            R4D_ZERO_UNLESS(rb[r], rb_ok[r])                                                                       \
             if (BT) {                                                                                              \
                 float* p = &Bs[BUF][b_dst[r]];                                                                     \
                 p[0] = rb[r].x; p[LDB] = rb[r].y; p[2 * LDB] = rb[r].z; p[3 * LDB] = rb[r].w;                      \
