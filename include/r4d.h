@@ -107,9 +107,10 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d,
                       float* logits_d, void* stream);
 
-/* Attention implementation switch: -1 = auto (default: fused flash-style kernel for head_dim <= 128, three
- * launches above), 1 = fused wherever instantiated (head_dim in {32,64,96,128,256}; scores never leave the CU),
- * 0 = three launches (batched Q.K^T GEMM, causal softmax, P.V GEMM).  Same results to fp32 rounding. */
+/* Attention implementation switch: -1 = auto (default) / 1 = fused flash-style kernels wherever instantiated
+ * (head_dim in {32,64,96}: key-split kernel; {128,256}: column-split kernel; scores never leave the CU),
+ * 0 = three launches (batched Q.K^T GEMM, causal softmax, P.V GEMM; also the fallback for other head dims),
+ * 2 = fused with the key-split kernel forced at head_dim 128/256 (A/B tuning).  Same results to fp32 rounding. */
 int r4d_set_attention_fused(int32_t mode);
 
 /* --- single ops, exported for per-op parity tests (same kernels the encoder launches) --- */

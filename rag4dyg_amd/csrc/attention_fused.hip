@@ -253,6 +253,196 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Column-split variant for wide heads (head_dim 128 / 256).  The key-split kernel above needs HD/2 accumulator
+// registers per lane for O^T, which at head_dim 256 leaves one wave per SIMD.  Here the 4 wavefronts of a
+// workgroup walk 128-key super-tiles TOGETHER: wave w computes S^T for its own 32-key sub-tile (full head_dim),
+// the row max / row sum are combined across the 4 waves through 1 KB of LDS, every wave publishes its
+// probabilities P^T[key][q] to LDS, and wave w accumulates only ITS quarter of the head columns of O^T over all
+// 128 keys (B operand = P^T from LDS, A operand = V rows, coalesced 4/8-byte loads).  O^T is HD/8 registers per
+// lane (32 at hd 256), so three workgroups fit per CU, the waves are always balanced and there is no merge phase.
+template <int HD>
+__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, int T, int d, float scale,
+                                                               float* __restrict__ out) {
+    constexpr int CW = HD / 4;                         // head columns owned by one wave
+    constexpr int VW = CW / 32;                        // floats per lane per V load = O^T tiles per wave (1 or 2)
+    constexpr int NSTEP = HD / 8, GRP = 4, NG = NSTEP / GRP;
+    constexpr int LDP = 33;
+    extern __shared__ float lds[];
+    float* Qs = lds;                                   // [HD][33]   Q^T, k-major
+    float* Ps = lds + HD * ATT_LDQ;                    // [128][33]  P^T of the current super-tile
+    float* red = Ps + 128 * LDP;                       // [2][4][32] per-wave row max / row sum
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qt * 32;
+    const long long ld3 = 3LL * d;
+    const float* __restrict__ base = qkv + (long long)b * T * ld3 + (long long)h * HD;
+    const float* __restrict__ Kb = base + d;
+    const float* __restrict__ Vb = base + 2 * d + wid * CW;
+    {
+        constexpr int NQL = (HD + 63) / 64;
+        float qv[8][NQL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* src = base + (long long)min(q0 + wid * 8 + j, T - 1) * ld3;
+#pragma unroll
+            for (int i = 0; i < NQL; ++i) qv[j][i] = src[min(lane + 64 * i, HD - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = wid * 8 + j;
+            const bool ok = q0 + q < T;
+#pragma unroll
+            for (int i = 0; i < NQL; ++i) {
+                const int k = lane + 64 * i;
+                if (k < HD) Qs[k * ATT_LDQ + q] = ok ? qv[j][i] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16a O[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qidx = q0 + li;
+    const int key_limit = min(T, q0 + 32);             // keys >= key_limit are masked for every query of the tile
+    const bool pow2_scale = (HD == 64 || HD == 256);
+    const float inv_scale = 1.0f / scale;
+
+    for (int st0 = 0; st0 < key_limit; st0 += 128) {
+        const int key0 = st0 + wid * 32;
+        const bool active = key0 < key_limit;           // wave-uniform
+        f32x16a S;
+        float mt = -INFINITY;
+        if (active) {
+            const float4* __restrict__ krow =
+                reinterpret_cast<const float4*>(Kb + (long long)min(key0 + li, T - 1) * ld3) + lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            float4 kb[2][GRP];
+            float qb[2][GRP][4];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                kb[0][u] = krow[2 * u];
+                const float* qa = Qs + (8 * u + 4 * lh) * ATT_LDQ + li;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qb[0][u][c] = qa[c * ATT_LDQ];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) {
+                        kb[(g + 1) & 1][u] = krow[2 * ((g + 1) * GRP + u)];
+                        const float* qa = Qs + (8 * ((g + 1) * GRP + u) + 4 * lh) * ATT_LDQ + li;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) qb[(g + 1) & 1][u][c] = qa[c * ATT_LDQ];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const float4 kv = kb[g & 1][u];
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qb[g & 1][u][0], S, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qb[g & 1][u][1], S, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qb[g & 1][u][2], S, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qb[g & 1][u][3], S, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float sv = pow2_scale ? S[r] * inv_scale : S[r] / scale;
+                S[r] = (key <= qidx) ? sv : -INFINITY;
+                mt = fmaxf(mt, S[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        }
+        if (lh == 0) red[wid * 32 + li] = mt;
+        __syncthreads();
+        const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (active && m_new != -INFINITY) ? __expf(S[r] - m_new) : 0.f;
+            Ps[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = p;
+            ps += p;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        if (lh == 0) red[128 + wid * 32 + li] = ps;
+        __syncthreads();
+        l_run = l_run * alpha + ((red[128 + li] + red[160 + li]) + (red[192 + li] + red[224 + li]));
+        if (__any(alpha != 1.0f && m_run != -INFINITY)) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        }
+        m_run = m_new;
+        // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P^T[key][q]
+        const int nsteps = (min(128, key_limit - st0) + 1) >> 1;       // key pairs (2t, 2t+1), wave-uniform
+        constexpr int VD = 8;
+        float vr[VD][4];
+        const float* vbase = Vb + VW * li;
+#pragma unroll
+        for (int t = 0; t < VD - 1; ++t)
+            VLoad<VW>::ld(vbase + (long long)min(st0 + 2 * min(t, nsteps - 1) + lh, T - 1) * ld3, vr[t]);
+        for (int t0 = 0; t0 < nsteps; t0 += VD) {
+#pragma unroll
+            for (int u = 0; u < VD; ++u) {
+                const int t = t0 + u;
+                if (t < nsteps) {
+                    const int tn = min(t + VD - 1, nsteps - 1);
+                    VLoad<VW>::ld(vbase + (long long)min(st0 + 2 * tn + lh, T - 1) * ld3, vr[(u + VD - 1) % VD]);
+                    const float pb = Ps[(2 * t + lh) * LDP + li];
+#pragma unroll
+                    for (int j = 0; j < VW; ++j)
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[u][j], pb, O[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- normalise, transpose through LDS (re-using the Q buffer), coalesced row stores
+    __syncthreads();
+    constexpr int LDO = HD + 1;
+    {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int j = 0; j < VW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = wid * CW + VW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + j;
+                lds[li * LDO + c] = O[j][r] * inv;
+            }
+    }
+    __syncthreads();
+    for (int q = wid; q < 32; q += 4) {
+        if (q0 + q >= T) break;
+        float* dst = out + ((long long)b * T + q0 + q) * d + (long long)h * HD;
+        for (int c = lane * 4; c < HD; c += 256) {
+            const float* sp = &lds[q * LDO + c];
+            *reinterpret_cast<float4*>(dst + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    }
+}
+
+template <int HD>
+static int launch_colsplit(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+    size_t lds = ((size_t)HD * ATT_LDQ + 128 * 33 + 256) * 4;
+    const size_t o_bytes = (size_t)32 * (HD + 1) * 4;
+    if (o_bytes > lds) lds = o_bytes;
+    ProfScope prof(PK_ATTN_FUSED, 2.0 * B * H * (double)T * T * HD, s);
+    hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3(cdiv(T, 32), H, B), dim3(256), lds, s, qkv, T, d,
+                       (float)sqrt((double)HD), out);
+    R4D_CHECK_LAUNCH("attn_colsplit");
+    return R4D_OK;
+}
+
 template <int HD>
 static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
     constexpr int NCB = HD / 32;
@@ -279,6 +469,8 @@ static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, h
     return R4D_OK;
 }
 
+int g_attention_variant = 0;          // tuning aid: 1 forces the key-split kernel at head_dim 128 / 256
+
 // returns R4D_OK, an error, or +1 when the head_dim has no fused instantiation (caller falls back)
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
     const int hd = d / H;
@@ -287,8 +479,10 @@ int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* 
         case 32: return launch_hd<32>(qkv, B, T, H, d, out, s);
         case 64: return launch_hd<64>(qkv, B, T, H, d, out, s);
         case 96: return launch_hd<96>(qkv, B, T, H, d, out, s);
-        case 128: return launch_hd<128>(qkv, B, T, H, d, out, s);
-        case 256: return launch_hd<256>(qkv, B, T, H, d, out, s);
+        case 128: return g_attention_variant == 1 ? launch_hd<128>(qkv, B, T, H, d, out, s)
+                                                  : launch_colsplit<128>(qkv, B, T, H, d, out, s);
+        case 256: return g_attention_variant == 1 ? launch_hd<256>(qkv, B, T, H, d, out, s)
+                                                  : launch_colsplit<256>(qkv, B, T, H, d, out, s);
         default: return 1;
     }
 }

@@ -36,10 +36,10 @@ static inline int tpad(int T) { return (T + 127) / 128 * 128; }
 int g_attention_fused = -1;           // -1 auto (by head_dim), 0 three launches, 1 fused wherever instantiated
 
 static int attention(const float* qkv, int B, int T, int H, int d, float* a_out, float* scores, hipStream_t s) {
-    // Measured on MI355X (tools/attn_bench.py, B=128): the fused kernel is 1.1-2.7x faster than the three-launch
-    // form for head_dim <= 128; at head_dim 256 (UCI_13) its 128 O^T accumulators leave one wave per SIMD and it
-    // is ~20 % slower, so auto keeps the GEMM form there.
-    const bool fused = g_attention_fused == 1 || (g_attention_fused < 0 && d / H <= 128);
+    // Measured on MI355X (tools/attn_bench.py, B=128, T=128..300): the fused kernels are 1.15-2.7x faster than the
+    // three-launch form at every instantiated head_dim (key-split kernel for hd <= 96, column-split for 128 / 256),
+    // so auto == fused; head dims without an instantiation fall through to the GEMM form.
+    const bool fused = g_attention_fused != 0;
     if (fused) {
         const int rc_f = launch_attention_fused(qkv, B, T, H, d, a_out, s);
         if (rc_f <= 0) return rc_f;                      // +1: no fused instantiation for this head_dim
@@ -109,7 +109,12 @@ using namespace r4d;
 extern "C" {
 
 int r4d_abi_version(void) { return R4D_ABI_VERSION; }
-int r4d_set_attention_fused(int32_t mode) { g_attention_fused = mode < 0 ? -1 : (mode != 0); return R4D_OK; }
+int r4d_set_attention_fused(int32_t mode) {
+    // mode 2: fused with the key-split kernel forced at head_dim 128/256 (A/B tuning); 1: fused (column-split there)
+    g_attention_variant = (mode == 2) ? 1 : 0;
+    g_attention_fused = mode < 0 ? -1 : (mode != 0);
+    return R4D_OK;
+}
 const char* r4d_last_error(void) { return g_err; }
 
 size_t r4d_gpt2_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B, int32_t T) {

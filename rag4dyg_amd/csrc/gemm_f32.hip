@@ -342,6 +342,7 @@ static int pick_tile(const GemmArgs& g) {
 int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {
     GemmArgs g = g0;
     R4D_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+    R4D_REQUIRE(g.nbatch >= 1 && g.nbatch <= 65535, "gemm: batch count %d outside [1, 65535] (grid.z limit)", g.nbatch);
     R4D_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 (got %d,%d)", g.lda, g.ldb);
     R4D_REQUIRE(g.causal == CAUSAL_PV || g.K % 4 == 0, "gemm: K=%d must be a multiple of 4", g.K);
     R4D_REQUIRE(g.b_trans || g.N % 4 == 0, "gemm: N=%d must be a multiple of 4 for row-major B", g.N);

@@ -235,6 +235,7 @@ template <typename T>
 static int topk_rows(const T* vals, int rows, int n, long long ld, int k, long long index_offset, T* out_v,
                      long long* out_i, void* ws, size_t ws_bytes, hipStream_t s) {
     R4D_REQUIRE(k >= 1 && k <= 64 && k <= n, "topk: k=%d must be in [1, min(64, n=%d)]", k, n);
+    R4D_REQUIRE(rows >= 1 && rows <= 65535, "topk: %d rows outside [1, 65535] per call (grid.y limit)", rows);
     if (ws_bytes < topk_ws_bytes<T>(rows, n, k)) {
         set_error("topk: workspace too small");
         return R4D_ERR_WORKSPACE;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const T* __restrict__ s
 template <typename T>
 static int argsort_desc(const T* scores, int rows, int n, int32_t* perm, hipStream_t s) {
     R4D_REQUIRE(scores && perm, "argsort: null pointer");
-    R4D_REQUIRE(rows >= 0 && n >= 1 && n <= 65536, "argsort: n=%d out of range [1,65536]", n);
+    R4D_REQUIRE(rows >= 0 && rows <= 65535 && n >= 1 && n <= 65536, "argsort: rows=%d (<= 65535), n=%d (<= 65536) out of range", rows, n);
     if (rows == 0) return R4D_OK;
     ProfScope prof(PK_RANK_COUNT, (double)rows * n * (sizeof(T) + 4), s);
     hipLaunchKernelGGL((rank_count_kernel<T>), dim3(cdiv(n, 256), rows), dim3(256), 0, s, scores, n, perm);
@@ -355,7 +356,7 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
                        int64_t index_offset, float* out_val_d, int64_t* out_idx_d, float* out_scores_d,
                        void* workspace_d, size_t workspace_bytes, void* stream) {
     R4D_REQUIRE(q_hat_d && pool_hat_d && out_val_d && out_idx_d, "score_topk: null pointer");
-    R4D_REQUIRE(Q >= 1 && N >= 1 && d >= 4 && d % 4 == 0, "score_topk: bad shape Q=%d N=%d d=%d", Q, N, d);
+    R4D_REQUIRE(Q >= 1 && Q <= 65535 && N >= 1 && d >= 4 && d % 4 == 0, "score_topk: bad shape Q=%d N=%d d=%d", Q, N, d);
     R4D_REQUIRE(k >= 1 && k <= 64 && k <= N, "score_topk: k=%d must be in [1, min(64, N=%d)]", k, N);
     if (!workspace_d || workspace_bytes < r4d_score_topk_workspace_bytes(Q, N, k)) {
         set_error("score_topk: workspace too small");

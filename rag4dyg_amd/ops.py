@@ -59,7 +59,7 @@ def conv1d(x, w, bias, epilogue="none", residual=None):
 
 def set_attention_fused(mode):
     """-1 / None: auto by head_dim (default); True: fused flash-style kernel; False: three-launch GEMM form."""
-    _lib.load().r4d_set_attention_fused(-1 if mode is None or mode == -1 else int(bool(mode)))
+    _lib.load().r4d_set_attention_fused(-1 if mode is None or mode == -1 else (2 if mode == 2 else int(bool(mode))))
 
 
 def attention(qkv, n_head):

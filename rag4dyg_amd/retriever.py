@@ -18,7 +18,7 @@ from torch.utils.data import DataLoader
 
 from . import ops
 from .dataloader import LineByLineTextDatasetHistory, get_dataloader, load_and_cache_examples
-from .retrieval import PoolIndex
+from .retrieval import PoolIndex, encode_batches
 
 
 def hit_rate_at_k(predictions, targets, k=1):
@@ -70,7 +70,7 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
     scores = DataLoader(scores, batch_size=args.eval_batch_size, shuffle=False, num_workers=0, drop_last=False)
 
     # HOT LOOP 1 (:414-422): pool embeddings, then one resident normalised index
-    train_embeddings = torch.cat([model.encode_meanpool(batch.to(device)) for batch in train_dataloader], dim=0)
+    train_embeddings = encode_batches(model, [batch.to(device) for batch in train_dataloader])    # fused groups
     print('size of train_embeddings: ', train_embeddings.size())
     index = PoolIndex(train_embeddings)
     n_pool = len(index)

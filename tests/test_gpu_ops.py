@@ -70,10 +70,10 @@ def test_conv1d_golden(dev):
     assert rel_err(y, g["conv_y"]) < 1e-5
 
 
-@pytest.fixture(params=["fused", "unfused"])
+@pytest.fixture(params=["fused", "keysplit", "unfused"])
 def attn_mode(request):
     from rag4dyg_amd import ops
-    ops.set_attention_fused(request.param == "fused")
+    ops.set_attention_fused({"fused": True, "keysplit": 2, "unfused": False}[request.param])
     yield request.param
     ops.set_attention_fused(None)
 

@@ -13,7 +13,7 @@ for (B, T, H, hd) in SHAPES:
     d = H * hd
     qkv = torch.randn(B, T, 3 * d, device=dev)
     res = []
-    for fused in (1, 0):
+    for fused in (1, 2, 0):
         ops.set_attention_fused(fused)
         for _ in range(3):
             ops.attention(qkv, H)
@@ -25,5 +25,5 @@ for (B, T, H, hd) in SHAPES:
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20 * 1e3)
     flop = 2.0 * B * H * T * T * hd
-    print(f"B={B:4d} T={T:4d} H={H} hd={hd:3d}  fused {res[0]:8.1f} us ({flop/res[0]/1e6:6.1f} TF)   unfused {res[1]:8.1f} us ({flop/res[1]/1e6:6.1f} TF)", flush=True)
+    print(f"B={B:4d} T={T:4d} H={H} hd={hd:3d}  fused {res[0]:8.1f} us ({flop/res[0]/1e6:6.1f} TF)  keysplit {res[1]:8.1f} us   unfused {res[2]:8.1f} us ({flop/res[2]/1e6:6.1f} TF)", flush=True)
 ops.set_attention_fused(None)
