@@ -216,7 +216,7 @@ def main():
         lib.r4d_profile_enable(0)
         tot_ms = sum(v["ms"] for v in prof.values())
         for name, v in prof.items():
-            is_mfma = name.startswith("gemm")
+            is_mfma = name.startswith(("gemm", "attn"))
             rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
             kernels[name] = {"share": round(v["ms"] / tot_ms, 4), "launches": v["launches"],
                              "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
@@ -227,7 +227,7 @@ def main():
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-        if dom.startswith("gemm"):
+        if dom.startswith(("gemm", "attn")):
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

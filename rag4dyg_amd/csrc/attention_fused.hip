@@ -22,6 +22,15 @@
 namespace r4d {
 
 typedef float f32x16a __attribute__((ext_vector_type(16)));
+
+// Up to ATT_MAXG right-padded batches (each with its own T) in ONE launch: blockIdx.z walks the sequences of all
+// batches; the batch of a sequence is found by a short scan of the prefix table (kernel argument, by value).
+struct AttnGroups {
+    int n;
+    int seq_prefix[ATT_MAXG + 1];     // first global sequence index of each batch
+    int T[ATT_MAXG];
+    long long row0[ATT_MAXG];         // first token row of each batch in qkv / out
+};
 constexpr int ATT_LDQ = 33;
 
 template <int VW>
@@ -47,7 +56,7 @@ struct VLoad<4> {
 
 // HD = head_dim in {32, 64, 96, 128, 256}.  VW = floats per lane per V load, NU = V loads per key pair.
 template <int HD>
-__global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(const float* __restrict__ qkv, int T, int d, float scale,
+__global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, float scale,
                                                          float* __restrict__ out) {
     constexpr int VW = HD >= 128 ? 4 : HD / 32;
     constexpr int NU = HD >= 128 ? HD / 128 : 1;
@@ -57,10 +66,15 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
     extern __shared__ float lds[];                     // Q tile [HD][33]; later 2 merge slots; later O tile [32][HD+4]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qt = blockIdx.x, h = blockIdx.y;
+    int gi = 0;
+    while (gi + 1 < G.n && (int)blockIdx.z >= G.seq_prefix[gi + 1]) ++gi;
+    const int T = G.T[gi];
     const int q0 = qt * 32;
+    if (q0 >= T) return;                               // grid.x covers the longest batch
+    const long long rowb = G.row0[gi] + (long long)((int)blockIdx.z - G.seq_prefix[gi]) * T;     // first row of the sequence
     const long long ld3 = 3LL * d;
-    const float* __restrict__ base = qkv + (long long)b * T * ld3 + (long long)h * HD;
+    const float* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
     const float* __restrict__ Kb = base + d;
     const float* __restrict__ Vb = base + 2 * d;
 
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
     __syncthreads();
     for (int q = wid; q < 32; q += 4) {
         if (q0 + q >= T) break;
-        float* dst = out + ((long long)b * T + q0 + q) * d + (long long)h * HD;
+        float* dst = out + (rowb + q0 + q) * d + (long long)h * HD;
         for (int c = lane * 4; c < HD; c += 256) {
             const float* sp = &lds[q * LDO + c];
             *reinterpret_cast<float4*>(dst + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
 // 128 keys (B operand = P^T from LDS, A operand = V rows, coalesced 4/8-byte loads).  O^T is HD/8 registers per
 // lane (32 at hd 256), so three workgroups fit per CU, the waves are always balanced and there is no merge phase.
 template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, int T, int d, float scale,
+__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, float scale,
                                                                float* __restrict__ out) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // floats per lane per V load = O^T tiles per wave (1 or 2)
@@ -274,10 +288,15 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
     float* red = Ps + 128 * LDP;                       // [2][4][32] per-wave row max / row sum
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qt = blockIdx.x, h = blockIdx.y;
+    int gi = 0;
+    while (gi + 1 < G.n && (int)blockIdx.z >= G.seq_prefix[gi + 1]) ++gi;
+    const int T = G.T[gi];
     const int q0 = qt * 32;
+    if (q0 >= T) return;                               // grid.x covers the longest batch
+    const long long rowb = G.row0[gi] + (long long)((int)blockIdx.z - G.seq_prefix[gi]) * T;     // first row of the sequence
     const long long ld3 = 3LL * d;
-    const float* __restrict__ base = qkv + (long long)b * T * ld3 + (long long)h * HD;
+    const float* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
     const float* __restrict__ Kb = base + d;
     const float* __restrict__ Vb = base + 2 * d + wid * CW;
     {
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
     __syncthreads();
     for (int q = wid; q < 32; q += 4) {
         if (q0 + q >= T) break;
-        float* dst = out + ((long long)b * T + q0 + q) * d + (long long)h * HD;
+        float* dst = out + (rowb + q0 + q) * d + (long long)h * HD;
         for (int c = lane * 4; c < HD; c += 256) {
             const float* sp = &lds[q * LDO + c];
             *reinterpret_cast<float4*>(dst + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
@@ -432,19 +451,21 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 }
 
 template <int HD>
-static int launch_colsplit(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+static int launch_colsplit(const float* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out,
+                           hipStream_t s) {
     size_t lds = ((size_t)HD * ATT_LDQ + 128 * 33 + 256) * 4;
     const size_t o_bytes = (size_t)32 * (HD + 1) * 4;
     if (o_bytes > lds) lds = o_bytes;
-    ProfScope prof(PK_ATTN_FUSED, 2.0 * B * H * (double)T * T * HD, s);
-    hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3(cdiv(T, 32), H, B), dim3(256), lds, s, qkv, T, d,
-                       (float)sqrt((double)HD), out);
+    ProfScope prof(PK_ATTN_FUSED, flop, s);
+    hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3(cdiv(Tmax, 32), H, G.seq_prefix[G.n]), dim3(256), lds, s, qkv, G,
+                       d, (float)sqrt((double)HD), out);
     R4D_CHECK_LAUNCH("attn_colsplit");
     return R4D_OK;
 }
 
 template <int HD>
-static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+static int launch_hd(const float* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out,
+                     hipStream_t s) {
     constexpr int NCB = HD / 32;
     const size_t q_bytes = (size_t)HD * ATT_LDQ * 4, slot_bytes = 2 * ((size_t)NCB * 16 * 64 + 128) * 4,
                  o_bytes = (size_t)32 * (HD + 1) * 4;
@@ -462,8 +483,8 @@ static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, h
         }
     }
     // algorithmic flop: causal half of Q.K^T and P.V = 2 * T^2 * hd per head
-    ProfScope prof(PK_ATTN_FUSED, 2.0 * B * H * (double)T * T * HD, s);
-    hipLaunchKernelGGL((attn_fused_kernel<HD>), dim3(cdiv(T, 32), H, B), dim3(256), lds, s, qkv, T, d,
+    ProfScope prof(PK_ATTN_FUSED, flop, s);
+    hipLaunchKernelGGL((attn_fused_kernel<HD>), dim3(cdiv(Tmax, 32), H, G.seq_prefix[G.n]), dim3(256), lds, s, qkv, G, d,
                        (float)sqrt((double)HD), out);
     R4D_CHECK_LAUNCH("attn_fused");
     return R4D_OK;
@@ -471,20 +492,43 @@ static int launch_hd(const float* qkv, int B, int T, int H, int d, float* out, h
 
 int g_attention_variant = 0;          // tuning aid: 1 forces the key-split kernel at head_dim 128 / 256
 
-// returns R4D_OK, an error, or +1 when the head_dim has no fused instantiation (caller falls back)
-int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+// Attention of n <= ATT_MAXG batches in one launch; batch g holds Bs[g] sequences of Ts[g] tokens starting at token
+// row row0s[g] of qkv [rows, 3d] / out [rows, d].  Returns R4D_OK, an error, or +1 when head_dim has no fused
+// instantiation (caller falls back to the three-launch form).
+int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,
+                                  int d, float* out, hipStream_t s) {
     const int hd = d / H;
-    R4D_REQUIRE(B <= 65535 && H <= 65535, "attention: B=%d / H=%d exceed the grid limits", B, H);
+    R4D_REQUIRE(n >= 1 && n <= ATT_MAXG, "attention: %d batches per launch (max %d)", n, ATT_MAXG);
+    R4D_REQUIRE(H <= 65535, "attention: H=%d exceeds the grid limit", H);
+    AttnGroups G;
+    G.n = n;
+    G.seq_prefix[0] = 0;
+    int Tmax = 0;
+    double flop = 0.0;                                  // causal half of Q.K^T and P.V: 2 * T^2 * hd per head
+    for (int g = 0; g < n; ++g) {
+        G.seq_prefix[g + 1] = G.seq_prefix[g] + Bs[g];
+        G.T[g] = Ts[g];
+        G.row0[g] = row0s[g];
+        if (Ts[g] > Tmax) Tmax = Ts[g];
+        flop += 2.0 * Bs[g] * H * (double)Ts[g] * Ts[g] * hd;
+    }
+    for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
+    R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
     switch (hd) {
-        case 32: return launch_hd<32>(qkv, B, T, H, d, out, s);
-        case 64: return launch_hd<64>(qkv, B, T, H, d, out, s);
-        case 96: return launch_hd<96>(qkv, B, T, H, d, out, s);
-        case 128: return g_attention_variant == 1 ? launch_hd<128>(qkv, B, T, H, d, out, s)
-                                                  : launch_colsplit<128>(qkv, B, T, H, d, out, s);
-        case 256: return g_attention_variant == 1 ? launch_hd<256>(qkv, B, T, H, d, out, s)
-                                                  : launch_colsplit<256>(qkv, B, T, H, d, out, s);
+        case 32: return launch_hd<32>(qkv, G, Tmax, flop, H, d, out, s);
+        case 64: return launch_hd<64>(qkv, G, Tmax, flop, H, d, out, s);
+        case 96: return launch_hd<96>(qkv, G, Tmax, flop, H, d, out, s);
+        case 128: return g_attention_variant == 1 ? launch_hd<128>(qkv, G, Tmax, flop, H, d, out, s)
+                                                  : launch_colsplit<128>(qkv, G, Tmax, flop, H, d, out, s);
+        case 256: return g_attention_variant == 1 ? launch_hd<256>(qkv, G, Tmax, flop, H, d, out, s)
+                                                  : launch_colsplit<256>(qkv, G, Tmax, flop, H, d, out, s);
         default: return 1;
     }
+}
+
+int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s) {
+    const long long row0 = 0;
+    return launch_attention_fused_groups(qkv, 1, &B, &T, &row0, H, d, out, s);
 }
 
 }  // namespace r4d

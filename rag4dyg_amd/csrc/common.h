@@ -74,6 +74,9 @@ int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
+constexpr int ATT_MAXG = 16;
+int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,
+                                  int d, float* out, hipStream_t s);
 extern int g_attention_variant;
 extern int g_attention_fused;        // -1 auto (default), 1 fused, 0 three-launch GEMM form (r4d_set_attention_fused)
 constexpr int LNF_ROWS_PER_CHUNK = 16;

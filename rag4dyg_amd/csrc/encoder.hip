@@ -196,9 +196,29 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         }
         float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
         if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
-        for (int g = 0; g < n_groups; ++g) {
-            const Group& G = groups[g];
-            if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
+        bool fused_done = false;
+        if (g_attention_fused != 0) {                    // all batches of the call in ceil(n/16) fused launches
+            fused_done = true;
+            for (int g0 = 0; g0 < n_groups && fused_done; g0 += ATT_MAXG) {
+                int Bs[ATT_MAXG], Ts[ATT_MAXG];
+                long long r0[ATT_MAXG];
+                const int n = n_groups - g0 < ATT_MAXG ? n_groups - g0 : ATT_MAXG;
+                int nseq = 0;
+                for (int j = 0; j < n; ++j) {
+                    Bs[j] = groups[g0 + j].B; Ts[j] = groups[g0 + j].T; r0[j] = (long long)groups[g0 + j].row0;
+                    nseq += Bs[j];
+                }
+                if (nseq > 65535) { fused_done = false; break; }
+                rc = launch_attention_fused_groups(qkv, n, Bs, Ts, r0, H, d, ws.att, s);
+                if (rc < 0) return rc;
+                if (rc > 0) fused_done = false;          // no fused instantiation for this head_dim
+            }
+        }
+        if (!fused_done) {
+            for (int g = 0; g < n_groups; ++g) {
+                const Group& G = groups[g];
+                if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
+            }
         }
         if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
