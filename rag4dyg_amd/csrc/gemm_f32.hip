@@ -24,9 +24,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 __device__ __forceinline__ float gelu_new_f(float x) {
-    // 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))  -- modeling_gpt2.py:25,206
-    const float c = 0.7978845608028654f;
-    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+    // gelu_new(x) = 0.5x(1+tanh(u)), u = sqrt(2/pi)(x+0.044715x^3)  -- modeling_gpt2.py:25,206.
+    // Algebraically 0.5(1+tanh(u)) = 1/(1+exp(-2u)), so the epilogue is v_exp_f32 + v_rcp_f32 (~8 VALU ops)
+    // instead of ocml tanhf (~40): at K = 512 the tanh form was ~15 % of a c_fc tile's issue time.
+    // |error| < 3e-7 |x| (checked against the oracle at 1e-5 relative in tests/test_gpu_ops.py).
+    const float c2 = 2.0f * 0.7978845608028654f;
+    const float u2 = c2 * (x + 0.044715f * x * x * x);
+    return x * __frcp_rn(1.0f + __expf(-u2));
 }
 
 template <int N>
