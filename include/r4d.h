@@ -152,8 +152,9 @@ int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* ou
                  void* workspace_d, size_t workspace_bytes, void* stream);
 /* Merge G per-shard candidate lists (after the RCCL all-gather): vals_d [G,Q,k], idx_d [G,Q,k]
  * -> out [Q,k], same canonical order; result == single-GPU top-k by construction. */
+size_t r4d_merge_topk_workspace_bytes(int32_t G, int32_t Q, int32_t k);
 int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k,
-                       float* out_val_d, int64_t* out_idx_d, void* stream);
+                       float* out_val_d, int64_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Full-row ranking (file-compat mode): perm_d int32 [rows,n] = stable argsort of -scores (ties by
  * ascending index) == np.argsort(-S, axis=1, kind='stable').  n <= 65536. */
 int r4d_argsort_desc_f32(const float* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream);

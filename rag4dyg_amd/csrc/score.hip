@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 //   * the 32 normalised queries sit in LDS k-major (Qs[k][q], d*132 B) for the whole kernel; an MFMA A operand
 //     is one conflict-free ds_read_b32 (row stride 33 floats; 12 % of the LDS read rate at full MFMA issue);
 //   * every wavefront owns whole 32-row pool tiles and the full d, so there is no cross-wave reduction and no
-//     barrier in the loop; lane (j, h) streams row j of its tile with 16-byte global loads (k permuted
-//     identically on both operands: component c of load s is k = 8s + 4h + c), 8 loads = 8 KB per wave in flight;
+//     barrier in the loop; lane (j, h) streams row j of its tile with 16-byte global loads, the lane pair of a row
+//     consuming each 128-byte line at once (k permuted identically on both operands), 16 KB per wave in flight;
 //   * exact-f32 MFMA 32x32x2 accumulates S[32 q x 32 rows]; the epilogue applies (x+1)/2 and writes 128-byte
 //     row segments of the score matrix, from which topk_seg_kernel selects.
 typedef float f32x16s __attribute__((ext_vector_type(16)));
@@ -54,26 +54,29 @@ __global__ __launch_bounds__(256) void pool_scan_kernel(const float* __restrict_
     }
     __syncthreads();
     const int ntiles = (N + 31) / 32;
-    const int nsteps = d / 8;
+    // k order: lane half h of row j owns the 64-byte halves [32g + 16h, 32g + 16h + 16) of the row, i.e. the lane
+    // pair (j,0),(j,1) consumes each 128-byte line of the row at once (four 16-byte loads per lane per line) instead
+    // of revisiting it over four loop trips; component c of load u of group g is k = 32g + 16h + 4u + c on BOTH
+    // operands.  d % 32 == 0 here (r4d_score_topk_f32 falls back to the GEMM otherwise).
+    const int ngroups = d / 32;
     for (int t = blockIdx.x * 4 + wid; t < ntiles; t += gridDim.x * 4) {
         const int row = t * 32 + li;
         const float4* __restrict__ prow =
-            reinterpret_cast<const float4*>(pool + (long long)min(row, N - 1) * d) + lh;     // clamped: always valid
+            reinterpret_cast<const float4*>(pool + (long long)min(row, N - 1) * d) + 4 * lh;   // clamped: always valid
         f32x16s acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // loads are unconditional from clamped indices (a `cond ? *p : 0` select would become a flat load of a
-        // scratch zero); out-of-range steps are skipped by the wave-uniform guards around the MFMAs
-        float4 b0[SCAN_U], b1[SCAN_U];
+        // two groups (2 x 64 B per lane) per buffer, ping-pong: 16 loads = 256 B per lane in flight
+        float4 b0[8], b1[8];
 #pragma unroll
-        for (int u = 0; u < SCAN_U; ++u) b0[u] = prow[2 * min(u, nsteps - 1)];
-        for (int s0 = 0; s0 < nsteps; s0 += 2 * SCAN_U) {
+        for (int u = 0; u < 8; ++u) b0[u] = prow[8 * min(u >> 2, ngroups - 1) + (u & 3)];
+        for (int g0 = 0; g0 < ngroups; g0 += 4) {
 #pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) b1[u] = prow[2 * min(s0 + SCAN_U + u, nsteps - 1)];
+            for (int u = 0; u < 8; ++u) b1[u] = prow[8 * min(g0 + 2 + (u >> 2), ngroups - 1) + (u & 3)];
 #pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) {
-                if (s0 + u < nsteps) {
-                    const float* qa = Qs + (8 * (s0 + u) + 4 * lh) * SCAN_LDQ + li;
+            for (int u = 0; u < 8; ++u) {
+                if (g0 + (u >> 2) < ngroups) {
+                    const float* qa = Qs + (32 * (g0 + (u >> 2)) + 16 * lh + 4 * (u & 3)) * SCAN_LDQ + li;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b0[u].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b0[u].y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b0[u].z, acc, 0, 0, 0);
@@ -81,11 +84,11 @@ __global__ __launch_bounds__(256) void pool_scan_kernel(const float* __restrict_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) b0[u] = prow[2 * min(s0 + 2 * SCAN_U + u, nsteps - 1)];
+            for (int u = 0; u < 8; ++u) b0[u] = prow[8 * min(g0 + 4 + (u >> 2), ngroups - 1) + (u & 3)];
 #pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) {
-                if (s0 + SCAN_U + u < nsteps) {
-                    const float* qa = Qs + (8 * (s0 + SCAN_U + u) + 4 * lh) * SCAN_LDQ + li;
+            for (int u = 0; u < 8; ++u) {
+                if (g0 + 2 + (u >> 2) < ngroups) {
+                    const float* qa = Qs + (32 * (g0 + 2 + (u >> 2)) + 16 * lh + 4 * (u & 3)) * SCAN_LDQ + li;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b1[u].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b1[u].y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b1[u].z, acc, 0, 0, 0);
@@ -148,74 +151,92 @@ __device__ __forceinline__ Cand<T> shfl_xor_cand(const Cand<T>& c, int o) {
 template <typename T>
 __device__ __forceinline__ T neg_inf() { return (T)(-INFINITY); }
 
-constexpr int TOPK_E = 16;                 // candidates per thread
-constexpr int TOPK_SEG = 256 * TOPK_E;     // candidates per workgroup
+constexpr int TOPK_E = 16;                 // candidates per lane
+constexpr int TOPK_SEG = 64 * TOPK_E;      // candidates per WAVEFRONT segment
 
-// k rounds of workgroup-wide arg-best with removal over the register-resident candidates c[0..E).
-// Every thread keeps its current local best; only the round's winner rescans.  Results to out[0..k).
+// Candidate inside a segment: value + POSITION in the row / candidate list.  Positions order ties exactly like
+// global indices do (level 1: position == column; deeper levels: candidate lists are laid out by (segment, rank) and
+// every segment is already sorted by (value desc, index asc)), so the reduction carries 32-bit positions and the
+// 64-bit global index is looked up only for the k winners.
 template <typename T>
-__device__ void block_topk_rounds(Cand<T> (&c)[TOPK_E], int k, T* out_v, long long* out_i) {
-    __shared__ Cand<T> wbest[4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const Cand<T> none = {neg_inf<T>(), 0x7fffffffffffffffLL};
+struct WCand {
+    T v;
+    unsigned int p;
+};
+template <typename T>
+__device__ __forceinline__ bool wbetter(const WCand<T>& a, const WCand<T>& b) {
+    return (a.v > b.v) | ((a.v == b.v) & (a.p < b.p));          // branch-free: || / && compile to exec-mask branches
+}
+
+// One wavefront reduces one segment of 1024 candidates of one row to its k best: k rounds of a 6-step shuffle
+// arg-best over (value, position) pairs with removal -- no LDS, no barrier.  Every lane keeps its current local best;
+// only the round's winner rescans its 16 registers.
+//   vals [rows, ld]; idx_in (nullable) parallel global indices, else index = column + index_offset.
+//   out_v / out_i [rows, nseg*k]
+template <typename T>
+__global__ __launch_bounds__(256) void topk_seg_kernel(const T* __restrict__ vals, const long long* __restrict__ idx_in,
+                                                       int n, long long ld, int k, long long index_offset, int nseg,
+                                                       int rows, T* __restrict__ out_v, long long* __restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);        // (row, segment) of this wave
+    if (unit >= (long long)rows * nseg) return;
+    const int row = (int)(unit / nseg), seg = (int)(unit % nseg);
+    const T* v = vals + (long long)row * ld;
+    const WCand<T> none = {neg_inf<T>(), 0xffffffffu};
+    WCand<T> c[TOPK_E];
+#pragma unroll
+    for (int e = 0; e < TOPK_E; ++e) {
+        const int col = seg * TOPK_SEG + e * 64 + lane;
+        const T x = v[min(col, n - 1)];                                 // clamped address, value masked below
+        c[e].v = (col < n && x == x) ? x : neg_inf<T>();                // NaN sorts last (as numpy)
+        c[e].p = (col < n) ? (unsigned)col : 0xffffffffu;
+    }
     auto local_best = [&](int& slot) {
-        Cand<T> b = none;
+        WCand<T> b = none;
         slot = -1;
 #pragma unroll
-        for (int e = 0; e < TOPK_E; ++e)
-            if (better(c[e], b)) { b = c[e]; slot = e; }
+        for (int e = 0; e < TOPK_E; ++e) {
+            const bool bt = wbetter(c[e], b);
+            b.v = bt ? c[e].v : b.v; b.p = bt ? c[e].p : b.p; slot = bt ? e : slot;
+        }
         return b;
     };
     int slot;
-    Cand<T> mine = local_best(slot);
+    WCand<T> mine = local_best(slot);
+    T* ov = out_v + ((long long)row * nseg + seg) * k;
+    long long* oi = out_i + ((long long)row * nseg + seg) * k;
+    const long long* ii = idx_in ? idx_in + (long long)row * ld : nullptr;
+    WCand<T> won = none;                                                // lane r keeps the r-th winner (k <= 64)
     for (int r = 0; r < k; ++r) {
-        Cand<T> w = mine;
+        WCand<T> w = mine;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const Cand<T> t = shfl_xor_cand(w, o);
-            if (better(t, w)) w = t;
+            WCand<T> t;
+            t.v = __shfl_xor(w.v, o, 64);
+            t.p = __shfl_xor(w.p, o, 64);
+            const bool bt = wbetter(t, w);
+            w.v = bt ? t.v : w.v; w.p = bt ? t.p : w.p;
         }
-        if (lane == 0) wbest[wid] = w;
-        __syncthreads();
-        Cand<T> g = wbest[0];
+        if (lane == r) won = w;
+        if (__any(slot >= 0 && mine.p == w.p)) {                        // positions are unique: exactly one owner
+            const bool own = slot >= 0 && mine.p == w.p;
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (better(wbest[q], g)) g = wbest[q];
-        __syncthreads();
-        if (threadIdx.x == 0) { out_v[r] = g.v; out_i[r] = g.i; }
-        if (slot >= 0 && mine.i == g.i && mine.v == g.v) {          // indices are unique: exactly one owner
-#pragma unroll
-            for (int e = 0; e < TOPK_E; ++e)
-                if (e == slot) c[e] = none;
-            mine = local_best(slot);
-        }
-    }
-}
-
-// One workgroup reduces one segment of TOPK_SEG candidates of one row to its k best.
-//   vals [rows, ld]; idx_in (nullable) parallel global indices, else index = column + index_offset.
-//   out_v/out_i [rows, nseg*k]
-template <typename T>
-__global__ __launch_bounds__(256) void topk_seg_kernel(const T* __restrict__ vals, const long long* __restrict__ idx_in,
-                                                       int n, long long ld, int k, long long index_offset,
-                                                       T* __restrict__ out_v, long long* __restrict__ out_i) {
-    const int seg = blockIdx.x, row = blockIdx.y, nseg = gridDim.x;
-    const T* v = vals + (long long)row * ld;
-    const long long* ii = idx_in ? idx_in + (long long)row * ld : nullptr;
-    Cand<T> c[TOPK_E];
-#pragma unroll
-    for (int e = 0; e < TOPK_E; ++e) {
-        const int col = seg * TOPK_SEG + e * 256 + threadIdx.x;
-        if (col < n) {
-            T x = v[col];
-            c[e].v = (x != x) ? neg_inf<T>() : x;
-            c[e].i = ii ? ii[col] : (long long)col + index_offset;
-        } else {
-            c[e].v = neg_inf<T>();
-            c[e].i = 0x7fffffffffffffffLL;
+            for (int e = 0; e < TOPK_E; ++e) {
+                const bool kill = own & (e == slot);
+                c[e].v = kill ? none.v : c[e].v; c[e].p = kill ? none.p : c[e].p;
+            }
+            int s2;
+            const WCand<T> nb = local_best(s2);
+            mine.v = own ? nb.v : mine.v; mine.p = own ? nb.p : mine.p; slot = own ? s2 : slot;
         }
     }
-    block_topk_rounds<T>(c, k, out_v + ((long long)row * nseg + seg) * k, out_i + ((long long)row * nseg + seg) * k);
+    // the k index look-ups and stores go out in parallel, off the selection loop's critical path
+    if (lane < k) {
+        const bool pad = won.p == 0xffffffffu;
+        const long long gi = ii ? ii[pad ? 0 : won.p] : (long long)won.p + index_offset;
+        ov[lane] = won.v;
+        oi[lane] = pad ? 0x7fffffffffffffffLL : gi;
+    }
 }
 
 template <typename T>
@@ -230,12 +251,12 @@ static size_t topk_ws_bytes(int rows, int n, int k) {
     return total + 256;
 }
 
-// rows x n values -> rows x k best (value, index).  Multi-level: segments of 4096 candidates.
+// rows x n values -> rows x k best (value, index).  Multi-level: wavefront segments of 1024 candidates.
 template <typename T>
 static int topk_rows(const T* vals, int rows, int n, long long ld, int k, long long index_offset, T* out_v,
                      long long* out_i, void* ws, size_t ws_bytes, hipStream_t s) {
     R4D_REQUIRE(k >= 1 && k <= 64 && k <= n, "topk: k=%d must be in [1, min(64, n=%d)]", k, n);
-    R4D_REQUIRE(rows >= 1 && rows <= 65535, "topk: %d rows outside [1, 65535] per call (grid.y limit)", rows);
+    R4D_REQUIRE(rows >= 1, "topk: no rows");
     if (ws_bytes < topk_ws_bytes<T>(rows, n, k)) {
         set_error("topk: workspace too small");
         return R4D_ERR_WORKSPACE;
@@ -253,9 +274,10 @@ static int topk_rows(const T* vals, int rows, int n, long long ld, int k, long l
             ov = (T*)wp; wp += align_up((size_t)rows * nseg * k * sizeof(T), 256);
             oi = (long long*)wp; wp += align_up((size_t)rows * nseg * k * 8, 256);
         }
+        const long long units = (long long)rows * nseg;
         ProfScope prof(PK_TOPK, (double)rows * cur * (sizeof(T) + (ci ? 8 : 0)), s);
-        hipLaunchKernelGGL((topk_seg_kernel<T>), dim3(nseg, rows), dim3(256), 0, s, cv, ci, (int)cur, cld, k,
-                           index_offset, ov, oi);
+        hipLaunchKernelGGL((topk_seg_kernel<T>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, cv, ci, (int)cur, cld,
+                           k, index_offset, nseg, rows, ov, oi);
         R4D_CHECK_LAUNCH("topk_seg");
         if (nseg == 1) break;
         cv = ov; ci = oi; cur = (long long)nseg * k; cld = cur;
@@ -270,26 +292,17 @@ __global__ void narrow_idx_kernel(const long long* __restrict__ in, int32_t* __r
 }
 
 // ------------------------------------------------------------------------------------ shard merge
-// vals/idx [G,Q,k] -> [Q,k]; one workgroup per query row; G*k <= 4096.
-__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ vals, const long long* __restrict__ idx,
-                                                         int G, int Q, int k, float* __restrict__ out_v,
-                                                         long long* __restrict__ out_i) {
-    const int q = blockIdx.x;
-    Cand<float> c[TOPK_E];
-#pragma unroll
-    for (int e = 0; e < TOPK_E; ++e) {
-        const int t = e * 256 + threadIdx.x;
-        if (t < G * k) {
-            const int g = t / k, j = t % k;
-            const long long off = ((long long)g * Q + q) * k + j;
-            c[e].v = vals[off];
-            c[e].i = idx[off];
-        } else {
-            c[e].v = -INFINITY;
-            c[e].i = 0x7fffffffffffffffLL;
-        }
-    }
-    block_topk_rounds<float>(c, k, out_v + (long long)q * k, out_i + (long long)q * k);
+// vals/idx [G,Q,k] -> row-major candidate lists [Q, G*k] (shard-major, so positions order ties like global indices),
+// then the same wavefront top-k.
+__global__ __launch_bounds__(256) void gather_candidates_kernel(const float* __restrict__ vals,
+                                                                const long long* __restrict__ idx, int G, int Q, int k,
+                                                                float* __restrict__ ov, long long* __restrict__ oi) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)G * Q * k) return;
+    const int j = (int)(t % k), g = (int)((t / k) % G), q = (int)(t / ((long long)k * G));
+    const long long src = ((long long)g * Q + q) * k + j;
+    ov[t] = vals[src];
+    oi[t] = idx[src];
 }
 
 // ------------------------------------------------------------------------------------ full-row ranking
@@ -366,7 +379,7 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
     float* scores = out_scores_d ? out_scores_d : (float*)workspace_d;
     char* ws = (char*)workspace_d + align_up((size_t)Q * N * sizeof(float), 256);
     int rc;
-    if (Q <= 64 && d % 8 == 0 && d <= 1024) {
+    if (Q <= 64 && d % 32 == 0 && d <= 1024) {
         rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, s);         // HBM-bound regime: stream the pool once
     } else {
         GemmArgs g;                                                             // MFMA-bound regime: tiled GEMM
@@ -389,15 +402,51 @@ int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* ou
                             (hipStream_t)stream);
 }
 
+size_t r4d_merge_topk_workspace_bytes(int32_t G, int32_t Q, int32_t k) {
+    if (G <= 0 || Q <= 0 || k <= 0) return 0;
+    return align_up((size_t)G * Q * k * 4, 256) + align_up((size_t)G * Q * k * 8, 256) + topk_ws_bytes<float>(Q, G * k, k);
+}
+
 int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k, float* out_val_d,
-                       int64_t* out_idx_d, void* stream) {
-    R4D_REQUIRE(vals_d && idx_d && out_val_d && out_idx_d, "merge_topk: null pointer");
-    R4D_REQUIRE(G >= 1 && Q >= 1 && k >= 1 && k <= 64 && (long long)G * k <= TOPK_SEG,
-                "merge_topk: G=%d k=%d out of range (G*k <= %d)", G, k, TOPK_SEG);
-    ProfScope prof(PK_MERGE_TOPK, 12.0 * G * Q * k, (hipStream_t)stream);
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, vals_d, (const long long*)idx_d,
-                       G, Q, k, out_val_d, (long long*)out_idx_d);
-    R4D_CHECK_LAUNCH("merge_topk");
+                       int64_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream) {
+    R4D_REQUIRE(vals_d && idx_d && out_val_d && out_idx_d && workspace_d, "merge_topk: null pointer");
+    R4D_REQUIRE(G >= 1 && Q >= 1 && k >= 1 && k <= 64, "merge_topk: G=%d Q=%d k=%d out of range", G, Q, k);
+    if (workspace_bytes < r4d_merge_topk_workspace_bytes(G, Q, k)) {
+        set_error("merge_topk: workspace too small");
+        return R4D_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const long long tot = (long long)G * Q * k;
+    float* cv = (float*)workspace_d;
+    long long* ci = (long long*)((char*)workspace_d + align_up((size_t)tot * 4, 256));
+    char* ws = (char*)ci + align_up((size_t)tot * 8, 256);
+    {
+        ProfScope prof(PK_MERGE_TOPK, 24.0 * tot, s);
+        hipLaunchKernelGGL(gather_candidates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, vals_d,
+                           (const long long*)idx_d, G, Q, k, cv, ci);
+        R4D_CHECK_LAUNCH("gather_candidates");
+    }
+    // level 1 of topk_rows must read the gathered indices: run it by hand with idx_in = ci
+    const float* v = cv;
+    const long long* ii = ci;
+    long long cur = (long long)G * k, cld = cur;
+    while (true) {
+        const int nseg = (int)((cur + TOPK_SEG - 1) / TOPK_SEG);
+        float* ov;
+        long long* oi;
+        if (nseg == 1) { ov = out_val_d; oi = (long long*)out_idx_d; }
+        else {
+            ov = (float*)ws; ws += align_up((size_t)Q * nseg * k * 4, 256);
+            oi = (long long*)ws; ws += align_up((size_t)Q * nseg * k * 8, 256);
+        }
+        const long long units = (long long)Q * nseg;
+        ProfScope prof(PK_TOPK, (double)Q * cur * 12.0, s);
+        hipLaunchKernelGGL((topk_seg_kernel<float>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, v, ii, (int)cur,
+                           cld, k, 0LL, nseg, Q, ov, oi);
+        R4D_CHECK_LAUNCH("topk_seg(merge)");
+        if (nseg == 1) break;
+        v = ov; ii = oi; cur = (long long)nseg * k; cld = cur;
+    }
     return R4D_OK;
 }
 

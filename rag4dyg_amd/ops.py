@@ -125,8 +125,10 @@ def merge_topk(vals, idx):
     G, Q, k = vals.shape
     ov = torch.empty(Q, k, dtype=torch.float32, device=vals.device)
     oi = torch.empty(Q, k, dtype=torch.int64, device=vals.device)
-    check(_lib.load().r4d_merge_topk_f32(_dev(vals, torch.float32, "vals"), _dev(idx, torch.int64, "idx"), G, Q, k,
-                                         ov.data_ptr(), oi.data_ptr(), _stream()), "merge_topk")
+    lib = _lib.load()
+    ws = workspace(lib.r4d_merge_topk_workspace_bytes(G, Q, k), vals.device, "merge")
+    check(lib.r4d_merge_topk_f32(_dev(vals, torch.float32, "vals"), _dev(idx, torch.int64, "idx"), G, Q, k,
+                                 ov.data_ptr(), oi.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "merge_topk")
     return ov, oi
 
 
