@@ -59,6 +59,11 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
     const float* ln_2_w;      const float* ln_2_b;        /* [d] */
     const float* c_fc_w;      const float* c_fc_b;        /* [d,4d], [4d] */
     const float* mlp_proj_w;  const float* mlp_proj_b;    /* [4d,d], [d]  */
+    /* OPTIONAL transposed copies of the four static Conv1D weights ([out,in] row-major, i.e. K contiguous), made
+     * once by the host when the checkpoint is loaded; NULL = not provided.  With them every GEMM operand is
+     * k-contiguous and the faster b128-LDS kernel runs (same values up to fp32 summation order). */
+    const float* c_attn_wT;   const float* attn_proj_wT;  /* [3d,d], [d,d]  */
+    const float* c_fc_wT;     const float* mlp_proj_wT;   /* [4d,d], [d,4d] */
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
@@ -119,7 +124,8 @@ int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int3
                       float eps, float* y_d, void* stream);
 /* y = epilogue(x[M,K] @ W[K,N] + bias[N]); epilogue: 0 none, 1 gelu_new (modeling_gpt2.py:206),
  * 2 add residual_d[M,N].  Conv1D.forward, modeling_utils.py:1267-1271. */
-int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* bias_d, const float* residual_d,
+int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d /* optional [N,K] copy or NULL */,
+                   const float* bias_d, const float* residual_d,
                    int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
 /* Causal multi-head attention on packed c_attn output qkv_d [B,T,3d] -> a_d [B,T,d] (heads merged).
  * Attention._attn + split/merge_heads, modeling_gpt2.py:140-175; scale = division by sqrt(hd) (:143).

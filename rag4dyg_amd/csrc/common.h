@@ -30,7 +30,8 @@ void set_error(const char* fmt, ...);
 // ------------------------------------------------------------------ launch profiler (profile.hip)
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
-    PK_GEMM_64x64_NT, PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
+    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32,
+    PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
@@ -64,6 +65,7 @@ struct GemmArgs {
     int causal;
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
+int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given as [N,K]: k-contiguous kernel
 
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,

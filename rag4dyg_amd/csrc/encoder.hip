@@ -15,13 +15,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int conv1d(const float* x, const float* w, const float* bias, const float* resid, int M, int K, int N,
-                  int epilogue, float* y, hipStream_t s) {
+static int conv1d(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K,
+                  int N, int epilogue, float* y, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = x; g.B = w; g.C = y; g.bias = bias; g.resid = resid;
-    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = N; g.ldc = N; g.ldr = N;
-    g.b_trans = 0; g.b_rows = K; g.nbatch = 1; g.nb1 = 1;
+    g.A = x; g.C = y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
+    if (wT) { g.B = wT; g.ldb = K; g.b_trans = 1; g.b_rows = N; }     // k-contiguous copy of the weight: fast kernel
+    else { g.B = w; g.ldb = N; g.b_trans = 0; g.b_rows = K; }         // reference layout [in,out]
+    g.nbatch = 1; g.nb1 = 1;
     g.epilogue = epilogue; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
     return launch_gemm_f32(g, s);
 }
@@ -195,7 +197,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             return R4D_ERR_HIP;
         }
         float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
         bool fused_done = false;
         if (g_attention_fused != 0) {                    // all batches of the call in ceil(n/16) fused launches
             fused_done = true;
@@ -220,10 +222,10 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
                 if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
             }
         }
-        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
-        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
-        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
     }
     for (int g = 0; g < n_groups; ++g) {
         const Group& G = groups[g];
@@ -280,12 +282,12 @@ int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int3
     return launch_layernorm(x_d, w_d, b_d, rows, d, eps, y_d, (hipStream_t)stream);
 }
 
-int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* bias_d, const float* residual_d, int32_t M,
-                   int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream) {
+int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d, const float* bias_d, const float* residual_d,
+                   int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream) {
     R4D_REQUIRE(x_d && w_d && y_d, "conv1d: null pointer");
     R4D_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv1d: epilogue %d not in {0,1,2}", epilogue);
     R4D_REQUIRE(epilogue != EPI_RESIDUAL || residual_d, "conv1d: residual epilogue needs residual_d");
-    return conv1d(x_d, w_d, bias_d, residual_d, M, K, N, epilogue, y_d, (hipStream_t)stream);
+    return conv1d(x_d, w_d, w_t_d, bias_d, residual_d, M, K, N, epilogue, y_d, (hipStream_t)stream);
 }
 
 size_t r4d_attention_workspace_bytes(int32_t B, int32_t n_head, int32_t T) {

@@ -352,6 +352,14 @@ int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {
     R4D_REQUIRE(g.b_trans || g.N % 4 == 0, "gemm: N=%d must be a multiple of 4 for row-major B", g.N);
     R4D_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: A/B must be 16-byte aligned");
     if (g.a_cols <= 0) g.a_cols = g.K;
+    {   // both operands k-contiguous: the b128-LDS kernel (gemm_f32_kc.hip); R4D_GEMM_KC=0 keeps this file's kernel
+        static int use_kc = -1;
+        if (use_kc < 0) { const char* e = getenv("R4D_GEMM_KC"); use_kc = e ? atoi(e) : 1; }
+        const bool vec4 = ((g.lda | g.ldb | g.sA0 | g.sA1 | g.sB0 | g.sB1) & 3) == 0 && g.K % 32 == 0;   // float4 staging, whole k-tiles
+        const bool fits = (long long)g.M * g.lda < (1ll << 29) && (long long)g.N * g.ldb < (1ll << 29);   // 32-bit byte offsets
+        if (use_kc && g.b_trans && g.causal != CAUSAL_PV && g.a_cols == g.K && g.b_rows == g.N && vec4 && fits)
+            return launch_gemm_f32_kc(g, stream);
+    }
     const int t = pick_tile(g);
     switch (t) {
         case 0: return launch_variant<128, 128, BKT, 4, 2>(g, kTiles[0].cls, stream);

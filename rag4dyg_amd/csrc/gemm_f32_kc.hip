@@ -1,0 +1,324 @@
+// fp32 MFMA GEMM, "k-contiguous" form: C[M,N] = epilogue(A[M,K] . B[N,K]^T + bias) with BOTH operands stored with
+// K contiguous (B = W^T for the Conv1D layers -- the host keeps a transposed copy of every static weight; Q.K^T, the
+// tied lm_head and the Q > 64 pool scan are k-contiguous by nature).
+//
+// Compared with gemm_f32.hip (B as [K,N], k-major LDS images, one 4/8-byte LDS read per operand per k-step):
+//   * both tiles go global -> LDS as 16-byte rows with NO transposition (ds_write_b128, row stride BK+4 floats);
+//   * a lane's MFMA operands are read along k: ONE ds_read_b128 per operand tile feeds FOUR v_mfma_f32_32x32x2_f32
+//     (k permuted identically on both operands: component c of the float4 of lane half h is k = 8g + 4h + c) -- a
+//     quarter of the LDS read instructions, all at the 256 B/clk rate; the stride 144 B makes the 16-lane groups
+//     of ds_read_b128 land on 16 distinct 16-byte slots (9*i mod 16), i.e. conflict-free;
+// which is what the vendor library's fp32 kernels do (local-read vector width 4).  Everything else as before:
+// double-buffered LDS, next k-tile's global loads in flight under the MFMA phase with the validity mask applied
+// at the LDS store, XCD-aware grouped tile order, fused bias / gelu_new / residual / scale epilogues.
+#include <stdlib.h>
+#include "common.h"
+
+#ifndef KC_DBG
+#define KC_DBG 0   // tuning aid (tools/kc_ablate.sh): bit 0 drops the fragment reads, bit 1 the staging, bit 2 the barrier, bit 3 only the global loads
+#endif
+#if KC_DBG & 2
+#define KC_DBG_STAGING(ST, LD)
+#elif KC_DBG & 8
+#define KC_DBG_STAGING(ST, LD) ST
+#else
+#define KC_DBG_STAGING(ST, LD) ST LD
+#endif
+#if KC_DBG & 1
+#define KC_DBG_FRAGS(X)
+#else
+#define KC_DBG_FRAGS(X) X
+#endif
+#if KC_DBG & 4
+#define KC_DBG_BARRIER(X)
+#else
+#define KC_DBG_BARRIER(X) X
+#endif
+
+namespace r4d {
+
+typedef float f32x16k __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_new_kc(float x) {
+    // gelu_new(x) = x / (1 + exp(-2u)), u = sqrt(2/pi)(x + 0.044715 x^3)  -- see gemm_f32.hip
+    const float c2 = 2.0f * 0.7978845608028654f;
+    return x * __frcp_rn(1.0f + __expf(-c2 * (x + 0.044715f * x * x * x)));
+}
+
+struct KcShape {
+    int M, N, K, lda, ldb, ldc, ldr, nb1, epilogue, causal;
+    long long sA0, sA1, sB0, sB1, sC0, sC1;
+    float scale_div;
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
+    const float* __restrict__ Ag, const float* __restrict__ Bg, float* __restrict__ Cg,
+    const float* __restrict__ biasg, const float* __restrict__ residg, const KcShape g) {
+    constexpr int NTHREADS = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int LDS_ROW = BK + 4;                                  // floats; 144 B at BK = 32, 80 B at BK = 16
+    constexpr int KV = BK / 4;                                       // float4 per tile row
+    constexpr int NLA = BM * KV / NTHREADS, NLB = BN * KV / NTHREADS;
+    constexpr int NS = BK / 8;                                       // MFMA steps (8 k each) per k-tile
+    constexpr int NBUF = 3;
+    constexpr int A_TILE = BM * LDS_ROW, B_TILE = BN * LDS_ROW, STAGE = A_TILE + B_TILE;
+    static_assert(NLA >= 1 && NLB >= 1 && TM >= 1 && TN >= 1 && (NS == 2 || NS == 4), "tile");
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];   // stage b: A image at b*STAGE, B image after it
+
+    // XCD-aware grouped tile order (see gemm_f32.hip)
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.causal == CAUSAL_QK && n0 > m0 + BM - 1) return;           // tile strictly above the diagonal
+
+    const int z0 = blockIdx.z / g.nb1, z1 = blockIdx.z % g.nb1;
+    const float* __restrict__ A = Ag + z0 * g.sA0 + z1 * g.sA1;
+    const float* __restrict__ B = Bg + z0 * g.sB0 + z1 * g.sB1;
+    float* __restrict__ C = Cg + z0 * g.sC0 + z1 * g.sC1;
+    const int nkt = (g.K + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // Staging coordinates.  NO validity masks anywhere in the k-loop: rows past M (or N) are CLAMPED to the last valid
+    // row, so the duplicate data only reaches accumulator rows (columns) the epilogue never stores, and K % BK == 0 is
+    // a precondition of this kernel (the dispatcher sends other K to gemm_f32.hip).  Every plain VALU instruction in
+    // the loop costs the matrix pipe ~4.5 cycles (tools/mfma_peak.hip: VALU and MFMA share the issue port), so the
+    // per-iteration address work is scalar: 32-bit byte offsets per lane + a uniform base that advances BK floats.
+    static_assert(NTHREADS % KV == 0, "every staged float4 of a thread sits at the same k offset");
+    const int st_k = 4 * (tid % KV), st_row = tid / KV;
+    constexpr int ROWS_PER_PASS = NTHREADS / KV;
+    int a_off[NLA], b_off[NLB];                                      // byte offsets (voffset of the buffer loads)
+#pragma unroll
+    for (int r = 0; r < NLA; ++r)
+        a_off[r] = (min(m0 + st_row + r * ROWS_PER_PASS, g.M - 1) * g.lda + st_k) * 4;
+#pragma unroll
+    for (int r = 0; r < NLB; ++r)
+        b_off[r] = (min(n0 + st_row + r * ROWS_PER_PASS, g.N - 1) * g.ldb + st_k) * 4;
+    const int st_dst = st_row * LDS_ROW + st_k;
+    // Pipeline (three LDS stages, one register stage, ONE barrier per k-tile and nothing latency-bound next to it):
+    //   iteration kt:  W(kt+2): registers (global loads issued one iteration ago, landed) -> LDS stage (kt+2)%3
+    //                  G(kt+3): global loads into the same registers, in flight for a whole iteration
+    //                  C(kt)  : MFMA steps on stage kt%3; fragment reads run one step ahead, and the LAST step's
+    //                           look-ahead already reads step 0 of k-tile kt+1 from stage (kt+1)%3 -- legal before the
+    //                           barrier because that stage was written in iteration kt-1 and published by ITS barrier
+    //                  barrier: publishes W(kt+2); stage kt%3 is free for W(kt+3) next iteration
+    // With two stages the LDS store, the barrier and the first fragment read of the next tile sit back-to-back on
+    // the critical path (~1000 cycles per 4096 MFMA cycles: measured 128 TF asymptote = 81 % with either LDS layout).
+    // The loads are UNCONDITIONAL (k-tile index clamped; the tail re-reads the last tile from L2 into stages nobody
+    // reads) so the loop body is branch-free and the compiler's vmcnt bookkeeping stays exact.
+    // (named registers, not arrays: a loop-carried float4 array that is only copied gets promoted to LDS by hipcc)
+    // Buffer loads: address = descriptor base + per-lane 32-bit voffset (loop-invariant) + SCALAR soffset (the k-tile),
+    // so the loop carries no address VALU at all (global_load needs a 64-bit v_lshl_add_u64 per load: the zext of the
+    // lane offset is hoisted out of the loop and the saddr form is no longer matched).
+    static_assert(NLA <= 2 && NLB <= 2, "staging registers");
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(B), 0, (int)(((long long)(g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
+    u32x4k ra0, ra1, rb0, rb1;
+#define KC_LOAD(KT)                                                                                \
+    {                                                                                              \
+        const int soff_ = min((KT), nkt - 1) * (BK * 4);                                           \
+        ra0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], soff_, 0);                   \
+        if (NLA > 1) ra1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], soff_, 0); \
+        rb0 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], soff_, 0);                   \
+        if (NLB > 1) rb1 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], soff_, 0); \
+    }
+#define KC_STORE(KT, STG)                                                                          \
+    {                                                                                              \
+        float* sa_ = lds + (STG) * STAGE + st_dst;                                                 \
+        *reinterpret_cast<u32x4k*>(sa_) = ra0;                                                     \
+        if (NLA > 1) *reinterpret_cast<u32x4k*>(sa_ + ROWS_PER_PASS * LDS_ROW) = ra1;              \
+        *reinterpret_cast<u32x4k*>(sa_ + A_TILE) = rb0;                                            \
+        if (NLB > 1) *reinterpret_cast<u32x4k*>(sa_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = rb1;     \
+    }
+#define KC_FRAGS(SET, STG, STEP)                                                                   \
+    {                                                                                              \
+        const float* as_ = lds + (STG) * STAGE + frag_a + 8 * (STEP);                              \
+        const float* bs_ = lds + (STG) * STAGE + A_TILE + frag_b + 8 * (STEP);                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+            fa[SET][i] = *reinterpret_cast<const float4*>(as_ + i * 32 * LDS_ROW);                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+            fb[SET][j] = *reinterpret_cast<const float4*>(bs_ + j * 32 * LDS_ROW);                 \
+    }
+    // component-major MFMA order: consecutive MFMAs go to DIFFERENT accumulators
+#define KC_MFMAS(SET)                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                const float av_ = c == 0 ? fa[SET][i].x : c == 1 ? fa[SET][i].y : c == 2 ? fa[SET][i].z : fa[SET][i].w; \
+                const float bv_ = c == 0 ? fb[SET][j].x : c == 1 ? fb[SET][j].y : c == 2 ? fb[SET][j].z : fb[SET][j].w; \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv_, acc[i][j], 0, 0, 0);    \
+            }
+
+    const int frag_a = (wm * WM + li) * LDS_ROW + 4 * lh;
+    const int frag_b = (wn * WN + li) * LDS_ROW + 4 * lh;
+    float4 fa[2][TM], fb[2][TN];
+    f32x16k acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: the loads of k-tiles 0, 1, 2 go out back-to-back (ONE exposed memory latency, not three): tiles 0 and 1
+    // land in temporaries that die here, tile 2 in the loop's staging registers
+    {
+        const int s1_ = min(1, nkt - 1) * (BK * 4);
+        const u32x4k p0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], 0, 0);
+        const u32x4k p1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], 0, 0);
+        const u32x4k p2 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], 0, 0);
+        const u32x4k p3 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], 0, 0);
+        const u32x4k q0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], s1_, 0);
+        const u32x4k q1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], s1_, 0);
+        const u32x4k q2 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], s1_, 0);
+        const u32x4k q3 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], s1_, 0);
+        KC_LOAD(2)
+        float* s0_ = lds + st_dst;
+        float* s1p_ = lds + STAGE + st_dst;
+        *reinterpret_cast<u32x4k*>(s0_) = p0;
+        if (NLA > 1) *reinterpret_cast<u32x4k*>(s0_ + ROWS_PER_PASS * LDS_ROW) = p1;
+        *reinterpret_cast<u32x4k*>(s0_ + A_TILE) = p2;
+        if (NLB > 1) *reinterpret_cast<u32x4k*>(s0_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = p3;
+        *reinterpret_cast<u32x4k*>(s1p_) = q0;
+        if (NLA > 1) *reinterpret_cast<u32x4k*>(s1p_ + ROWS_PER_PASS * LDS_ROW) = q1;
+        *reinterpret_cast<u32x4k*>(s1p_ + A_TILE) = q2;
+        if (NLB > 1) *reinterpret_cast<u32x4k*>(s1p_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = q3;
+    }
+    __syncthreads();
+    KC_FRAGS(0, 0, 0)
+
+    // one k-tile; CUR/NXT/WR are the stages of k-tiles kt, kt+1, kt+2
+#define KC_ITER(CUR, NXT, WR)                                                                      \
+    {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        KC_DBG_STAGING(KC_STORE(kt + 2, WR), KC_LOAD(kt + 3))                                      \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
+            KC_DBG_FRAGS(if (s + 1 < NS) KC_FRAGS((s + 1) & 1, CUR, s + 1) else KC_FRAGS(0, NXT, 0)) \
+            KC_MFMAS(s & 1)                                                                        \
+        }                                                                                          \
+        /* pin the issue order (the scheduler otherwise regroups the LDS reads behind the MFMAs and every step   */ \
+        /* starts with an exposed lgkmcnt wait); NS is even, so the look-ahead of the last step lands in set 0    */ \
+        __builtin_amdgcn_sched_group_barrier(0x200, NLA + NLB, 0);   /* LDS writes of W(kt+2)   */  \
+        __builtin_amdgcn_sched_group_barrier(0x020, NLA + NLB, 0);   /* buffer loads of G(kt+3) */  \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);                           \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        KC_DBG_BARRIER(__syncthreads();)                                                           \
+    }
+    // (rolled loop, runtime stages: three v_add per iteration.  Unrolling by three for immediate LDS offsets measured
+    // 4-5 % SLOWER with if-regions for the remainder, and with breaks hipcc renames the accumulators per exit and
+    // spills 170 registers.)
+    int cur = 0, nxt = 1, wr = 2;                                    // stages of k-tiles kt, kt+1, kt+2
+    for (int kt = 0; kt < nkt; ++kt) {
+        KC_ITER(cur, nxt, wr)
+        const int t_ = cur; cur = nxt; nxt = wr; wr = t_;
+    }
+#undef KC_ITER
+#undef KC_LOAD
+#undef KC_STORE
+#undef KC_FRAGS
+#undef KC_MFMAS
+
+    // epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) inside each 32x32 tile.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + li;
+        const bool col_ok = col < g.N;
+        const int colc = min(col, g.N - 1);
+        const float bias = biasg ? biasg[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float res[16];
+            if (g.epilogue == EPI_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    res[r] = residg[(long long)row * g.ldr + colc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias;
+                if (g.epilogue == EPI_GELU) v = gelu_new_kc(v);
+                else if (g.epilogue == EPI_RESIDUAL) v += res[r];
+                else if (g.epilogue == EPI_SCALE_DIV) v = v / g.scale_div;
+                else if (g.epilogue == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+                if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+struct KcTile { int bm, bn, cls, blocks_per_cu, waves_per_block; double eff; };
+static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8192^3, tools/gemm_bench.py shape 14)
+    {128, 128, PK_GEMM_KC_128x128x32, 1, 8, 0.86},   // BK 32, three stages = 108 KB: one workgroup per CU
+    {128, 128, PK_GEMM_KC_128x128x16, 2, 8, 0.91},   // BK 16, three stages = 60 KB: two per CU
+    {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.86},     // BK 16, 45 KB: three per CU
+    {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
+};
+constexpr int kNumKc = 4;
+
+template <int BM, int BN, int BK, int WGM, int WGN, int MINW>
+static int launch_kc(const GemmArgs& g, int cls, hipStream_t stream) {
+    constexpr int NTHREADS = 64 * WGM * WGN;
+    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+    const double flop = (g.causal ? 1.0 : 2.0) * (double)g.M * g.N * g.K * g.nbatch;
+    ProfScope prof(cls, flop, stream);
+    KcShape sh;
+    sh.M = g.M; sh.N = g.N; sh.K = g.K; sh.lda = g.lda; sh.ldb = g.ldb; sh.ldc = g.ldc; sh.ldr = g.ldr;
+    sh.nb1 = g.nb1; sh.epilogue = g.epilogue; sh.causal = g.causal;
+    sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
+    sh.scale_div = g.scale_div;
+    hipLaunchKernelGGL((gemm_f32_kc_kernel<BM, BN, BK, WGM, WGN, MINW>), dim3(tiles, 1, g.nbatch), dim3(NTHREADS), 0,
+                       stream, g.A, g.B, g.C, g.bias, g.resid, sh);
+    R4D_CHECK_LAUNCH("gemm_f32_kc");
+    return R4D_OK;
+}
+
+// k-contiguous GEMM: requires g.b_trans (B is [N,K]) and no causal P.V trimming.
+int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("R4D_GEMM_KC_TILE");   // tuning aid: 0..3 forces a tile shape
+        forced = e ? atoi(e) : -1;
+    }
+    int best = kNumKc - 1;
+    if (forced >= 0 && forced < kNumKc) best = forced;
+    else {
+        double best_cost = 1e300;
+        for (int t = 0; t < kNumKc; ++t) {
+            const KcTile& c = kKc[t];
+            long long blocks = (long long)cdiv(g.M, c.bm) * cdiv(g.N, c.bn) * g.nbatch;
+            if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(g.M, c.bm) * g.nbatch / 2;
+            const long long per_cu = (blocks + 255) / 256;
+            const double conc = (double)(per_cu < c.blocks_per_cu ? per_cu : c.blocks_per_cu);
+            const double wps = conc * c.waves_per_block / 4.0;
+            const double eff = c.eff * (wps >= 2.0 ? 1.0 : wps / 2.0);
+            const double cost = (double)per_cu * c.bm * c.bn / eff;
+            if (cost < best_cost) { best_cost = cost; best = t; }
+        }
+    }
+    switch (best) {
+        case 0: return launch_kc<128, 128, 32, 4, 2, 2>(g, kKc[0].cls, stream);
+        case 1: return launch_kc<128, 128, 16, 4, 2, 4>(g, kKc[1].cls, stream);
+        case 2: return launch_kc<128, 64, 16, 2, 2, 3>(g, kKc[2].cls, stream);
+        default: return launch_kc<64, 64, 32, 2, 2, 2>(g, kKc[3].cls, stream);
+    }
+}
+
+}  // namespace r4d

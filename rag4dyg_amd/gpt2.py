@@ -184,6 +184,17 @@ class GPT2Model(_PreTrained):
         return new
 
     # ------------------------------------------------------------------ kernel hand-off
+    def _wt(self, w):
+        """Contiguous transposed copy [out,in] of a static Conv1D weight, cached until the weight changes
+        (keyed by storage pointer and in-place version counter)."""
+        cache = self.__dict__.setdefault("_wt_cache", {})
+        key = id(w)
+        ent = cache.get(key)
+        if ent is None or ent[0] != (w.data_ptr(), w._version):
+            ent = ((w.data_ptr(), w._version), w.detach().t().contiguous())
+            cache[key] = ent
+        return ent[1].data_ptr()
+
     def _c_structs(self):
         cfg = self.config
         c = _lib.GPT2ConfigC(cfg.n_layer, cfg.n_head, cfg.n_embd, self.wte.num_embeddings, self.wpe.num_embeddings,
@@ -199,7 +210,9 @@ class GPT2Model(_PreTrained):
             layers[i] = _lib.GPT2LayerC(p(blk.ln_1.weight), p(blk.ln_1.bias), p(blk.attn.c_attn.weight),
                                         p(blk.attn.c_attn.bias), p(blk.attn.c_proj.weight), p(blk.attn.c_proj.bias),
                                         p(blk.ln_2.weight), p(blk.ln_2.bias), p(blk.mlp.c_fc.weight),
-                                        p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias))
+                                        p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias),
+                                        self._wt(blk.attn.c_attn.weight), self._wt(blk.attn.c_proj.weight),
+                                        self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight))
         w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers)
         return c, w, layers
 

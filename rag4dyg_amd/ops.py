@@ -44,15 +44,17 @@ def layernorm(x, w, b, eps=1e-5):
     return y
 
 
-def conv1d(x, w, bias, epilogue="none", residual=None):
-    """y = epilogue(x @ W[K,N] + bias); epilogue in {'none','gelu','residual'} (Conv1D, modeling_utils.py:1267-1271)."""
+def conv1d(x, w, bias, epilogue="none", residual=None, w_t=None):
+    """y = epilogue(x @ W[K,N] + bias); epilogue in {'none','gelu','residual'} (Conv1D, modeling_utils.py:1267-1271).
+    ``w_t``: optional contiguous transposed copy W^T [N,K] of the (static) weight -> the k-contiguous GEMM kernel."""
     K, N = w.shape
     M = x.numel() // K
     y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
     epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
     rp = _dev(residual, torch.float32, "residual") if residual is not None else None
     bp = _dev(bias, torch.float32, "bias") if bias is not None else None
-    check(_lib.load().r4d_conv1d_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"), bp, rp, M, K, N, epi,
+    tp = _dev(w_t, torch.float32, "w_t") if w_t is not None else None
+    check(_lib.load().r4d_conv1d_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"), tp, bp, rp, M, K, N, epi,
                                      y.data_ptr(), _stream()), "conv1d")
     return y
 

@@ -57,9 +57,10 @@ def test_conv1d_all_epilogues(dev, M, K, N):
     r = torch.randn(M, N, generator=g)
     ref = gpt2_ref.conv1d(x, w, b)
     xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
-    assert rel_err(ops.conv1d(xd, wd, bd).cpu().numpy(), ref.numpy()) < 1e-5
-    assert rel_err(ops.conv1d(xd, wd, bd, "gelu").cpu().numpy(), gpt2_ref.gelu_new(ref).numpy()) < 1e-5
-    assert rel_err(ops.conv1d(xd, wd, bd, "residual", rd).cpu().numpy(), (ref + r).numpy()) < 1e-5
+    for wt in (None, wd.t().contiguous()):              # reference-layout kernel / k-contiguous kernel
+        assert rel_err(ops.conv1d(xd, wd, bd, w_t=wt).cpu().numpy(), ref.numpy()) < 1e-5
+        assert rel_err(ops.conv1d(xd, wd, bd, "gelu", w_t=wt).cpu().numpy(), gpt2_ref.gelu_new(ref).numpy()) < 1e-5
+        assert rel_err(ops.conv1d(xd, wd, bd, "residual", rd, w_t=wt).cpu().numpy(), (ref + r).numpy()) < 1e-5
 
 
 def test_conv1d_golden(dev):
