@@ -1,21 +1,30 @@
 // fp32 MFMA GEMM, "k-contiguous" form: C[M,N] = epilogue(A[M,K] . B[N,K]^T + bias) with BOTH operands stored with
 // K contiguous (B = W^T for the Conv1D layers -- the host keeps a transposed copy of every static weight; Q.K^T, the
-// tied lm_head and the Q > 64 pool scan are k-contiguous by nature).
+// tied lm_head and the Q > 64 pool scan are k-contiguous by nature).  Preconditions (checked by the dispatcher in
+// gemm_f32.hip, which otherwise uses that file's kernel): K % 32 == 0, 16-byte aligned rows, operands < 2 GiB.
 //
-// Compared with gemm_f32.hip (B as [K,N], k-major LDS images, one 4/8-byte LDS read per operand per k-step):
-//   * both tiles go global -> LDS as 16-byte rows with NO transposition (ds_write_b128, row stride BK+4 floats);
+// The design rule, measured with tools/mfma_peak.hip and tools/kc_ablate.sh on gfx950: plain VALU and LDS
+// instructions do NOT hide under v_mfma -- each one takes ~3-5 cycles of the SIMD's issue port away from the matrix
+// pipe (1 v_add per MFMA: 156 -> 148 TF; 4: 132 TF) -- so an MFMA-bound loop is priced by its non-MFMA instruction
+// count.  Hence:
+//   * both tiles go global -> LDS as 16-byte rows with NO transposition (ds_write_b128, row stride BK+4 floats:
+//     the 16-lane groups of a b128 access land on 16 distinct 16-byte slots, conflict-free);
 //   * a lane's MFMA operands are read along k: ONE ds_read_b128 per operand tile feeds FOUR v_mfma_f32_32x32x2_f32
-//     (k permuted identically on both operands: component c of the float4 of lane half h is k = 8g + 4h + c) -- a
-//     quarter of the LDS read instructions, all at the 256 B/clk rate; the stride 144 B makes the 16-lane groups
-//     of ds_read_b128 land on 16 distinct 16-byte slots (9*i mod 16), i.e. conflict-free;
-// which is what the vendor library's fp32 kernels do (local-read vector width 4).  Everything else as before:
-// double-buffered LDS, next k-tile's global loads in flight under the MFMA phase with the validity mask applied
-// at the LDS store, XCD-aware grouped tile order, fused bias / gelu_new / residual / scale epilogues.
+//     (k permuted identically on both operands: component c of the float4 of lane half h is k = 8g + 4h + c);
+//   * NO masks and NO address arithmetic in the k-loop: out-of-range rows are clamped (their products only reach
+//     accumulator rows the epilogue never stores), loads are buffer_load_dwordx4 with a loop-invariant lane offset
+//     and the k-tile in the SCALAR offset;
+//   * three LDS stages, one barrier per k-tile, the next tile's first fragments read before the barrier, global
+//     loads in flight for a whole iteration (see the pipeline comment in the kernel).
+// Per wave and BK = 16 k-tile that leaves 16 MFMAs + 6 ds_read + 2 ds_write + 2 buffer_load + 5 VALU.
+// Measured (MI355X, 157.3 TF peak): 8192^3 143 TF (vendor hipBLASLt 154.6); M=35456 K=512 N=1536 130 TF (the
+// previous kernel 102; vendor 141).  XCD-aware grouped tile order and fused bias / gelu_new / residual / scale
+// epilogues as in gemm_f32.hip.
 #include <stdlib.h>
 #include "common.h"
 
 #ifndef KC_DBG
-#define KC_DBG 0   // tuning aid (tools/kc_ablate.sh): bit 0 drops the fragment reads, bit 1 the staging, bit 2 the barrier, bit 3 only the global loads
+#define KC_DBG 0   // tuning aid (tools/kc_ablate.sh): bit 0 drops the fragment reads, bit 1 the staging, bit 2 the barrier, bit 3 only the global loads, bit 4 the C stores
 #endif
 #if KC_DBG & 2
 #define KC_DBG_STAGING(ST, LD)
@@ -120,28 +129,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     // Buffer loads: address = descriptor base + per-lane 32-bit voffset (loop-invariant) + SCALAR soffset (the k-tile),
     // so the loop carries no address VALU at all (global_load needs a 64-bit v_lshl_add_u64 per load: the zext of the
     // lane offset is hoisted out of the loop and the saddr form is no longer matched).
-    static_assert(NLA <= 2 && NLB <= 2, "staging registers");
+    static_assert(NLA <= 4 && NLB <= 4, "staging registers");
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(A), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(B), 0, (int)(((long long)(g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
-    u32x4k ra0, ra1, rb0, rb1;
-#define KC_LOAD(KT)                                                                                \
+    u32x4k ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define KC_LD_(RSRC, OFF, SOFF) __builtin_amdgcn_raw_buffer_load_b128(RSRC, OFF, SOFF, 0)
+#define KC_LOAD_INTO(A0, A1, A2, A3, B0, B1, B2, B3, SOFF)                                         \
     {                                                                                              \
-        const int soff_ = min((KT), nkt - 1) * (BK * 4);                                           \
-        ra0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], soff_, 0);                   \
-        if (NLA > 1) ra1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], soff_, 0); \
-        rb0 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], soff_, 0);                   \
-        if (NLB > 1) rb1 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], soff_, 0); \
+        A0 = KC_LD_(a_rsrc, a_off[0], SOFF);                                                       \
+        if (NLA > 1) A1 = KC_LD_(a_rsrc, a_off[NLA > 1 ? 1 : 0], SOFF);                            \
+        if (NLA > 2) A2 = KC_LD_(a_rsrc, a_off[NLA > 2 ? 2 : 0], SOFF);                            \
+        if (NLA > 3) A3 = KC_LD_(a_rsrc, a_off[NLA > 3 ? 3 : 0], SOFF);                            \
+        B0 = KC_LD_(b_rsrc, b_off[0], SOFF);                                                       \
+        if (NLB > 1) B1 = KC_LD_(b_rsrc, b_off[NLB > 1 ? 1 : 0], SOFF);                            \
+        if (NLB > 2) B2 = KC_LD_(b_rsrc, b_off[NLB > 2 ? 2 : 0], SOFF);                            \
+        if (NLB > 3) B3 = KC_LD_(b_rsrc, b_off[NLB > 3 ? 3 : 0], SOFF);                            \
     }
-#define KC_STORE(KT, STG)                                                                          \
+#define KC_ST_(PTR, V) *reinterpret_cast<u32x4k*>(PTR) = V
+#define KC_STORE_FROM(A0, A1, A2, A3, B0, B1, B2, B3, STG)                                         \
     {                                                                                              \
         float* sa_ = lds + (STG) * STAGE + st_dst;                                                 \
-        *reinterpret_cast<u32x4k*>(sa_) = ra0;                                                     \
-        if (NLA > 1) *reinterpret_cast<u32x4k*>(sa_ + ROWS_PER_PASS * LDS_ROW) = ra1;              \
-        *reinterpret_cast<u32x4k*>(sa_ + A_TILE) = rb0;                                            \
-        if (NLB > 1) *reinterpret_cast<u32x4k*>(sa_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = rb1;     \
+        KC_ST_(sa_, A0);                                                                           \
+        if (NLA > 1) KC_ST_(sa_ + 1 * ROWS_PER_PASS * LDS_ROW, A1);                                \
+        if (NLA > 2) KC_ST_(sa_ + 2 * ROWS_PER_PASS * LDS_ROW, A2);                                \
+        if (NLA > 3) KC_ST_(sa_ + 3 * ROWS_PER_PASS * LDS_ROW, A3);                                \
+        KC_ST_(sa_ + A_TILE, B0);                                                                  \
+        if (NLB > 1) KC_ST_(sa_ + A_TILE + 1 * ROWS_PER_PASS * LDS_ROW, B1);                       \
+        if (NLB > 2) KC_ST_(sa_ + A_TILE + 2 * ROWS_PER_PASS * LDS_ROW, B2);                       \
+        if (NLB > 3) KC_ST_(sa_ + A_TILE + 3 * ROWS_PER_PASS * LDS_ROW, B3);                       \
     }
+#define KC_LOAD(KT) KC_LOAD_INTO(ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, min((KT), nkt - 1) * (BK * 4))
+#define KC_STORE(KT, STG) KC_STORE_FROM(ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, STG)
 #define KC_FRAGS(SET, STG, STEP)                                                                   \
     {                                                                                              \
         const float* as_ = lds + (STG) * STAGE + frag_a + 8 * (STEP);                              \
@@ -175,26 +195,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     // prologue: the loads of k-tiles 0, 1, 2 go out back-to-back (ONE exposed memory latency, not three): tiles 0 and 1
     // land in temporaries that die here, tile 2 in the loop's staging registers
     {
-        const int s1_ = min(1, nkt - 1) * (BK * 4);
-        const u32x4k p0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], 0, 0);
-        const u32x4k p1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], 0, 0);
-        const u32x4k p2 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], 0, 0);
-        const u32x4k p3 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], 0, 0);
-        const u32x4k q0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[0], s1_, 0);
-        const u32x4k q1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[NLA - 1], s1_, 0);
-        const u32x4k q2 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[0], s1_, 0);
-        const u32x4k q3 = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[NLB - 1], s1_, 0);
+        u32x4k p0, p1, p2, p3, p4, p5, p6, p7, q0, q1, q2, q3, q4, q5, q6, q7;
+        KC_LOAD_INTO(p0, p1, p2, p3, p4, p5, p6, p7, 0)
+        KC_LOAD_INTO(q0, q1, q2, q3, q4, q5, q6, q7, min(1, nkt - 1) * (BK * 4))
         KC_LOAD(2)
-        float* s0_ = lds + st_dst;
-        float* s1p_ = lds + STAGE + st_dst;
-        *reinterpret_cast<u32x4k*>(s0_) = p0;
-        if (NLA > 1) *reinterpret_cast<u32x4k*>(s0_ + ROWS_PER_PASS * LDS_ROW) = p1;
-        *reinterpret_cast<u32x4k*>(s0_ + A_TILE) = p2;
-        if (NLB > 1) *reinterpret_cast<u32x4k*>(s0_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = p3;
-        *reinterpret_cast<u32x4k*>(s1p_) = q0;
-        if (NLA > 1) *reinterpret_cast<u32x4k*>(s1p_ + ROWS_PER_PASS * LDS_ROW) = q1;
-        *reinterpret_cast<u32x4k*>(s1p_ + A_TILE) = q2;
-        if (NLB > 1) *reinterpret_cast<u32x4k*>(s1p_ + A_TILE + ROWS_PER_PASS * LDS_ROW) = q3;
+        KC_STORE_FROM(p0, p1, p2, p3, p4, p5, p6, p7, 0)
+        KC_STORE_FROM(q0, q1, q2, q3, q4, q5, q6, q7, 1)
     }
     __syncthreads();
     KC_FRAGS(0, 0, 0)
@@ -229,6 +235,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     }
 #undef KC_ITER
 #undef KC_LOAD
+#undef KC_LOAD_INTO
+#undef KC_STORE_FROM
+#undef KC_LD_
+#undef KC_ST_
 #undef KC_STORE
 #undef KC_FRAGS
 #undef KC_MFMAS
@@ -258,6 +268,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
                 else if (g.epilogue == EPI_RESIDUAL) v += res[r];
                 else if (g.epilogue == EPI_SCALE_DIV) v = v / g.scale_div;
                 else if (g.epilogue == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+#if KC_DBG & 16
+                if (v == 12345.678f)                                     // ablation: (almost) never true, keeps v alive
+#endif
                 if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
         }
@@ -271,6 +284,8 @@ static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8
     {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.86},     // BK 16, 45 KB: three per CU
     {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
 };
+// (measured and dropped: 4 waves with 64x64 wave tiles at BK 16 -- 140 TF asymptote but 121 TF at K = 512; 4 waves at
+// BK 32, one workgroup per CU -- 127 / 101 TF)
 constexpr int kNumKc = 4;
 
 template <int BM, int BN, int BK, int WGM, int WGN, int MINW>
