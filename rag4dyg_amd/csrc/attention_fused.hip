@@ -272,52 +272,91 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
 // registers per lane for O^T, which at head_dim 256 leaves one wave per SIMD.  Here the 4 wavefronts of a
 // workgroup walk 128-key super-tiles TOGETHER: wave w computes S^T for its own 32-key sub-tile (full head_dim),
 // the row max / row sum are combined across the 4 waves through 1 KB of LDS, every wave publishes its
-// probabilities P^T[key][q] to LDS, and wave w accumulates only ITS quarter of the head columns of O^T over all
-// 128 keys (B operand = P^T from LDS, A operand = V rows, coalesced 4/8-byte loads).  O^T is HD/8 registers per
-// lane (32 at hd 256), so three workgroups fit per CU, the waves are always balanced and there is no merge phase.
+// probabilities to LDS, and wave w accumulates only ITS quarter of the head columns of O^T over all 128 keys.
+// O^T is HD/8 registers per lane (32 at hd 256), so three workgroups fit per CU, the waves are always balanced and
+// there is no merge phase.
+//
+// Instruction diet (plain VALU / LDS / VMEM instructions do not hide under v_mfma on gfx950, tools/mfma_peak.hip):
+//   * Q is staged ROW-major [query][HD+4] and pre-multiplied by log2(e)/sqrt(hd): the logits come out of the MFMA in
+//     the exp2 domain (softmax = exp2(s - max), no per-element scale), and a lane's Q operand for FOUR MFMAs is one
+//     conflict-free ds_read_b128 -- matching the four k of the lane's 16-byte K load;
+//   * K and V rows come in through buffer loads: lane offset loop-invariant, the key row in the SCALAR offset, rows
+//     past the sequence answered with zeros by the range check -- no clamps, no 64-bit address arithmetic;
+//   * the causal mask is applied only on super-tiles that touch the diagonal (wave-uniform test);
+//   * P is published [query][key] with four ds_write_b128 per wave and read back as one ds_read_b128 per EIGHT
+//     P.V MFMAs (keys permuted identically on the V loads).
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2a __attribute__((ext_vector_type(2)));
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef float f32x2a __attribute__((ext_vector_type(2)));
+
+template <int VW>
+struct VBuf;                                            // one V fragment: VW consecutive head columns of one key row
+template <>
+struct VBuf<1> {
+    float v[1];
+    __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+template <>
+struct VBuf<2> {
+    float v[2];
+    __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        // (bit_cast the WHOLE vector: __builtin_bit_cast(float, t.y) on an ext-vector element reads element 0)
+        const f32x2a t = __builtin_bit_cast(f32x2a, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+
 template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, float scale,
+__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, float qscale,
                                                                float* __restrict__ out) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // floats per lane per V load = O^T tiles per wave (1 or 2)
-    constexpr int NSTEP = HD / 8, GRP = 4, NG = NSTEP / GRP;
-    constexpr int LDP = 33;
+    constexpr int NSTEP = HD / 8;                      // 16-byte K loads (and Q reads) per key row
+    constexpr int LDQ = HD + 4, LDP = 132;             // row strides (floats): 16-lane b128 groups hit 16 distinct slots
+    constexpr int KD = 8;                              // K loads in flight per lane
+    constexpr int VD = 3;                              // V key-groups (8 keys) in flight
     extern __shared__ float lds[];
-    float* Qs = lds;                                   // [HD][33]   Q^T, k-major
-    float* Ps = lds + HD * ATT_LDQ;                    // [128][33]  P^T of the current super-tile
-    float* red = Ps + 128 * LDP;                       // [2][4][32] per-wave row max / row sum
+    float* Qs = lds;                                   // [32][LDQ]  Q * log2(e)/sqrt(hd)
+    float* Ps = lds + 32 * LDQ;                        // [32][LDP]  probabilities of the current super-tile, [query][key]
+    float* red = Ps + 32 * LDP;                        // [2][4][32] per-wave row max / row sum
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y;
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y;   // long (late) query tiles first
     int gi = 0;
     while (gi + 1 < G.n && (int)blockIdx.z >= G.seq_prefix[gi + 1]) ++gi;
     const int T = G.T[gi];
     const int q0 = qt * 32;
     if (q0 >= T) return;                               // grid.x covers the longest batch
     const long long rowb = G.row0[gi] + (long long)((int)blockIdx.z - G.seq_prefix[gi]) * T;     // first row of the sequence
-    const long long ld3 = 3LL * d;
+    const int ld3 = 3 * d;
     const float* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
-    const float* __restrict__ Kb = base + d;
-    const float* __restrict__ Vb = base + 2 * d + wid * CW;
-    {
-        constexpr int NQL = (HD + 63) / 64;
-        float qv[8][NQL];
+    const int seq_bytes = ((T - 1) * ld3 + HD) * 4;    // one head's K (or V) rows of this sequence, as a byte range
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + d), 0, seq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + 2 * d), 0, seq_bytes, 0x00020000);
+    const int qidx = q0 + li;
+    const int key_limit = min(T, q0 + 32);             // keys >= key_limit are masked for every query of the tile
+    const int k_voff = ((32 * wid + li) * ld3 + 4 * lh) * 4;                 // bytes; + scalar (st0 * ld3 + 8u) * 4
+    const int v_voff = (4 * lh * ld3 + wid * CW + VW * li) * 4;             // bytes; + scalar (st0 + 8s + c) * ld3 * 4
+    // K fragments of the NEXT super-tile are requested before the P.V phase of the current one (and the first ones
+    // here, before the Q tile is staged), V fragments before the softmax: no phase starts on an exposed memory latency
+    u32x4a kb[KD];
+    if (wid * 32 < key_limit) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* src = base + (long long)min(q0 + wid * 8 + j, T - 1) * ld3;
+        for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, 32 * u, 0);
+    }
+    {   // Q tile: thread t stages row t/8, 16-byte pieces 4*(t%8) + 32j; rows past T repeat the last row (never stored)
+        const int row = tid >> 3, seg = 4 * (tid & 7);
+        const float* src = base + (long long)min(q0 + row, T - 1) * ld3 + seg;
+        float4 qv[HD / 32];
 #pragma unroll
-            for (int i = 0; i < NQL; ++i) qv[j][i] = src[min(lane + 64 * i, HD - 1)];
-        }
+        for (int j = 0; j < HD / 32; ++j) qv[j] = *reinterpret_cast<const float4*>(src + 32 * j);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = wid * 8 + j;
-            const bool ok = q0 + q < T;
-#pragma unroll
-            for (int i = 0; i < NQL; ++i) {
-                const int k = lane + 64 * i;
-                if (k < HD) Qs[k * ATT_LDQ + q] = ok ? qv[j][i] : 0.f;
-            }
-        }
+        for (int j = 0; j < HD / 32; ++j)
+            *reinterpret_cast<float4*>(Qs + row * LDQ + seg + 32 * j) =
+                make_float4(qv[j].x * qscale, qv[j].y * qscale, qv[j].z * qscale, qv[j].w * qscale);
     }
     __syncthreads();
 
@@ -327,10 +366,8 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int qidx = q0 + li;
-    const int key_limit = min(T, q0 + 32);             // keys >= key_limit are masked for every query of the tile
-    const bool pow2_scale = (HD == 64 || HD == 256);
-    const float inv_scale = 1.0f / scale;
+    const float* q_frag = Qs + li * LDQ + 4 * lh;
+    const float* p_frag = Ps + li * LDP + 4 * lh;
 
     for (int st0 = 0; st0 < key_limit; st0 += 128) {
         const int key0 = st0 + wid * 32;
@@ -338,61 +375,57 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
         f32x16a S;
         float mt = -INFINITY;
         if (active) {
-            const float4* __restrict__ krow =
-                reinterpret_cast<const float4*>(Kb + (long long)min(key0 + li, T - 1) * ld3) + lh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.f;
-            float4 kb[2][GRP];
-            float qb[2][GRP][4];
+            const int k_soff = st0 * ld3 * 4;
 #pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                kb[0][u] = krow[2 * u];
-                const float* qa = Qs + (8 * u + 4 * lh) * ATT_LDQ + li;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) qb[0][u][c] = qa[c * ATT_LDQ];
+            for (int u = 0; u < NSTEP; ++u) {
+                const f32x4a kv = __builtin_bit_cast(f32x4a, kb[u % KD]);
+                if (u + KD < NSTEP)
+                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
+                const float4 qf = *reinterpret_cast<const float4*>(q_frag + 8 * u);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf.x, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf.y, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf.z, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf.w, S, 0, 0, 0);
             }
+            if (key0 + 31 > q0) {                      // the sub-tile touches the diagonal (or runs past T): mask
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
-#pragma unroll
-                    for (int u = 0; u < GRP; ++u) {
-                        kb[(g + 1) & 1][u] = krow[2 * ((g + 1) * GRP + u)];
-                        const float* qa = Qs + (8 * ((g + 1) * GRP + u) + 4 * lh) * ATT_LDQ + li;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) qb[(g + 1) & 1][u][c] = qa[c * ATT_LDQ];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    const float4 kv = kb[g & 1][u];
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qb[g & 1][u][0], S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qb[g & 1][u][1], S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qb[g & 1][u][2], S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qb[g & 1][u][3], S, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    S[r] = (key <= qidx) ? S[r] : -INFINITY;
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float sv = pow2_scale ? S[r] * inv_scale : S[r] / scale;
-                S[r] = (key <= qidx) ? sv : -INFINITY;
-                mt = fmaxf(mt, S[r]);
-            }
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, S[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         }
+        const int ngroups = (min(128, key_limit - st0) + 7) >> 3;      // 8-key groups of the P.V phase, wave-uniform
+        const int v_soff = st0 * ld3 * 4;
+        VBuf<VW> vb[VD][4];
+#pragma unroll
+        for (int u = 0; u < VD; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * u + c) * ld3 * 4);
         if (lh == 0) red[wid * 32 + li] = mt;
         __syncthreads();
         const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
-        const float m_new = fmaxf(m_run, m_tile);
-        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        const float m_new = fmaxf(m_run, m_tile);      // finite from the first super-tile on (key 0 is never masked)
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
         float ps = 0.f;
+        if (active) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (active && m_new != -INFINITY) ? __expf(S[r] - m_new) : 0.f;
-            Ps[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = p;
-            ps += p;
+            for (int g = 0; g < 4; ++g) {
+                float4 p;
+                p.x = __builtin_amdgcn_exp2f(S[4 * g + 0] - m_new);
+                p.y = __builtin_amdgcn_exp2f(S[4 * g + 1] - m_new);
+                p.z = __builtin_amdgcn_exp2f(S[4 * g + 2] - m_new);
+                p.w = __builtin_amdgcn_exp2f(S[4 * g + 3] - m_new);
+                ps += (p.x + p.y) + (p.z + p.w);
+                *reinterpret_cast<float4*>(Ps + li * LDP + wid * 32 + 8 * g + 4 * lh) = p;   // keys 8g + 4lh + 0..3
+            }
+            ps += __shfl_xor(ps, 32, 64);
         }
-        ps += __shfl_xor(ps, 32, 64);
         if (lh == 0) red[128 + wid * 32 + li] = ps;
         __syncthreads();
         l_run = l_run * alpha + ((red[128 + li] + red[160 + li]) + (red[192 + li] + red[224 + li]));
@@ -403,30 +436,37 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
                 for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
         }
         m_run = m_new;
-        // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P^T[key][q]
-        const int nsteps = (min(128, key_limit - st0) + 1) >> 1;       // key pairs (2t, 2t+1), wave-uniform
-        constexpr int VD = 8;
-        float vr[VD][4];
-        const float* vbase = Vb + VW * li;
+        // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P[q][key], 8 keys per group:
+        // lane half lh handles keys 8s + 4lh + c (c = 0..3) -- the four components of its ds_read_b128 of P
+        if (st0 + 128 + wid * 32 < key_limit) {         // this wave's K rows of the next super-tile
+            const int kn_soff = (st0 + 128) * ld3 * 4;
 #pragma unroll
-        for (int t = 0; t < VD - 1; ++t)
-            VLoad<VW>::ld(vbase + (long long)min(st0 + 2 * min(t, nsteps - 1) + lh, T - 1) * ld3, vr[t]);
-        for (int t0 = 0; t0 < nsteps; t0 += VD) {
+            for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
+        }
+        for (int s0 = 0; s0 < ngroups; s0 += VD) {
 #pragma unroll
             for (int u = 0; u < VD; ++u) {
-                const int t = t0 + u;
-                if (t < nsteps) {
-                    const int tn = min(t + VD - 1, nsteps - 1);
-                    VLoad<VW>::ld(vbase + (long long)min(st0 + 2 * tn + lh, T - 1) * ld3, vr[(u + VD - 1) % VD]);
-                    const float pb = Ps[(2 * t + lh) * LDP + li];
+                const int sg = s0 + u;
+                if (sg < ngroups) {
+                    const float4 pf = *reinterpret_cast<const float4*>(p_frag + 8 * sg);
+                    VBuf<VW> vc[4];
 #pragma unroll
-                    for (int j = 0; j < VW; ++j)
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[u][j], pb, O[j], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        vc[c] = vb[u][c];
+                        vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * (sg + VD) + c) * ld3 * 4);   // past the range: zeros
+                    }
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0].v[j], pf.x, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[1].v[j], pf.y, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[2].v[j], pf.z, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[3].v[j], pf.w, O[j], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    // ---- normalise, transpose through LDS (re-using the Q buffer), coalesced row stores
+    // ---- normalise, transpose through LDS (re-using the Q / P buffers), coalesced row stores
     __syncthreads();
     constexpr int LDO = HD + 1;
     {
@@ -453,12 +493,10 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 template <int HD>
 static int launch_colsplit(const float* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out,
                            hipStream_t s) {
-    size_t lds = ((size_t)HD * ATT_LDQ + 128 * 33 + 256) * 4;
-    const size_t o_bytes = (size_t)32 * (HD + 1) * 4;
-    if (o_bytes > lds) lds = o_bytes;
+    const size_t lds = ((size_t)32 * (HD + 4) + 32 * 132 + 256) * 4;       // >= the [32][HD+1] output tile
     ProfScope prof(PK_ATTN_FUSED, flop, s);
     hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3(cdiv(Tmax, 32), H, G.seq_prefix[G.n]), dim3(256), lds, s, qkv, G,
-                       d, (float)sqrt((double)HD), out);
+                       d, (float)(1.4426950408889634 / sqrt((double)HD)), out);
     R4D_CHECK_LAUNCH("attn_colsplit");
     return R4D_OK;
 }
