@@ -310,8 +310,8 @@ struct VBuf<2> {
 };
 
 template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, float qscale,
-                                                               float* __restrict__ out) {
+__global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, int H, int ntq,
+                                                               float qscale, float* __restrict__ out) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // floats per lane per V load = O^T tiles per wave (1 or 2)
     constexpr int NSTEP = HD / 8;                      // 16-byte K loads (and Q reads) per key row
@@ -324,13 +324,20 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
     float* red = Ps + 32 * LDP;                        // [2][4][32] per-wave row max / row sum
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y;   // long (late) query tiles first
+    // Work mapping (1-D grid): all query tiles of one (sequence, head) run on the SAME XCD (workgroup ids are dealt
+    // round-robin to the 8 XCDs, each with its own L2), back to back, so K and V of that head are fetched from HBM once
+    // instead of once per query tile (measured before: 970 MB per launch against 290 MB of qkv + out, L2 hit rate 22 %,
+    // i.e. the kernel ran at the HBM limit).  Long (late) query tiles go first.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / ntq) * 8 + xcd;           // (sequence, head) index
+    if (pair >= G.seq_prefix[G.n] * H) return;
+    const int qt = ntq - 1 - slot % ntq, h = pair % H, seq = pair / H;
     int gi = 0;
-    while (gi + 1 < G.n && (int)blockIdx.z >= G.seq_prefix[gi + 1]) ++gi;
+    while (gi + 1 < G.n && seq >= G.seq_prefix[gi + 1]) ++gi;
     const int T = G.T[gi];
     const int q0 = qt * 32;
-    if (q0 >= T) return;                               // grid.x covers the longest batch
-    const long long rowb = G.row0[gi] + (long long)((int)blockIdx.z - G.seq_prefix[gi]) * T;     // first row of the sequence
+    if (q0 >= T) return;                               // ntq covers the longest batch
+    const long long rowb = G.row0[gi] + (long long)(seq - G.seq_prefix[gi]) * T;     // first row of the sequence
     const int ld3 = 3 * d;
     const float* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
     const int seq_bytes = ((T - 1) * ld3 + HD) * 4;    // one head's K (or V) rows of this sequence, as a byte range
@@ -495,8 +502,11 @@ static int launch_colsplit(const float* qkv, const AttnGroups& G, int Tmax, doub
                            hipStream_t s) {
     const size_t lds = ((size_t)32 * (HD + 4) + 32 * 132 + 256) * 4;       // >= the [32][HD+1] output tile
     ProfScope prof(PK_ATTN_FUSED, flop, s);
-    hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3(cdiv(Tmax, 32), H, G.seq_prefix[G.n]), dim3(256), lds, s, qkv, G,
-                       d, (float)(1.4426950408889634 / sqrt((double)HD)), out);
+    const int ntq = cdiv(Tmax, 32);
+    const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
+    R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention: grid too large");
+    hipLaunchKernelGGL((attn_colsplit_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
+                       (float)(1.4426950408889634 / sqrt((double)HD)), out);
     R4D_CHECK_LAUNCH("attn_colsplit");
     return R4D_OK;
 }

@@ -57,6 +57,9 @@ def bench_class(k):
     m = re.match(r"gemm_f32_kernel<(\d+), (\d+), \d+, \d+, \d+, (false|true)>", k)
     if m:
         return f"gemm_f32_{m.group(1)}x{m.group(2)}_{'nt' if m.group(3) == 'true' else 'nn'}"
+    m = re.match(r"gemm_f32_kc_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+>", k)
+    if m:
+        return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
     return {"ln_kernel<false>": "layernorm", "ln_kernel<true>": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
