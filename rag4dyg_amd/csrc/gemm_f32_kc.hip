@@ -279,7 +279,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
 
 struct KcTile { int bm, bn, cls, blocks_per_cu, waves_per_block; double eff; };
 static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8192^3, tools/gemm_bench.py shape 14)
-    {128, 128, PK_GEMM_KC_128x128x32, 1, 8, 0.86},   // BK 32, three stages = 108 KB: one workgroup per CU
+    {128, 128, PK_GEMM_KC_128x128x32, 1, 8, 0.0},    // BK 32, 108 KB, one workgroup per CU: 136 TF asymptote; the BK 16 form
+                                                     // wins at every size, so eff 0 = only via R4D_GEMM_KC_TILE=0
     {128, 128, PK_GEMM_KC_128x128x16, 2, 8, 0.91},   // BK 16, three stages = 60 KB: two per CU
     {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.86},     // BK 16, 45 KB: three per CU
     {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
@@ -318,6 +319,7 @@ int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
         double best_cost = 1e300;
         for (int t = 0; t < kNumKc; ++t) {
             const KcTile& c = kKc[t];
+            if (c.eff <= 0.0) continue;
             long long blocks = (long long)cdiv(g.M, c.bm) * cdiv(g.N, c.bn) * g.nbatch;
             if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(g.M, c.bm) * g.nbatch / 2;
             const long long per_cu = (blocks + 255) / 256;

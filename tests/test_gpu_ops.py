@@ -63,6 +63,35 @@ def test_conv1d_all_epilogues(dev, M, K, N):
         assert rel_err(ops.conv1d(xd, wd, bd, "residual", rd, w_t=wt).cpu().numpy(), (ref + r).numpy()) < 1e-5
 
 
+def test_conv1d_k_contiguous_tiles(dev):
+    """Every auto-selectable tile of the k-contiguous GEMM is exercised (checked through the launch profiler) and
+    agrees with the oracle on ragged M / N."""
+    import ctypes
+    from rag4dyg_amd import ops, _lib
+    from oracle import gpt2_ref
+    lib = _lib.load()
+    _lib.check(lib.r4d_profile_enable(1), "profile_enable")
+    try:
+        for (M, K, N) in [(16380, 64, 1530), (4090, 512, 1536), (130, 96, 250), (257, 1024, 100), (129, 32, 130)]:
+            g = torch.Generator().manual_seed(M + K + N)
+            x = torch.randn(M, K, generator=g)
+            w = torch.randn(K, N, generator=g) * 0.05
+            b = torch.randn(N, generator=g) * 0.1
+            wd = w.to(dev)
+            y = ops.conv1d(x.to(dev), wd, b.to(dev), w_t=wd.t().contiguous()).cpu()
+            assert rel_err(y.numpy(), gpt2_ref.conv1d(x, w, b).numpy()) < 1e-5, (M, K, N)
+        torch.cuda.synchronize()
+        seen = set()
+        for c in range(lib.r4d_profile_num_classes()):
+            ms, n, wk = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.check(lib.r4d_profile_read(c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(wk)), "profile_read")
+            if n.value:
+                seen.add(lib.r4d_profile_class_name(c).decode())
+    finally:
+        _lib.check(lib.r4d_profile_enable(0), "profile_enable")
+    assert {"gemm_f32_kc_128x128x16", "gemm_f32_kc_128x64x16", "gemm_f32_kc_64x64x32"} <= seen, seen
+
+
 def test_conv1d_golden(dev):
     from rag4dyg_amd import ops
     g = load_golden("g2_ops")
