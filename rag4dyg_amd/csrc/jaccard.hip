@@ -12,9 +12,28 @@
 // token.  |A|B| = |A| + |B| - |A&B|; the f64 division is correctly rounded == python's int/int.
 #include "common.h"
 
+#ifndef JAC_DBG
+#define JAC_DBG 0   // tuning aid (tools/kc_ablate.sh jaccard.hip JAC_DBG n): bit 0 skips the token loop, bit 1 the division, bit 2 the store
+#endif
+
 namespace r4d {
 
 constexpr int JAC_MAX_VOCAB_LDS = 19455;           // 8 B * (19455 + 1) = 152 KB
+constexpr int JAC_RCP = 512;                       // reciprocal table entries (4 KB of LDS after the mask table)
+
+// Correctly rounded a / b for small integers without the 13-instruction IEEE f64 division sequence (which, not the
+// HBM writes, bounded this kernel: ablation 1149 us -> 555 us on 20k x 20k when the division is removed):
+//   r = RN(1/b) from an LDS table (filled once per workgroup with the true division), q0 = RN(a*r) is within 1 ulp,
+//   rem = a - b*q0 exactly (one FMA), q1 = RN(q0 + rem*r) is the correctly rounded quotient (Markstein's theorem:
+//   r correctly rounded, b's significand not all ones).  tests/test_host_cpu.py proves q1 == a/b for every
+//   1 <= a <= b < 512 with exact rational arithmetic, tests/test_gpu_ops.py checks the kernel on sets that produce
+//   every such (a, b).  Unions >= 512 take the IEEE division (wave-uniform branch).
+__device__ __forceinline__ double small_int_div(int a, int b, const double* __restrict__ rcp) {
+    const double af = (double)a, bf = (double)b, r = rcp[b];
+    const double q0 = af * r;
+    const double rem = __builtin_fma(-bf, q0, af);
+    return __builtin_fma(rem, r, q0);
+}
 
 __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __restrict__ a_ptr,
                                                           const int32_t* __restrict__ a_idx, int na, int a_nnz,
@@ -22,10 +41,14 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
                                                           const int32_t* __restrict__ b_idx, int nb, int vocab,
                                                           int zero_diag, int rows_per_block, double* __restrict__ out) {
     extern __shared__ unsigned long long mask[];    // [vocab + 1]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the wavefront index is made PROVABLY wave-uniform: everything per A row (CSR pointers, loop control, the row's
+    // output base address) then lives in scalar registers / scalar loads instead of vector instructions
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col0 = blockIdx.x * 64;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    double* rcp = reinterpret_cast<double*>(mask + vocab + 1);           // [JAC_RCP]
     for (int t = tid; t <= vocab; t += nthreads) mask[t] = 0ull;          // slot [vocab] stays zero
+    for (int t = tid; t < JAC_RCP; t += nthreads) rcp[t] = t ? 1.0 / (double)t : 0.0;
     __syncthreads();
     if (tid < 256) {   // scatter the 64 B-sets of this tile: 4 threads per set
         const int j = tid >> 2, sub = tid & 3, col = col0 + j;
@@ -42,63 +65,115 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
     const int lb = (col < nb) ? (b_ptr[col + 1] - b_ptr[col]) : 0;
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(na, row_begin + rows_per_block);
-    // Software pipeline over this wavefront's rows (i, i+nwaves, ...): the CSR pointers of the row after next
-    // and the first 64 tokens of the next row are in flight while the current row is counted and stored, so the
-    // two dependent global round trips per row (ptr -> tokens) are off the critical path.  All loads use clamped,
-    // always-valid indices; validity is applied to the VALUE.
+    // R = 4 independent A rows per wavefront iteration (rows i, i+nwaves, ..., i+3*nwaves).  With the big table only
+    // one workgroup (4 waves per SIMD) fits a CU and one row is a serial chain of dependent latencies (token ->
+    // LDS word -> count -> reciprocal from LDS -> 3 f64 ops -> store), ~1000 cycles per row and wave: four chains
+    // side by side fill them.  Software pipeline: the CSR pointers of the group after next (scalar loads) and the
+    // first 64 tokens of the next group's rows are in flight while the current group is counted and stored.  All
+    // loads use clamped, always-valid indices; validity is applied to the VALUE (tokens past a row read as -1,
+    // which selects the always-zero slot mask[vocab]).
+    constexpr int R = 4;
     const int last = na - 1, nz1 = a_nnz - 1;
     const unsigned int* mask32 = reinterpret_cast<const unsigned int*>(mask);
     const int half = lane >> 5, bit = lane & 31;
+    const int stride = R * nwaves;
     int i = row_begin + wid;
-    int sA = a_ptr[min(i, last)], eA = a_ptr[min(i, last) + 1];
-    int sB = a_ptr[min(i + nwaves, last)], eB = a_ptr[min(i + nwaves, last) + 1];
-    int tokA = a_idx[min(sA + lane, nz1)];
-    tokA = (sA + lane < eA) ? tokA : -1;
-    for (; i < row_end; i += nwaves) {
-        const int i2 = min(i + 2 * nwaves, last);
-        const int sC = a_ptr[i2], eC = a_ptr[i2 + 1];
-        int tokB = a_idx[min(sB + lane, nz1)];
-        tokB = (sB + lane < eB) ? tokB : -1;
-        const int la = eA - sA;
-        int cnt = 0;
-        int mytok = tokA;
-        for (int p0 = sA; p0 < eA; p0 += 64) {
-            if (p0 != sA) {
-                mytok = a_idx[min(p0 + lane, nz1)];
-                mytok = (p0 + lane < eA) ? mytok : -1;
+    int sA[R], eA[R], sB[R], eB[R], tokA[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ia = min(i + r * nwaves, last), ib = min(i + stride + r * nwaves, last);
+        sA[r] = a_ptr[ia]; eA[r] = a_ptr[ia + 1];
+        sB[r] = a_ptr[ib]; eB[r] = a_ptr[ib + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = a_idx[min(sA[r] + lane, nz1)];
+        tokA[r] = (sA[r] + lane < eA[r]) ? t : -1;
+    }
+    for (; i < row_end; i += stride) {
+        int sC[R], eC[R], tokB[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ic = min(i + 2 * stride + r * nwaves, last);
+            sC[r] = a_ptr[ic]; eC[r] = a_ptr[ic + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = a_idx[min(sB[r] + lane, nz1)];
+            tokB[r] = (sB[r] + lane < eB[r]) ? t : -1;
+        }
+        int la[R], cnt[R];
+        int mmax = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            la[r] = eA[r] - sA[r];
+            cnt[r] = 0;
+            mmax = max(mmax, min(la[r], 64));
+        }
+        if (JAC_DBG & 1) mmax = 0;
+        // joint walk over the first 64 tokens of the four rows: four independent broadcast LDS reads per step
+        for (int t = 0; t < mmax; ++t) {
+            unsigned int bits[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int tok = __builtin_amdgcn_readlane(tokA[r], t);               // scalar broadcast
+                const int tkk = ((unsigned)tok < (unsigned)vocab) ? tok : vocab;
+                bits[r] = mask32[2 * tkk + half];
             }
-            const int m = min(64, eA - p0);
-            // 4 tokens per trip: four independent broadcast LDS reads in flight (out-of-range / padding tokens
-            // are redirected to the always-zero slot mask[vocab], so there is no branch in the loop)
-            int t = 0;
-            if (m <= 2) {                             // typical output set: one or two tokens, no unroll overhead
-                for (; t < m; ++t) {
-                    const int tok = __builtin_amdgcn_readlane(mytok, t);
-                    const int tkk = ((unsigned)tok < (unsigned)vocab) ? tok : vocab;
-                    cnt += (int)((mask32[2 * tkk + half] >> bit) & 1u);
+#pragma unroll
+            for (int r = 0; r < R; ++r) cnt[r] += (int)((bits[r] >> bit) & 1u);
+        }
+        // rows longer than 64 tokens (rare): the remaining chunks, one row at a time
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((JAC_DBG & 1) || la[r] <= 64) continue;
+            for (int p0 = sA[r] + 64; p0 < eA[r]; p0 += 64) {
+                int mytok = a_idx[min(p0 + lane, nz1)];
+                mytok = (p0 + lane < eA[r]) ? mytok : -1;
+                const int m = min(64, eA[r] - p0);
+                for (int t = 0; t < m; t += 4) {
+                    unsigned int bits[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int tok = __builtin_amdgcn_readlane(mytok, (t + u) & 63);
+                        const int tkk = ((unsigned)tok < (unsigned)vocab) ? tok : vocab;   // lanes past m hold -1
+                        bits[u] = mask32[2 * tkk + half];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cnt[r] += (int)((bits[u] >> bit) & 1u);
                 }
             }
-            for (; t < m; t += 4) {
-                int tk[4];
+        }
+        double q[R];
+        int any_cnt = 0, any_big = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int tok = __builtin_amdgcn_readlane(mytok, (t + u) & 63);     // scalar broadcast
-                    tk[u] = ((unsigned)tok < (unsigned)vocab && t + u < m) ? tok : vocab;
-                }
-                unsigned int bits[4];
+        for (int r = 0; r < R; ++r) {
+            any_cnt |= cnt[r];
+            any_big |= (la[r] + lb - cnt[r] >= JAC_RCP);
+            q[r] = 0.0;
+        }
+        if (!(JAC_DBG & 2) && __any(any_cnt != 0)) {     // most 4 x 64-pair groups have only empty intersections: skip
+            if (__any(any_big)) {                        // some union >= table size: IEEE division for the whole group
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bits[u] = mask32[2 * tk[u] + half];
+                for (int r = 0; r < R; ++r)
+                    if (la[r] > 0 && lb > 0) q[r] = (double)cnt[r] / (double)(la[r] + lb - cnt[r]);
+            } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) cnt += (int)((bits[u] >> bit) & 1u);
+                for (int r = 0; r < R; ++r)         // rcp[0] = 0: an empty set gives 0.0
+                    q[r] = small_int_div(cnt[r], (la[r] > 0 && lb > 0) ? la[r] + lb - cnt[r] : 0, rcp);
             }
         }
-        double r = 0.0;
-        if (__any(cnt != 0)) {                       // most 64-pair segments have an empty intersection: skip the
-            if (la > 0 && lb > 0) r = (double)cnt / (double)(la + lb - cnt);    // f64 division for the whole wave
-            if (zero_diag && i == col) r = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = i + r * nwaves;                  // wave-uniform
+            if (row < row_end) {
+                double v = q[r];
+                if (zero_diag && row == col) v = 0.0;
+                if ((JAC_DBG & 4) ? (v == 12345.0) : (col < nb)) (out + (long long)row * nb)[(unsigned)col] = v;
+            }
         }
-        if (col < nb) out[(long long)i * nb + col] = r;
-        sA = sB; eA = eB; tokA = tokB; sB = sC; eB = eC;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { sA[r] = sB[r]; eA[r] = eB[r]; tokA[r] = tokB[r]; sB[r] = sC[r]; eB[r] = eC[r]; }
     }
 }
 
@@ -147,12 +222,12 @@ extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, i
         int chunks = max(1, min(cdiv(na, 64), cdiv(2048, col_tiles)));
         const int rows_per_block = cdiv(na, chunks);
         chunks = cdiv(na, rows_per_block);
-        const size_t lds = ((size_t)vocab + 1) * sizeof(unsigned long long);
+        const size_t lds = ((size_t)vocab + 1) * sizeof(unsigned long long) + JAC_RCP * sizeof(double);
         if (lds > 64 * 1024) {
             static bool raised = false;     // opt in to > 64 KB dynamic LDS once
             if (!raised) {
                 if (hipFuncSetAttribute((const void*)jaccard_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (JAC_MAX_VOCAB_LDS + 1) * 8) != hipSuccess) {
+                                        (JAC_MAX_VOCAB_LDS + 1) * 8 + JAC_RCP * 8) != hipSuccess) {
                     set_error("jaccard: cannot raise dynamic LDS limit");
                     return R4D_ERR_HIP;
                 }

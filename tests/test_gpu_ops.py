@@ -329,6 +329,23 @@ def test_jaccard_edge_cases_and_merge_fallback(dev):
         assert np.array_equal(outd, refd)
 
 
+def test_jaccard_every_small_quotient_is_correctly_rounded(dev):
+    """Prefix sets A_i = {0..i-1}, B_j = {0..j-1} give |A&B| / |A|B| = min(i,j) / max(i,j): every quotient a/b with
+    1 <= a <= b <= 600 goes through the kernel -- the LDS-reciprocal path (b < 512) and the IEEE path (b >= 512) --
+    and must equal numpy's correctly rounded float64 division bit for bit."""
+    from rag4dyg_amd import ops
+    n = 600
+    lens = np.arange(0, n + 1, dtype=np.int32)                        # set i has i tokens (set 0 is empty)
+    ptr = np.zeros(n + 2, np.int32); ptr[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.arange(l, dtype=np.int32) for l in lens])
+    out = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), n + 1).cpu().numpy()
+    i, j = np.meshgrid(lens.astype(np.float64), lens.astype(np.float64), indexing="ij")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = np.where(np.maximum(i, j) > 0, np.minimum(i, j) / np.maximum(i, j), 0.0)
+    ref[0, :] = 0.0; ref[:, 0] = 0.0
+    assert out.dtype == np.float64 and np.array_equal(out.view(np.uint64), ref.view(np.uint64))
+
+
 # ----------------------------------------------------------------------------------------- full-size properties
 def test_full_size_pool_scan_properties(dev):
     """North-star size (100k-row pool, d=512, reference query batch 32): size-independent properties instead of a

@@ -278,6 +278,21 @@ def test_sharded_topk_world_size_2_gloo(tmp_path, world):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+def test_small_integer_division_scheme_is_correctly_rounded():
+    """The Jaccard kernel divides small integers as q1 = fma(a - b*q0, r, q0) with r = RN(1/b), q0 = RN(a*r)
+    (rag4dyg_amd/csrc/jaccard.hip: small_int_div).  Proof by exhaustion with exact rational arithmetic that q1 is the
+    correctly rounded a/b -- python's int/int -- for every 1 <= a <= b < 512 (the table range)."""
+    from fractions import Fraction
+    for b in range(1, 512):
+        r = 1.0 / b                                                  # RN(1/b): the table entry
+        fr, fb = Fraction(r), Fraction(b)
+        for a in range(1, b + 1):
+            q0 = float(a) * r                                        # RN(a * r)
+            rem = float(Fraction(a) - fb * Fraction(q0))             # fma(-b, q0, a): one rounding of the exact value
+            q1 = float(Fraction(q0) + Fraction(rem) * fr)            # fma(rem, r, q0)
+            assert q1 == a / b, (a, b)
+
+
 def test_evaluation_metrics_natural_log_ndcg():
     import math
     from rag4dyg_amd.evaluation import Evaluation
