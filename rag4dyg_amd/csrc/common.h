@@ -70,20 +70,29 @@ int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given a
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
                      hipStream_t s);
-int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const float* wte, const float* wpe,
-                           int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
-                           float* x_out, float* y_out, hipStream_t s);
+constexpr int ATT_MAXG = 16;
+// Up to ATT_MAXG right-padded batches handled by ONE launch of a row kernel (each batch keeps its own T): rows of the
+// batches are consecutive in x / y, sequences consecutive in the pooled output.  ids[g] / emb[g]: exactly one is set.
+struct RowGroups {
+    int n;
+    int B[ATT_MAXG], T[ATT_MAXG];
+    const int64_t* ids[ATT_MAXG];
+    const float* emb[ATT_MAXG];
+};
+int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
+                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s);
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
-constexpr int ATT_MAXG = 16;
 int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,
                                   int d, float* out, hipStream_t s);
 extern int g_attention_variant;
 extern int g_attention_fused;        // -1 auto (default), 1 fused, 0 three-launch GEMM form (r4d_set_attention_fused)
 constexpr int LNF_ROWS_PER_CHUNK = 16;
 size_t lnf_meanpool_scratch_floats(int B, int T, int d);
-int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
-                        float* hidden_out, float* pool_out, float* scratch, hipStream_t s);
+// x / hidden_out: first row of the first batch; pool_out: first sequence of the first batch; scratch: the sum over the
+// batches of lnf_meanpool_scratch_floats
+int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* w, const float* b, int d, float eps,
+                               float* hidden_out, float* pool_out, float* scratch, hipStream_t s);
 
 }  // namespace r4d

@@ -74,6 +74,17 @@ struct Group {                 // one right-padded reference batch inside a fuse
     const int64_t* ids; const float* emb; int B, T; size_t row0, seq0;
 };
 
+static RowGroups row_groups(const Group* groups, int g0, int n_groups) {
+    RowGroups R;
+    R.n = n_groups - g0 < ATT_MAXG ? n_groups - g0 : ATT_MAXG;
+    for (int j = 0; j < ATT_MAXG; ++j) {
+        const bool in = j < R.n;
+        R.B[j] = in ? groups[g0 + j].B : 0; R.T[j] = in ? groups[g0 + j].T : 0;
+        R.ids[j] = in ? groups[g0 + j].ids : nullptr; R.emb[j] = in ? groups[g0 + j].emb : nullptr;
+    }
+    return R;
+}
+
 struct Workspace {
     float *x, *ln, *qkv, *att, *fc, *scores, *pool;
     size_t bytes;
@@ -134,8 +145,7 @@ size_t r4d_gpt2_groups_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_gro
         M += (size_t)Bs[g] * Ts[g];
         const size_t f = score_floats(Bs[g], cfg->n_head, Ts[g]);
         if (f > sc) sc = f;
-        const size_t p = lnf_meanpool_scratch_floats(Bs[g], Ts[g], cfg->n_embd);
-        if (p > pl) pl = p;
+        pl += lnf_meanpool_scratch_floats(Bs[g], Ts[g], cfg->n_embd);      // all batches pooled by one launch
     }
     return carve(nullptr, M, sc, pl, cfg->n_embd).bytes;
 }
@@ -166,8 +176,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         Mtot += (size_t)G.B * G.T;
         const size_t f = score_floats(G.B, H, G.T);
         if (f > sc) sc = f;
-        const size_t p = lnf_meanpool_scratch_floats(G.B, G.T, d);
-        if (p > pl) pl = p;
+        pl += lnf_meanpool_scratch_floats(G.B, G.T, d);
     }
     R4D_REQUIRE(Mtot <= 0x7fffffff / (size_t)(4 * d), "gpt2: %zu rows in one call is too many", Mtot);
     const int M = (int)Mtot;
@@ -181,10 +190,11 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
                     "gpt2: null weight in layer %d", l);
         if (l == 0) {
-            for (int g = 0; g < n_groups; ++g) {
-                const Group& G = groups[g];
-                rc = launch_embed_layernorm(G.ids, G.emb, w->wte, w->wpe, cfg->vocab, G.B * G.T, G.T, d, L.ln_1_w,
-                                            L.ln_1_b, cfg->ln_eps, ws.x + G.row0 * d, ws.ln + G.row0 * d, s);
+            for (int g0 = 0; g0 < n_groups; g0 += ATT_MAXG) {          // ATT_MAXG batches per launch
+                const RowGroups R = row_groups(groups, g0, n_groups);
+                const size_t r0 = groups[g0].row0;
+                rc = launch_embed_layernorm_groups(R, w->wte, w->wpe, cfg->vocab, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps,
+                                                   ws.x + r0 * d, ws.ln + r0 * d, s);
                 if (rc) return rc;
             }
         } else if ((rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s))) {
@@ -227,12 +237,15 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
         if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
     }
-    for (int g = 0; g < n_groups; ++g) {
-        const Group& G = groups[g];
-        rc = launch_lnf_meanpool(ws.x + G.row0 * d, w->ln_f_w, w->ln_f_b, G.B, G.T, d, cfg->ln_eps,
-                                 out_hidden_d ? out_hidden_d + G.row0 * d : nullptr,
-                                 out_meanpool_d ? out_meanpool_d + G.seq0 * d : nullptr, ws.pool, s);
+    size_t part0 = 0;                                                   // scratch offset of the launch's first batch
+    for (int g0 = 0; g0 < n_groups; g0 += ATT_MAXG) {
+        const RowGroups R = row_groups(groups, g0, n_groups);
+        const Group& G = groups[g0];
+        rc = launch_lnf_meanpool_groups(R, ws.x + G.row0 * d, w->ln_f_w, w->ln_f_b, d, cfg->ln_eps,
+                                        out_hidden_d ? out_hidden_d + G.row0 * d : nullptr,
+                                        out_meanpool_d ? out_meanpool_d + G.seq0 * d : nullptr, ws.pool + part0, s);
         if (rc) return rc;
+        for (int j = 0; j < R.n; ++j) part0 += lnf_meanpool_scratch_floats(R.B[j], R.T[j], d);
     }
     return R4D_OK;
 }

@@ -33,42 +33,16 @@ __device__ __forceinline__ void ln_row(float (&v)[MAXV], int nv, int d, float ep
     for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = (v[i] - mean) * rstd;
 }
 
-// x_out[m,:] = (ids ? wte[ids[m]] : inputs_embeds[m]) + wpe[m % T]   (modeling_gpt2.py:463-469)
-// y_out[m,:] = LayerNorm(x_out[m,:])                                  (ln_1 of block 0)
-// With EMBED == false: y = LayerNorm(x_in) only.
-template <bool EMBED>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in, const int64_t* __restrict__ ids,
-                                                 const float* __restrict__ wte, const float* __restrict__ wpe,
-                                                 int vocab, int rows, int T, int d, const float* __restrict__ w,
-                                                 const float* __restrict__ b, float eps, float* __restrict__ x_out,
-                                                 float* __restrict__ y_out) {
+// y[m,:] = LayerNorm(x[m,:]), one wavefront per row
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in, int rows, int d, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float eps, float* __restrict__ y_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = d >> 6;
     float v[MAXV];
-    if (EMBED) {
-        const float* src;
-        bool bad = false;
-        if (ids) {
-            const long long id = ids[row];
-            bad = id < 0 || id >= vocab;                 // out-of-vocabulary id: poison the row, never fault
-            src = wte + (bad ? 0 : id) * (long long)d;
-        } else {
-            src = x_in + (long long)row * d;
-        }
-        const float* pe = wpe + (long long)(row % T) * d;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i < nv) {
-                const float e = src[lane + 64 * i] + pe[lane + 64 * i];
-                v[i] = bad ? __builtin_nanf("") : e;
-                x_out[(long long)row * d + lane + 64 * i] = v[i];
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x_in[(long long)row * d + lane + 64 * i];
-    }
+    for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x_in[(long long)row * d + lane + 64 * i];
     ln_row(v, nv, d, eps);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -80,20 +54,85 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "layernorm: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (rows <= 0) return R4D_OK;
     ProfScope prof(PK_LAYERNORM, 8.0 * rows * d, s);            // bytes: read x + write y
-    hipLaunchKernelGGL((ln_kernel<false>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, 0, rows,
-                       1, d, w, b, eps, nullptr, y);
+    hipLaunchKernelGGL(ln_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
     R4D_CHECK_LAUNCH("layernorm");
     return R4D_OK;
 }
 
-int launch_embed_layernorm(const int64_t* ids, const float* inputs_embeds, const float* wte, const float* wpe,
-                           int vocab, int rows, int T, int d, const float* w, const float* b, float eps,
-                           float* x_out, float* y_out, hipStream_t s) {
+// Prefix tables of a RowGroups launch (kernel argument, by value; the batch of a row / sequence is found by a short scan).
+struct RowTable {
+    int n;
+    int T[ATT_MAXG];
+    int seq_prefix[ATT_MAXG + 1];            // first sequence of each batch
+    long long row_prefix[ATT_MAXG + 1];      // first token row of each batch
+    long long part_prefix[ATT_MAXG + 1];     // first partial row (B * chunks) of each batch in the mean-pool scratch
+};
+struct RowInputs { const int64_t* ids[ATT_MAXG]; const float* emb[ATT_MAXG]; };
+
+static RowTable make_table(const RowGroups& G) {
+    RowTable t;
+    t.n = G.n;
+    t.seq_prefix[0] = 0; t.row_prefix[0] = 0; t.part_prefix[0] = 0;
+    for (int g = 0; g < ATT_MAXG; ++g) {
+        const int B = g < G.n ? G.B[g] : 0, T = g < G.n ? G.T[g] : 0;
+        t.T[g] = T;
+        t.seq_prefix[g + 1] = t.seq_prefix[g] + B;
+        t.row_prefix[g + 1] = t.row_prefix[g] + (long long)B * T;
+        t.part_prefix[g + 1] = t.part_prefix[g] + (long long)B * cdiv(T > 0 ? T : 1, LNF_ROWS_PER_CHUNK) * (B > 0);
+    }
+    return t;
+}
+
+// x_out[m,:] = (ids ? wte[ids[m]] : inputs_embeds[m]) + wpe[position of m in ITS batch]   (modeling_gpt2.py:463-469)
+// y_out[m,:] = LayerNorm(x_out[m,:])   (ln_1 of block 0) -- all batches of a fused call in one launch
+__global__ __launch_bounds__(256) void embed_ln_groups_kernel(const RowTable G, const RowInputs in,
+                                                              const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                              int vocab, int d, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps,
+                                                              float* __restrict__ x_out, float* __restrict__ y_out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= G.row_prefix[G.n]) return;
+    int g = 0;
+    while (g + 1 < G.n && row >= G.row_prefix[g + 1]) ++g;
+    const long long local = row - G.row_prefix[g];
+    const int nv = d >> 6;
+    float v[MAXV];
+    const float* src;
+    bool bad = false;
+    if (in.ids[g]) {
+        const long long id = in.ids[g][local];
+        bad = id < 0 || id >= vocab;                     // out-of-vocabulary id: poison the row, never fault
+        src = wte + (bad ? 0 : id) * (long long)d;
+    } else {
+        src = in.emb[g] + local * d;
+    }
+    const float* pe = wpe + (local % G.T[g]) * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            const float e = src[lane + 64 * i] + pe[lane + 64 * i];
+            v[i] = bad ? __builtin_nanf("") : e;
+            x_out[row * d + lane + 64 * i] = v[i];
+        }
+    ln_row(v, nv, d, eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) y_out[row * d + lane + 64 * i] = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
+                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    R4D_REQUIRE(G.n >= 1 && G.n <= ATT_MAXG, "embed: %d batches per launch (max %d)", G.n, ATT_MAXG);
+    const RowTable t = make_table(G);
+    const long long rows = t.row_prefix[G.n];
     if (rows <= 0) return R4D_OK;
+    RowInputs in;
+    for (int g = 0; g < ATT_MAXG; ++g) { in.ids[g] = g < G.n ? G.ids[g] : nullptr; in.emb[g] = g < G.n ? G.emb[g] : nullptr; }
     ProfScope prof(PK_EMBED_LN, 12.0 * rows * d + 8.0 * rows, s);   // bytes: gather row + write x, y (+ ids)
-    hipLaunchKernelGGL((ln_kernel<true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, inputs_embeds, ids, wte, wpe, vocab,
-                       rows, T, d, w, b, eps, x_out, y_out);
+    hipLaunchKernelGGL(embed_ln_groups_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, t, in, wte, wpe, vocab, d,
+                       w, b, eps, x_out, y_out);
     R4D_CHECK_LAUNCH("embed_layernorm");
     return R4D_OK;
 }
@@ -150,20 +189,26 @@ int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStr
 // its rows (one wavefront per row), sums them per wave in registers, combines its 4 waves through LDS in a
 // fixed order and writes one partial row; (2) one workgroup per sequence adds the S partials in order and
 // divides by T.  No atomics -> bitwise reproducible.
-__global__ __launch_bounds__(256) void lnf_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ b, int T, int d, float eps,
-                                                          int rows_per_chunk, float* __restrict__ hidden_out,
+__global__ __launch_bounds__(256) void lnf_partial_kernel(const RowTable G, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ b, int d,
+                                                          float eps, float* __restrict__ hidden_out,
                                                           float* __restrict__ partial) {
     extern __shared__ float red[];                     // [4][d]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int chunk = blockIdx.x, bidx = blockIdx.y, S = gridDim.x;
+    const int chunk = blockIdx.x, seq = blockIdx.y;
+    int g = 0;
+    while (g + 1 < G.n && seq >= G.seq_prefix[g + 1]) ++g;
+    const int T = G.T[g], S = (T + LNF_ROWS_PER_CHUNK - 1) / LNF_ROWS_PER_CHUNK;
+    if (chunk >= S) return;                            // grid.x covers the longest batch
+    const int bidx = seq - G.seq_prefix[g];            // sequence within its batch
+    const long long row0 = G.row_prefix[g] + (long long)bidx * T;
     const int nv = d >> 6;
-    const int t0 = chunk * rows_per_chunk, t1 = min(T, t0 + rows_per_chunk);
+    const int t0 = chunk * LNF_ROWS_PER_CHUNK, t1 = min(T, t0 + LNF_ROWS_PER_CHUNK);
     float acc[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) acc[i] = 0.f;
     for (int t = t0 + wid; t < t1; t += 4) {
-        const long long base = ((long long)bidx * T + t) * d;
+        const long long base = (row0 + t) * d;
         float v[MAXV];
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x[base + lane + 64 * i];
@@ -180,37 +225,48 @@ __global__ __launch_bounds__(256) void lnf_partial_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) if (i < nv) red[wid * d + lane + 64 * i] = acc[i];
     __syncthreads();
+    const long long prow = G.part_prefix[g] + (long long)bidx * S + chunk;
     for (int c = threadIdx.x; c < d; c += 256)
-        partial[((long long)bidx * S + chunk) * d + c] = (red[c] + red[d + c]) + (red[2 * d + c] + red[3 * d + c]);
+        partial[prow * d + c] = (red[c] + red[d + c]) + (red[2 * d + c] + red[3 * d + c]);
 }
 
-__global__ __launch_bounds__(256) void meanpool_reduce_kernel(const float* __restrict__ partial, int S, int T, int d,
+__global__ __launch_bounds__(256) void meanpool_reduce_kernel(const RowTable G, const float* __restrict__ partial, int d,
                                                               float* __restrict__ pool_out) {
-    const int bidx = blockIdx.x;
+    const int seq = blockIdx.x;
+    int g = 0;
+    while (g + 1 < G.n && seq >= G.seq_prefix[g + 1]) ++g;
+    const int T = G.T[g], S = (T + LNF_ROWS_PER_CHUNK - 1) / LNF_ROWS_PER_CHUNK;
+    const long long prow = G.part_prefix[g] + (long long)(seq - G.seq_prefix[g]) * S;
     for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[((long long)bidx * S + k) * d + c];
-        pool_out[(long long)bidx * d + c] = s / (float)T;
+        for (int k = 0; k < S; ++k) s += partial[(prow + k) * d + c];
+        pool_out[(long long)seq * d + c] = s / (float)T;
     }
 }
 
 size_t lnf_meanpool_scratch_floats(int B, int T, int d) { return (size_t)B * cdiv(T, LNF_ROWS_PER_CHUNK) * d; }
 
-int launch_lnf_meanpool(const float* x, const float* w, const float* b, int B, int T, int d, float eps,
-                        float* hidden_out, float* pool_out, float* scratch, hipStream_t s) {
+int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* w, const float* b, int d, float eps,
+                               float* hidden_out, float* pool_out, float* scratch, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "ln_f: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     R4D_REQUIRE(!pool_out || scratch, "ln_f: mean-pool needs scratch");
-    if (B <= 0 || T <= 0) return R4D_OK;
-    const int S = cdiv(T, LNF_ROWS_PER_CHUNK);
+    R4D_REQUIRE(G.n >= 1 && G.n <= ATT_MAXG, "ln_f: %d batches per launch (max %d)", G.n, ATT_MAXG);
+    const RowTable t = make_table(G);
+    const int nseq = t.seq_prefix[G.n];
+    const long long rows = t.row_prefix[G.n], parts = t.part_prefix[G.n];
+    if (nseq <= 0 || rows <= 0) return R4D_OK;
+    R4D_REQUIRE(nseq <= 65535, "ln_f: %d sequences per launch exceed the grid limit", nseq);
+    int Tmax = 0;
+    for (int g = 0; g < G.n; ++g) Tmax = G.T[g] > Tmax ? G.T[g] : Tmax;
     {
-        ProfScope prof(PK_LNF_MEANPOOL, 4.0 * B * T * d * (hidden_out ? 2 : 1) + 4.0 * B * S * d, s);
-        hipLaunchKernelGGL(lnf_partial_kernel, dim3(S, B), dim3(256), 4 * d * sizeof(float), s, x, w, b, T, d, eps,
-                           LNF_ROWS_PER_CHUNK, hidden_out, pool_out ? scratch : nullptr);
+        ProfScope prof(PK_LNF_MEANPOOL, 4.0 * rows * d * (hidden_out ? 2 : 1) + 4.0 * parts * d, s);
+        hipLaunchKernelGGL(lnf_partial_kernel, dim3(cdiv(Tmax, LNF_ROWS_PER_CHUNK), nseq), dim3(256), 4 * d * sizeof(float), s,
+                           t, x, w, b, d, eps, hidden_out, pool_out ? scratch : nullptr);
         R4D_CHECK_LAUNCH("lnf_partial");
     }
     if (pool_out) {
-        ProfScope prof(PK_MEANPOOL_REDUCE, 4.0 * B * S * d + 4.0 * B * d, s);
-        hipLaunchKernelGGL(meanpool_reduce_kernel, dim3(B), dim3(256), 0, s, scratch, S, T, d, pool_out);
+        ProfScope prof(PK_MEANPOOL_REDUCE, 4.0 * parts * d + 4.0 * nseq * d, s);
+        hipLaunchKernelGGL(meanpool_reduce_kernel, dim3(nseq), dim3(256), 0, s, t, scratch, d, pool_out);
         R4D_CHECK_LAUNCH("meanpool_reduce");
     }
     return R4D_OK;

@@ -62,7 +62,7 @@ def bench_class(k):
         return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
-    return {"ln_kernel<false>": "layernorm", "ln_kernel<true>": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
+    return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
             "lnf_partial_kernel": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce",
             "normalize_rows_kernel": "normalize_rows", "topk_seg_kernel<float>": "topk_seg",
             "merge_topk_kernel": "merge_topk", "jaccard_lds_kernel": "jaccard"}.get(k, k)
