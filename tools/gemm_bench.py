@@ -25,6 +25,11 @@ def child():
     tile = ("kc" + tile) if os.environ.get("R4D_WT") else tile
     sel = os.environ.get("R4D_SHAPES")
     shapes = [SHAPES[int(i)] for i in sel.split(",")] if sel else SHAPES
+    if os.environ.get("R4D_SHAPE_LIST"):                 # "MxKxN[:epilogue],..."
+        shapes = []
+        for t in os.environ["R4D_SHAPE_LIST"].split(","):
+            dims, _, epi = t.partition(":")
+            shapes.append(tuple(int(v) for v in dims.split("x")) + (epi or "none",))
     for M, K, N, epi in shapes:
         x = torch.randn(M, K, device=dev)
         w = torch.randn(K, N, device=dev) * 0.02
