@@ -1,0 +1,370 @@
+"""RAG generator INFERENCE: fusion of the retrieved demonstrations + greedy link prediction.
+
+Host-side mirror of ``dataloader/generator.py`` (``TextIndexScoreDataset``), ``utils/model.py:105-224``
+(``fusion_mlp`` / ``fusion_graphpooling``) and ``utils/Evaluation_generator.py:49-265``
+(``get_eval_metrics_generator``), consuming the ``*_index.gen`` / ``*_score.gen`` files the retrieve path of this build
+writes.  All dense work runs on the gfx950 kernels: the GCN / MLP projections and the normalised-adjacency product
+through ``r4d_conv1d_f32``, the forward on ``inputs_embeds`` through ``r4d_gpt2_encode_f32``, the tied lm_head on the
+LAST row only through ``r4d_lm_logits_f32``.  torch is used for the embedding gathers and the concatenation (plumbing).
+
+Differences from the reference, all value-preserving:
+  * the fused rows depend only on the retrieved indices, so they are computed ONCE per query instead of once per
+    generated token (``Evaluation_generator.py:155`` re-runs the fusion every step);
+  * the GCN runs on a dense normalised adjacency (the fused graph of top-K sequences has a few hundred nodes) instead
+    of torch_geometric's scatter -- same sums, ``D^-1/2 (A+I) D^-1/2`` as GCNConv's defaults define it;
+  * GNNs with more than one layer: the reference applies ``F.dropout`` with ``training=True`` even at inference
+    (``modeling_rag.py:69``, stochastic); this build applies none (the expectation).  Shipped scripts use one layer.
+Training (``train/train_generator.py``) is out of scope: ``main_generator.py --do_train`` raises.
+"""
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .dataloader import read_nonblank_lines
+from .evaluation import Evaluation
+
+
+# ------------------------------------------------------------------------------------------------ fusion modules
+class GCNConvParams(nn.Module):
+    """Parameter holder with torch_geometric's GCNConv names: ``lin.weight`` [out, in] (PyG >= 2.0) and ``bias``."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin = nn.Linear(in_dim, out_dim, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        nn.init.xavier_uniform_(self.lin.weight)           # glorot, as GCNConv.reset_parameters
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        old = prefix + "weight"                           # PyG 1.7.x: ``weight`` [in, out]
+        if old in state_dict and prefix + "lin.weight" not in state_dict:
+            state_dict[prefix + "lin.weight"] = state_dict.pop(old).t().contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class GNN(nn.Module):
+    """``models/modeling_rag.py:44-71`` (layer widths; the forward lives in ``gnn_pool``)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, n_layers, dropout_rate=0.5):
+        super().__init__()
+        self.n_layers, self.dropout_rate = n_layers, dropout_rate
+        dims = [input_dim] + [hidden_dim] * (n_layers - 1) + [output_dim]
+        self.convs = nn.ModuleList(GCNConvParams(dims[i], dims[i + 1]) for i in range(n_layers))
+
+
+class MLP_custom(nn.Module):
+    """``models/modeling_rag.py:74-99``: same ``layers`` Sequential indices, so reference state_dicts load."""
+
+    def __init__(self, input_dim, output_dim, n_layers):
+        super().__init__()
+        self.n_layers = n_layers
+        hidden = int(input_dim / 2)
+        if n_layers == 1:
+            self.layers = nn.Sequential(nn.Linear(input_dim, output_dim))
+        else:
+            mods = [nn.Linear(input_dim, hidden), nn.ReLU()]
+            for _ in range(n_layers - 2):
+                mods += [nn.Linear(hidden, hidden), nn.ReLU()]
+            mods.append(nn.Linear(hidden, output_dim))
+            self.layers = nn.Sequential(*mods)
+
+
+def _linear(x, lin, epilogue="none"):
+    """y = x W^T + b on the k-contiguous GEMM (``W`` [out, in] IS the transposed Conv1D weight)."""
+    w = lin.weight
+    b = lin.bias if lin.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    return ops.conv1d(x.contiguous(), w.t().contiguous(), b, epilogue, None, w.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ graph fusion
+def star_union_graph(retrieval_sources, idxs):
+    """Fused graph of ``fusion_graphpooling`` (``utils/model.py:181-189``): ego (token 2 of each retrieved sequence)
+    linked to every token id of that sequence.  Node order = networkx insertion order.  Returns (nodes, edge set)."""
+    order, pos, edges = [], {}, set()
+    for n in idxs:
+        seq = [int(e) for e in retrieval_sources[int(n)]]
+        ego = seq[2]
+        for v in (ego,):
+            if v not in pos:
+                pos[v] = len(order); order.append(v)
+        a = pos[ego]
+        for e in seq:
+            if e not in pos:
+                pos[e] = len(order); order.append(e)
+            b = pos[e]
+            edges.add((a, b) if a <= b else (b, a))
+    return order, edges
+
+
+def gcn_norm_dense(n, edges, device):
+    """``D^-1/2 (A + I) D^-1/2`` (GCNConv ``gcn_norm`` defaults) as a dense fp32 matrix on ``device``."""
+    A = torch.zeros(n, n, dtype=torch.float32)
+    if edges:
+        e = torch.tensor([p for p in edges if p[0] != p[1]], dtype=torch.long).view(-1, 2)
+        A[e[:, 0], e[:, 1]] = 1.0
+        A[e[:, 1], e[:, 0]] = 1.0
+    A += torch.eye(n)
+    dinv = A.sum(dim=1).pow(-0.5)
+    return (dinv[:, None] * A * dinv[None, :]).to(device)
+
+
+def _pad4(a_norm):
+    """Zero columns up to a multiple of 4: the GEMM wants 16-byte rows (the matching rows of X W^T are zero-padded too)."""
+    n = a_norm.shape[1]
+    return a_norm if n % 4 == 0 else torch.nn.functional.pad(a_norm, (0, 4 - n % 4)).contiguous()
+
+
+@torch.no_grad()
+def gnn_pool(gnn, feats, a_norm):
+    """mean over nodes of ``GNN(feats)`` -> [d]: per layer ``A_norm (X W^T) + b`` = two GEMMs on the HIP library."""
+    x = feats
+    a_pad = _pad4(a_norm)                                             # [n, n4]
+    for i, conv in enumerate(gnn.convs):
+        xw = _linear(x, conv.lin)                                     # X W^T              [n, out]
+        xw = torch.nn.functional.pad(xw, (0, 0, 0, a_pad.shape[1] - xw.shape[0])).contiguous()
+        x = ops.conv1d(a_pad, xw, conv.bias.contiguous())             # A_norm (X W^T) + b
+        if i != gnn.n_layers - 1:
+            x = torch.relu(x)
+    return x.mean(dim=0)
+
+
+@torch.no_grad()
+def fusion_rows(args, model, tokenizer, dataset, idxs_sim, top_k):
+    """The rows spliced in after position 2 (``H_sim_``): [1, d] for graphpooling, [m, d] for mlp."""
+    wte = model.transformer.wte.weight
+    idxs = [int(v) for v in idxs_sim][:top_k]
+    if args.fusion == "graphpooling":
+        order, edges = star_union_graph(dataset.retrieval_sources, idxs)
+        feats = wte[torch.tensor(order, dtype=torch.long, device=wte.device)]
+        return gnn_pool(model.gnn_fusion, feats, gcn_norm_dense(len(order), edges, wte.device)).view(1, -1)
+    if args.fusion == "mlp":
+        max_len_sim = 512
+        cat = []
+        for n in idxs:
+            cat += list(dataset.retrieval_sources[n])
+        cat = cat[:max_len_sim] + [tokenizer.pad_token_id] * max(0, max_len_sim - len(cat))
+        h = wte[torch.tensor(cat, dtype=torch.long, device=wte.device)]         # [512, d]
+        h = h.contiguous().view(-1, max_len_sim)                                # flat reinterpretation, utils/model.py:156
+        mods = list(model.mlp_fusion.layers)
+        for j, mod in enumerate(mods):
+            if isinstance(mod, nn.Linear):
+                h = _linear(h, mod)
+            else:
+                h = torch.relu(h)
+        return h.contiguous().view(args.m, -1)                                  # :158 (batch of one)
+    raise ValueError(f"unknown fusion {args.fusion!r} (mlp | graphpooling)")
+
+
+@torch.no_grad()
+def fused_next_token(model, indexed_tokens, sim_rows):
+    """argmax of the last position's logits of ``model(inputs_embeds=cat(H[:, :2], H_sim, H[:, 2:]))``
+    (``utils/model.py:160-164,214-223``; ``Evaluation_generator.py:160``)."""
+    wte = model.transformer.wte.weight
+    H = wte[torch.tensor(indexed_tokens, dtype=torch.long, device=wte.device)]
+    H_aug = torch.cat([H[:2], sim_rows, H[2:]], dim=0).unsqueeze(0).contiguous()
+    hidden = model.transformer.encode(None, H_aug, want_hidden=True)["hidden"]
+    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), wte)
+    return int(torch.argmax(logits[0]).item())
+
+
+@torch.no_grad()
+def greedy_decode_rag(args, model, tokenizer, dataset, indexed_tokens, index, mode, max_len, n_spl):
+    """Decode loop of ``get_eval_metrics_generator`` (:141-167) for one query."""
+    sim_rows = fusion_rows(args, model, tokenizer, dataset, index, args.topK)    # constant over the steps
+    toks = list(indexed_tokens)
+    eos = tokenizer.encode("<|endoftext|>")
+    gen_len = 0
+    while True:
+        nxt = fused_next_token(model, toks, sim_rows)
+        toks.append(nxt)
+        gen_len += 1
+        if mode == "val":
+            if gen_len > 10:
+                break
+        elif len(toks) >= max_len - n_spl:
+            break
+        if nxt in eos:
+            break
+    return toks
+
+
+@torch.no_grad()
+def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl):
+    """``greedy_decode_rag`` for MANY queries at once (the reference decodes one query at a time; the queries are
+    independent, so the evaluation is data-parallel over them).  Each step is ONE forward over the still-active queries
+    right-padded to the longest: with causal attention and absolute positions from 0 the padding behind a sequence
+    cannot reach its real positions, and only the hidden row at each query's own last position goes through the lm_head.
+    Token ids, the splice and the bookkeeping stay on the device; one host sync per step (the stop rules)."""
+    wte = model.transformer.wte.weight
+    dev = wte.device
+    n = len(token_lists)
+    if n == 0:
+        return []
+    sims = torch.stack([fusion_rows(args, model, tokenizer, dataset, ix, args.topK) for ix in index_lists])   # [n, r, d]
+    r = sims.shape[1]
+    eos = tokenizer.encode("<|endoftext|>")
+    toks = [list(t) for t in token_lists]
+    cap = max(len(t) for t in toks) + r + 16
+    ids = torch.zeros(n, cap, dtype=torch.long, device=dev)            # augmented layout: [t0 t1 | r fused slots | t2 ...]
+    for i, t in enumerate(toks):
+        tt = torch.tensor(t, dtype=torch.long, device=dev)
+        ids[i, :2] = tt[:2]
+        ids[i, 2 + r:len(t) + r] = tt[2:]
+    lens = torch.tensor([len(t) + r for t in toks], dtype=torch.long, device=dev)
+    active = list(range(n))
+    gen_len = [0] * n
+    while active:
+        a = torch.tensor(active, dtype=torch.long, device=dev)
+        la = lens[a]
+        tmax = int(la.max().item())
+        if tmax + 1 > ids.shape[1]:
+            ids = torch.nn.functional.pad(ids, (0, tmax + 64 - ids.shape[1]))
+        H_aug = wte[ids[a, :tmax]]                                     # [na, tmax, d]
+        H_aug[:, 2:2 + r] = sims[a]
+        hidden = model.transformer.encode(None, H_aug.contiguous(), want_hidden=True)["hidden"]
+        last = hidden[torch.arange(len(active), device=dev), la - 1]
+        nxt = torch.argmax(ops.lm_logits(last.contiguous(), wte), dim=1)
+        ids[a, la] = nxt
+        lens[a] = la + 1
+        still = []
+        for i, v in zip(active, nxt.tolist()):
+            toks[i].append(v)
+            gen_len[i] += 1
+            stop = (gen_len[i] > 10) if mode == "val" else (len(toks[i]) >= max_len - n_spl)
+            if not stop and v not in eos:
+                still.append(i)
+        active = still
+    return toks
+
+
+# ------------------------------------------------------------------------------------------------ dataset / eval
+class TextIndexScoreDataset:
+    """``dataloader/generator.py:12-80``: texts, retrieved index / score rows and the retrieval sources (train pool)."""
+
+    def __init__(self, tokenizer, args, text_file_path, index_file_path, score_file_path, block_size=512):
+        for p in (text_file_path, index_file_path, score_file_path):
+            assert os.path.isfile(p), p
+        train_data = read_nonblank_lines(args.train_data_file)
+        text_lines = read_nonblank_lines(text_file_path)
+        self.egolist, self.egoId = [], {}
+        for i, line in enumerate(text_lines):
+            ego = int(line.split('<|history|>')[1].split(' ')[1])
+            self.egoId[ego] = i
+            self.egolist.append(ego)
+        self.index = [list(map(int, line.split())) for line in read_nonblank_lines(index_file_path)]
+        self.score = [list(map(float, line.split())) for line in read_nonblank_lines(score_file_path)]
+        self.text = tokenizer(text_lines, add_special_tokens=True, max_length=block_size)["input_ids"]
+        self.retrieval_sources = tokenizer(train_data, add_special_tokens=True, max_length=block_size)["input_ids"]
+
+    def __len__(self):
+        return len(self.text)
+
+    def __getitem__(self, i):
+        return (torch.tensor(self.text[i], dtype=torch.long), torch.tensor(self.index[i], dtype=torch.long),
+                torch.tensor(self.score[i], dtype=torch.float), torch.tensor(self.egolist[i], dtype=torch.long))
+
+
+def load_and_cache_examples(args, tokenizer, evaluate=False, test=False):
+    """``dataloader/generator.py:83-101``."""
+    if evaluate:
+        paths = (args.eval_data_file, args.val_index_file, args.val_score_file)
+    elif test:
+        paths = (args.test_data_file, args.test_index_file, args.test_score_file)
+    else:
+        paths = (args.train_data_file, args.train_index_file, args.train_score_file)
+    return TextIndexScoreDataset(tokenizer, args, *paths, block_size=args.block_size)
+
+
+def get_eval_metrics_generator(args, epoch, model, tokenizer, step, mode="val", is_rag=False, is_best=False):
+    """Drop-in for ``utils/Evaluation_generator.get_eval_metrics_generator`` (:49-265): R@5 / NDCG@5 / Jaccard of the
+    greedy link predictions, ``eval_results.json`` and (``is_best``) the results CSV under ``rag_results/...``."""
+    spl_tokens = tokenizer.additional_special_tokens + [tokenizer.bos_token, tokenizer.eos_token, tokenizer.pad_token]
+    if mode == 'val':
+        files = (args.eval_data_file, args.eval_data_gt_file, args.val_score_file, args.val_index_file)
+    else:
+        files = (args.test_data_file, args.test_data_gt_file, args.test_score_file, args.test_index_file)
+    data, data_gt, data_score, data_index = (read_nonblank_lines(f) for f in files)
+    assert len(data) == len(data_gt)
+    with open(os.path.join('./vocabs', args.dataset, str(args.timestamp), 'vocab.json')) as f:
+        vocab = json.load(f)
+    indicator, root_path = ('do_train', 'rag_results/train_mode') if args.do_train else ('do_val', 'rag_results/val_mode')
+    out_dir = os.path.join(root_path, args.dataset, str(args.timestamp), args.run_name,
+                           "results_seed" if args.run_seed else "results", mode + '_score')
+    os.makedirs(out_dir, exist_ok=True)
+
+    Eval = Evaluation()
+    model.eval()
+    MAX_LEN = model.config.n_ctx
+    topk = [5]
+    metric_terms = ['R', 'NDCG', 'jaccard']
+    top_k_scores = {metric: len(topk) * [0] for metric in metric_terms}
+    generated_dict = {}
+    train_dataset = load_and_cache_examples(args, tokenizer, evaluate=False)
+    num_user_test = 0
+    jobs = []                                           # (i, input_text, user_id, target_list, ids, index, num_user_test)
+    for i, (input_text, text_gt, index, _score) in enumerate(zip(data, data_gt, data_index, data_score)):
+        index = list(map(int, index.split()))
+        generated_dict[i] = {}
+        user_id = input_text.split()[2]
+        target_list = [t for t in text_gt.split()[1:-2] if t != user_id and t in vocab]
+        if len(target_list) == 0:
+            print('text_gt: ', text_gt)
+            continue
+        indexed_tokens = tokenizer.encode(input_text)
+        num_user_test += 1
+        if len(indexed_tokens) > MAX_LEN:
+            print('len_input: ', len(indexed_tokens))
+            indexed_tokens = indexed_tokens[-1000:]
+        jobs.append((i, input_text, user_id, target_list, indexed_tokens, index, num_user_test))
+    bs = max(1, int(getattr(args, "per_gpu_eval_batch_size", 32) or 32))
+    for b0 in range(0, len(jobs), bs):                  # the queries are independent: decode a batch of them per step
+        chunk = jobs[b0:b0 + bs]
+        if is_rag:
+            outs = greedy_decode_rag_batch(args, model, tokenizer, train_dataset, [j[4] for j in chunk],
+                                           [j[5] for j in chunk], mode, MAX_LEN, len(spl_tokens))
+        else:
+            from .evaluation import greedy_decode
+            outs = [greedy_decode(model, tokenizer, j[4], mode, MAX_LEN, len(spl_tokens), next(model.parameters()).device)
+                    for j in chunk]
+        for (i, input_text, user_id, target_list, indexed_tokens, _ix, nut), out_ids in zip(chunk, outs):
+            predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
+            predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
+            for topi, k in enumerate(topk):
+                try:
+                    top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
+                except ZeroDivisionError:
+                    pass
+                top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
+                top_k_scores['R'][topi] += Eval.recall_k(predicted, target_list, k)
+            generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
+                                      'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
+                                      'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
+                                      'num_user_test': str(nut)})
+    for metric in metric_terms:
+        for topi, _k in enumerate(topk):
+            top_k_scores[metric][topi] = round(top_k_scores[metric][topi] / max(num_user_test, 1), 4)
+    result_save_file = os.path.join(out_dir, mode + '_results_epoch.csv')
+    if is_best:
+        with open(result_save_file, 'w') as f:
+            f.write('epoch,' + ''.join(p + ',' for p in args.para_names))
+            f.write(''.join(f'R@{k},' for k in topk) + ''.join(f'NDCG@{k},' for k in topk) +
+                    ''.join(f'jaccard@{k},' for k in topk) + '\n')
+            f.write(str(epoch) + ',' + ''.join(str(v) + ',' for v in args.para_values))
+            for metric in metric_terms:
+                f.write(''.join(str(top_k_scores[metric][j]) + ',' for j in range(len(topk))))
+            f.write('\n')
+    with open(out_dir + '/eval_results.json', 'wt') as f:
+        json.dump(generated_dict, f, indent=4)
+    if is_best:
+        import pandas as pd
+        save_folder = os.path.join(indicator, mode + ('_metrics_seed_gen' if args.run_seed else '_metrics_ft_gen'))
+        os.makedirs(save_folder, exist_ok=True)
+        result_save_test = os.path.join(save_folder, args.dataset + '_SimpleDyG.csv')
+        test_results = pd.read_csv(result_save_file)
+        if os.path.exists(result_save_test):
+            test_results.to_csv(result_save_test, mode='a', header=False, index=False)
+        else:
+            test_results.to_csv(result_save_test, index=False)
+    return top_k_scores

@@ -357,6 +357,25 @@ class GPT2LMHeadModelRAG(_LMHeadBase):
     away (``train_retriever.py:419-420``; 31-48 % of the reference forward).
     """
 
+    def __init__(self, config):
+        super().__init__(config)
+        self.mlp_fusion = None                       # models/modeling_rag.py:582-584: created on demand, so that a
+        self.gnn_fusion = None                       # generator checkpoint's ``{mlp,gnn}_fusion.*`` keys load
+
+    def get_mlp(self, input_size, output_size, n_layers=1):
+        """``modeling_rag.py:589-593``."""
+        if self.mlp_fusion is None:
+            from .generator import MLP_custom
+            self.mlp_fusion = MLP_custom(input_size, output_size, n_layers)
+        return self.mlp_fusion
+
+    def get_gnn(self, nfeat, nhid, nclass, n_layers, dropout):
+        """``modeling_rag.py:595-600``."""
+        if self.gnn_fusion is None:
+            from .generator import GNN
+            self.gnn_fusion = GNN(nfeat, nhid, nclass, n_layers, dropout)
+        return self.gnn_fusion
+
     def forward(self, input_ids=None, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
                 head_mask=None, inputs_embeds=None, labels=None):
         return self._lm(input_ids, labels, inputs_embeds, past=past, attention_mask=attention_mask,

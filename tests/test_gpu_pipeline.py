@@ -267,3 +267,105 @@ def test_simpledyg_greedy_eval_matches_oracle_decode(dev, tmp_path, monkeypatch)
     assert (out_dir / "test_results_epoch.csv").exists() and (out_dir / "eval_results_0.json").exists()
     hdr = open(out_dir / "test_results_epoch.csv").readline()
     assert hdr.startswith("dataset,method,time,nlayer,nhead,nemb,bz,lr,seed,NDCG@5,jaccard@5")
+
+
+def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch):
+    """graph-pooling and MLP fusion rows within 1e-5 of the oracle, greedy RAG decode ids equal to the
+    oracle's CPU decode, and the main_generator CLI evaluates a checkpoint and writes the reference's files."""
+    import types
+    import main_generator
+    from oracle import generator_ref, gpt2_ref, jaccard_ref
+    from rag4dyg_amd import generator
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    base = _write_dataset(str(tmp_path), n_train=40, n_val=12, n_test=12, seed=7)
+    monkeypatch.chdir(tmp_path)
+    tok, _ = build_tokenizer("toy", 4, with_mask=False)
+    L, H, d, P, m_rows, topk = 2, 2, 64, 160, 3, 5
+    sd = gpt2_ref.make_state_dict(L, d, len(tok), n_positions=P, seed=11, random_affine=True)
+    cfg = GPT2Config(vocab_size=len(tok), n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H)
+    model = GPT2LMHeadModelRAG(cfg)
+    model.load_state_dict(sd, strict=False); model.tie_weights()
+    g = torch.Generator().manual_seed(5)
+    gnn = model.get_gnn(d, d // 2, d, 1, 0.2)
+    mlp = model.get_mlp(512, m_rows, 2)
+    with torch.no_grad():
+        gnn.convs[0].lin.weight.copy_(torch.randn(d, d, generator=g) * 0.2)
+        gnn.convs[0].bias.copy_(torch.randn(d, generator=g) * 0.1)
+        for mod in mlp.layers:
+            if hasattr(mod, "weight"):
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * 0.05)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    convs = [(gnn.convs[0].lin.weight.detach().clone(), gnn.convs[0].bias.detach().clone())]
+    layers = [(mod.weight.detach().clone(), mod.bias.detach().clone()) for mod in mlp.layers if hasattr(mod, "weight")]
+    ck = tmp_path / "gen" / "checkpoint-0"
+    ck.mkdir(parents=True)
+    model.mlp_fusion = None                             # a graph-pooling generator checkpoint holds gnn_fusion.* only
+    model.save_pretrained(str(ck))
+    model.mlp_fusion = mlp
+    model = model.to(dev).eval()
+    train_lines = jaccard_ref.read_lines(os.path.join(base, "train.link_prediction"))
+    sources = tok(train_lines, add_special_tokens=True, max_length=128)["input_ids"]
+    ds = types.SimpleNamespace(retrieval_sources=sources)
+    lines = jaccard_ref.read_lines(os.path.join(base, "val.link_prediction"))
+    rng = np.random.default_rng(1)
+    same = total = 0
+    for fusion in ("graphpooling", "mlp"):
+        args = types.SimpleNamespace(fusion=fusion, m=m_rows, topK=topk)
+        for ln in lines[:4]:
+            ids = tok.encode(ln)
+            idx = rng.permutation(len(sources))[:9].tolist()
+            if fusion == "graphpooling":
+                ref_aug = generator_ref.fusion_graphpooling_embeds(sd, sources, ids, idx, topk, convs)
+                fn = lambda t, idx=idx: generator_ref.fusion_graphpooling_embeds(sd, sources, t, idx, topk, convs)
+                nrows = 1
+            else:
+                ref_aug = generator_ref.fusion_mlp_embeds(sd, sources, ids, idx, topk, m_rows, layers, tok.pad_token_id)
+                fn = lambda t, idx=idx: generator_ref.fusion_mlp_embeds(sd, sources, t, idx, topk, m_rows, layers, tok.pad_token_id)
+                nrows = m_rows
+            rows = generator.fusion_rows(args, model, tok, ds, idx, topk).cpu()
+            assert rows.shape == (nrows, d)
+            assert rel_err(rows.numpy(), ref_aug[0, 2:2 + nrows].numpy()) < 1e-5
+            got = generator.greedy_decode_rag(args, model, tok, ds, ids, idx, "val", P, 12)
+            ref = generator_ref.greedy_decode_rag(sd, H, fn, ids, tok.eos_token_id, "val", P, 12)
+            same += got == ref; total += 1
+            assert got[:len(ids)] == ids and len(got) > len(ids)
+    assert same >= total - 1                            # argmax can only differ at sub-1e-6 logit ties
+    # data-parallel decode of many queries (right-padded batch) == one query at a time, val and test stop rules
+    args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=topk)
+    qs = [tok.encode(ln) for ln in lines[:9]]
+    ixs = [rng.permutation(len(sources))[:9].tolist() for _ in qs]
+    for mode in ("val", "test"):
+        one = [generator.greedy_decode_rag(args, model, tok, ds, q, ix, mode, P, 12) for q, ix in zip(qs, ixs)]
+        many = generator.greedy_decode_rag_batch(args, model, tok, ds, qs, ixs, mode, P, 12)
+        assert sum(a == b for a, b in zip(one, many)) >= len(qs) - 1
+        if mode == "test":
+            assert all(len(t) <= P - 12 for t in many) and any(len(t) == P - 12 or t[-1] == tok.eos_token_id for t in many)
+    # CLI: index / score files as main_retriever writes them (one row of pool indices / scores per query)
+    n_q = len(jaccard_ref.read_lines(os.path.join(base, "test.link_prediction")))
+    os.makedirs("resources/retrieval_result/toy", exist_ok=True)
+    with open("resources/retrieval_result/toy/test_index.gen", "w") as fi, open("resources/retrieval_result/toy/test_score.gen", "w") as fs:
+        for _ in range(n_q):
+            perm = rng.permutation(len(sources))
+            fi.write(" ".join(str(int(v)) for v in perm) + "\n")
+            fs.write(" ".join(f"{v:.4f}" for v in rng.random(len(sources))) + "\n")
+    os.makedirs("resources/train_generator/toy/4/train_gt_topk", exist_ok=True)      # read by TextIndexScoreDataset
+    with open("resources/train_generator/toy/4/train_gt_topk/train_index.gen", "w") as fi, \
+            open("resources/train_generator/toy/4/train_gt_topk/train_score.gen", "w") as fs:
+        for _ in range(len(sources)):
+            fi.write(" ".join(str(int(v)) for v in rng.permutation(len(sources))[:10]) + "\n")
+            fs.write(" ".join(f"{v:.4f}" for v in rng.random(10)) + "\n")
+    argv = (f"--dataset toy --timestamp 4 --output_dir {tmp_path}/gen --model_type gpt2 --fusion graphpooling --topK {topk} "
+            f"--train_index_file resources/train_generator/toy/4/train_gt_topk/train_index.gen "
+            f"--train_score_file resources/train_generator/toy/4/train_gt_topk/train_score.gen "
+            f"--gnn_layers 1 --m 1 --train_data_file {base}/train.link_prediction --do_eval --eval_all_checkpoints "
+            f"--eval_data_file {base}/val.link_prediction --eval_data_gt_file {base}/val_gt.link_prediction "
+            f"--test_data_file {base}/test.link_prediction --test_data_gt_file {base}/test_gt.link_prediction "
+            f"--test_index_file resources/retrieval_result/toy/test_index.gen "
+            f"--test_score_file resources/retrieval_result/toy/test_score.gen "
+            f"--block_size 128 --n_layer {L} --n_head {H} --n_embed {d} --config_name {ck}").split()
+    res = main_generator.main(argv)
+    r = next(iter(res.values()))
+    assert all(0.0 <= r[k][0] <= 1.0 for k in ("R", "NDCG", "jaccard"))
+    outs = list((tmp_path / "rag_results" / "val_mode" / "toy" / "4").glob("*/results/test_score/eval_results.json"))
+    assert len(outs) == 1

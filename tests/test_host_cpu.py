@@ -293,6 +293,57 @@ def test_small_integer_division_scheme_is_correctly_rounded():
             assert q1 == a / b, (a, b)
 
 
+def test_generator_fused_graph_matches_networkx_and_gcn_norm():
+    """the union-of-stars graph of ``fusion_graphpooling`` (``utils/model.py:181-189``) -- node order and
+    edges of the oracle's and the product's construction equal networkx's own; the dense GCN normalisation equals
+    ``D^-1/2 (A+I) D^-1/2`` computed from the networkx adjacency."""
+    import networkx as nx
+    from oracle import generator_ref
+    from rag4dyg_amd import generator
+    rng = np.random.default_rng(3)
+    sources = [[60, 61, int(rng.integers(0, 40))] + rng.integers(0, 40, rng.integers(1, 12)).tolist() + [62] for _ in range(30)]
+    for trial in range(20):
+        idxs = rng.integers(0, 30, 7).tolist()
+        G = nx.Graph()
+        for n in idxs:
+            seq = [int(e) for e in sources[n]]
+            G.add_edges_from([(int(seq[2]), e) for e in seq])
+        nodes = list(G.nodes)
+        pos = {v: i for i, v in enumerate(nodes)}
+        edges = {(min(pos[a], pos[b]), max(pos[a], pos[b])) for a, b in G.edges}
+        for impl in (generator_ref.star_union_graph, generator.star_union_graph):
+            order, e = impl(sources, idxs)
+            assert order == nodes and e == edges
+        A = nx.to_numpy_array(G, nodelist=nodes, weight=None)
+        np.fill_diagonal(A, 0.0)
+        A += np.eye(len(nodes))
+        dinv = A.sum(1) ** -0.5
+        ref = (dinv[:, None] * A * dinv[None, :]).astype(np.float32)
+        assert np.allclose(generator_ref.gcn_norm_dense(len(nodes), edges).numpy(), ref, rtol=1e-6, atol=1e-7)
+        assert np.allclose(generator.gcn_norm_dense(len(nodes), edges, "cpu").numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_generator_fusion_modules_use_reference_state_dict_keys():
+    """``gnn_fusion`` / ``mlp_fusion`` keys as a reference generator checkpoint holds them (PyG >= 2 ``lin.weight`` and the
+    PyG 1.7 ``weight`` [in,out] form both load)."""
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=50, n_positions=32, n_ctx=32, n_embd=64, n_layer=1, n_head=2))
+    assert not any(k.startswith(("gnn_fusion", "mlp_fusion")) for k in m.state_dict())
+    m.get_gnn(64, 32, 64, 1, 0.2)
+    m.get_mlp(512, 3, 2)
+    keys = set(m.state_dict())
+    assert {"gnn_fusion.convs.0.lin.weight", "gnn_fusion.convs.0.bias", "mlp_fusion.layers.0.weight",
+            "mlp_fusion.layers.0.bias", "mlp_fusion.layers.2.weight", "mlp_fusion.layers.2.bias"} <= keys
+    assert m.state_dict()["gnn_fusion.convs.0.lin.weight"].shape == (64, 64)
+    assert m.state_dict()["mlp_fusion.layers.0.weight"].shape == (256, 512) and m.state_dict()["mlp_fusion.layers.2.weight"].shape == (3, 256)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    w = sd.pop("gnn_fusion.convs.0.lin.weight")
+    sd["gnn_fusion.convs.0.weight"] = w.t().contiguous()                 # PyG 1.7 layout
+    m2 = GPT2LMHeadModelRAG(m.config); m2.get_gnn(64, 32, 64, 1, 0.2); m2.get_mlp(512, 3, 2)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.state_dict()["gnn_fusion.convs.0.lin.weight"], w)
+
+
 def test_evaluation_metrics_natural_log_ndcg():
     import math
     from rag4dyg_amd.evaluation import Evaluation

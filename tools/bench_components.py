@@ -19,6 +19,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from rag4dyg_amd import _lib, ops, synth                                   # noqa: E402
+from bench import host_cores                                                # noqa: E402
 
 PEAK = 8000.0
 dev = torch.device("cuda:0")
@@ -117,6 +118,67 @@ def pool():
              seqs_per_s=round(12500 / el, 1))
 
 
+def generator():
+    """RAG generator inference (graph-pooling fusion of top-7 retrieved sequences + greedy decode, val
+    mode = 11 tokens per query, batch 1 like the reference) on UCI_13-shaped synthetic data, model L6 H8 d768
+    (scripts/train_generator/train_rag_graphpooling_UCI_seed.sh), next to the oracle on the host cores."""
+    import types
+    from oracle import generator_ref, gpt2_ref
+    from rag4dyg_amd import generator as gen
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    shape = synth.SHAPES["UCI_13"]
+    L, H, d, topk = 6, 8, 768, 7
+    V = shape.vocab
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=4, random_affine=True)
+    model = GPT2LMHeadModelRAG(GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H))
+    model.load_state_dict(sd, strict=False); model.tie_weights()
+    gnn = model.get_gnn(d, d // 2, d, 1, 0.2)
+    convs = [(gnn.convs[0].lin.weight.detach().clone(), gnn.convs[0].bias.detach().clone())]
+    model = model.to(dev).eval()
+    pool_seqs = [s.tolist() for s in synth.sequences(shape, 512, "pool", seed=1)]
+    queries = [s.tolist() for s in synth.sequences(shape, 256, "query", seed=2)]
+    rng = np.random.default_rng(0)
+    idxs = [rng.permutation(512)[:topk].tolist() for _ in queries]
+    ds = types.SimpleNamespace(retrieval_sources=pool_seqs)
+    args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=topk)
+    tok = types.SimpleNamespace(encode=lambda s: [shape.v0], pad_token_id=shape.pad_id)     # <|endoftext|> = V0
+    eos = tok.encode("")[0]
+
+    def run_gpu(qs):
+        n = 0
+        for q, ix in qs:
+            out = gen.greedy_decode_rag(args, model, tok, ds, q, ix, "val", 1024, 12)
+            n += len(out) - len(q)
+        torch.cuda.synchronize()
+        return n
+    run_gpu(list(zip(queries[:4], idxs[:4])))
+    t0 = time.perf_counter()
+    ntok1 = run_gpu(list(zip(queries[:16], idxs[:16])))
+    el1 = time.perf_counter() - t0
+    gen.greedy_decode_rag_batch(args, model, tok, ds, queries[:8], idxs[:8], "val", 1024, 12)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ntok = 0
+    for b0 in range(0, len(queries), 32):                               # --per_gpu_eval_batch_size 32
+        outs = gen.greedy_decode_rag_batch(args, model, tok, ds, queries[b0:b0 + 32], idxs[b0:b0 + 32], "val", 1024, 12)
+        ntok += sum(len(o) - len(q) for o, q in zip(outs, queries[b0:b0 + 32]))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ncpu = 0
+    for q, ix in list(zip(queries, idxs))[:3]:
+        fn = lambda t, ix=ix: generator_ref.fusion_graphpooling_embeds(sd, pool_seqs, t, ix, topk, convs)
+        out = generator_ref.greedy_decode_rag(sd, H, fn, q, eos, "val", 1024, 12)
+        ncpu += len(out) - len(q)
+    elc = time.perf_counter() - t0
+    emit(component="generator_decode", shape="UCI_13", model="L6 H8 d768", fusion="graphpooling", topK=topk,
+         queries=len(queries), mean_query_len=round(float(np.mean([len(q) for q in queries])), 1), tokens=ntok,
+         tokens_per_s=round(ntok / el, 1), queries_per_s=round(len(queries) / el, 2), batch=32,
+         tokens_per_s_batch1=round(ntok1 / el1, 1),
+         cpu_baseline={"kind": "port", "cores": host_cores(), "tokens_per_s": round(ncpu / elc, 2),
+                       "sample": "3 queries, oracle torch-CPU fp32 (fusion + full forward per token, as the reference)"})
+
+
 if __name__ == "__main__":
-    for part in (sys.argv[1:] or ["scan", "jaccard", "pool"]):
-        {"scan": scan, "jaccard": jaccard, "pool": pool}[part]()
+    for part in (sys.argv[1:] or ["scan", "jaccard", "pool", "generator"]):
+        {"scan": scan, "jaccard": jaccard, "pool": pool, "generator": generator}[part]()
