@@ -107,6 +107,27 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
                                float* out_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
 
+/*
+ * Incremental decode with a key/value cache -- the model's `past` mechanism (`layer_past` concatenation,
+ * modeling_gpt2.py:177-197; `past` / `presents`, :400-509), which the reference's greedy loops never use
+ * (utils/Evaluation_generator.py:153-167 and Evaluation_SimpleDyG.py:126-134 re-run the FULL forward per token).
+ * One call = one new position for each of B independent sequences:
+ *   ids_d            device int64 [B] new token ids, or NULL when inputs_embeds_d is given
+ *   inputs_embeds_d  device f32 [B,d] or NULL
+ *   pos_d            device int32 [B]: position of the new token = number of positions already cached for that
+ *                    sequence (position embedding wpe[pos]; must be < t_cap and < n_positions, else the row is NaN)
+ *   kv_cache_d       device f32 [n_layer, B, t_cap, 2*d]: per position the K row then the V row of every head.
+ *                    Rows [0, pos) of each sequence must hold its history (fill them from r4d_gpt2_encode_f32's
+ *                    out_qkv_d: columns d..3d of c_attn); row pos is WRITTEN by this call.
+ *   out_hidden_d     device f32 [B,d]: ln_f output of the new position (feed r4d_lm_logits_f32)
+ * Same values as the last row of a full forward over the extended sequence, up to fp32 summation order.
+ */
+size_t r4d_gpt2_decode_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B);
+int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                             const float* inputs_embeds_d, const int32_t* pos_d, float* kv_cache_d, int32_t B,
+                             int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
+                             void* stream);
+
 /* lm_logits = hidden @ wte^T  (tied lm_head, modeling_gpt2.py:585; modeling_rag.py:675).
  * hidden_d [M,d], wte_d [V,d] -> logits_d [M,V]. */
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d,

@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
     PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32,
-    PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX,
+    PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
@@ -82,6 +82,13 @@ struct RowGroups {
 int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
                                   const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s);
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
+// decode step (one new position per sequence): x = (ids ? wte[id] : emb) + wpe[pos], y = LayerNorm(x)
+int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32_t* pos, const float* wte,
+                               const float* wpe, int vocab, int n_positions, int t_cap, int B, int d, const float* w,
+                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s);
+// one query per (sequence, head) against the cached keys/values; writes the new K/V row into the cache first
+int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t* pos, int B, int t_cap, int H, int d,
+                            float* out, hipStream_t s);
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
 int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,

@@ -278,6 +278,50 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
                        workspace_bytes, (hipStream_t)stream);
 }
 
+size_t r4d_gpt2_decode_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B) {
+    if (!cfg || B <= 0) return 0;
+    return carve(nullptr, (size_t)B, 0, 0, cfg->n_embd).bytes;
+}
+
+int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                             const float* inputs_embeds_d, const int32_t* pos_d, float* kv_cache_d, int32_t B,
+                             int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
+                             void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    R4D_REQUIRE(w && w->wte && w->wpe && w->ln_f_w && w->ln_f_b && w->layers, "gpt2 decode: null weights");
+    R4D_REQUIRE((ids_d != nullptr) != (inputs_embeds_d != nullptr), "gpt2 decode: specify exactly one of ids and inputs_embeds");
+    R4D_REQUIRE(pos_d && kv_cache_d && out_hidden_d, "gpt2 decode: null pointer");
+    R4D_REQUIRE(B >= 1 && t_cap >= 1, "gpt2 decode: B=%d t_cap=%d", B, t_cap);
+    const int d = cfg->n_embd, H = cfg->n_head;
+    Workspace ws = carve(workspace_d, (size_t)B, 0, 0, d);
+    if (!workspace_d || workspace_bytes < ws.bytes) {
+        set_error("gpt2 decode: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
+        return R4D_ERR_WORKSPACE;
+    }
+    const size_t layer_stride = (size_t)B * t_cap * 2 * d;
+    for (int l = 0; l < cfg->n_layer; ++l) {
+        const r4d_gpt2_layer& L = w->layers[l];
+        R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
+                    "gpt2 decode: null weight in layer %d", l);
+        if (l == 0)
+            rc = launch_embed_pos_layernorm(ids_d, inputs_embeds_d, pos_d, w->wte, w->wpe, cfg->vocab, cfg->n_positions,
+                                            t_cap, B, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s);
+        else
+            rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
+        if (rc) return rc;
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s))) return rc;
+        if ((rc = launch_decode_attention(ws.qkv, kv_cache_d + (size_t)l * layer_stride, pos_d, B, t_cap, H, d, ws.att, s)))
+            return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+    }
+    return launch_layernorm(ws.x, w->ln_f_w, w->ln_f_b, B, d, cfg->ln_eps, out_hidden_d, s);
+}
+
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d, float* logits_d,
                       void* stream) {
     R4D_REQUIRE(hidden_d && wte_d && logits_d, "lm_logits: null pointer");

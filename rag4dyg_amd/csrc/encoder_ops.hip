@@ -137,6 +137,143 @@ int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const fl
     return R4D_OK;
 }
 
+// Decode step: one NEW position per sequence.  x[b,:] = (ids ? wte[ids[b]] : emb[b]) + wpe[pos[b]], y = LayerNorm(x).
+// A position outside the cache / the position table poisons the row (NaN) instead of faulting.
+__global__ __launch_bounds__(256) void embed_pos_ln_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
+                                                           const int32_t* __restrict__ pos, const float* __restrict__ wte,
+                                                           const float* __restrict__ wpe, int vocab, int n_positions,
+                                                           int t_cap, int B, int d, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float eps,
+                                                           float* __restrict__ x_out, float* __restrict__ y_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int nv = d >> 6;
+    const int p = pos[row];
+    bool bad = p < 0 || p >= n_positions || p >= t_cap;
+    const float* src;
+    if (ids) {
+        const long long id = ids[row];
+        bad = bad || id < 0 || id >= vocab;
+        src = wte + (bad ? 0 : id) * (long long)d;
+    } else {
+        src = emb + (long long)row * d;
+    }
+    const float* pe = wpe + (long long)(bad ? 0 : p) * d;
+    float v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            const float e = src[lane + 64 * i] + pe[lane + 64 * i];
+            v[i] = bad ? __builtin_nanf("") : e;
+            x_out[(long long)row * d + lane + 64 * i] = v[i];
+        }
+    ln_row(v, nv, d, eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) y_out[(long long)row * d + lane + 64 * i] = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32_t* pos, const float* wte,
+                               const float* wpe, int vocab, int n_positions, int t_cap, int B, int d, const float* w,
+                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s) {
+    R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
+    if (B <= 0) return R4D_OK;
+    ProfScope prof(PK_EMBED_LN, 12.0 * B * d + 12.0 * B, s);
+    hipLaunchKernelGGL(embed_pos_ln_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, ids, emb, pos, wte, wpe, vocab,
+                       n_positions, t_cap, B, d, w, b, eps, x_out, y_out);
+    R4D_CHECK_LAUNCH("embed_pos_layernorm");
+    return R4D_OK;
+}
+
+// Decode attention: ONE query (the new position) per (sequence, head) against that sequence's cached keys / values
+// -- Attention._attn with a one-row query and layer_past (modeling_gpt2.py:140-160,177-197).  HBM-bound: every cached
+// K and V row of the head is read once.  The block first appends the new K / V row to the cache, then
+//   pass 1: wave w scores keys w, w+4, ... (lanes stride the head dim, wave-shuffle reduce), logits / sqrt(hd) to LDS;
+//   block max / sum; pass 2: wave w accumulates exp(s - max) * V over its keys, lanes own the head columns;
+//   the four partial sums are combined through LDS.  No masking needed: only positions <= pos exist.
+constexpr int DEC_MAXC = 4;                            // head_dim <= 256 = 64 lanes x 4
+__global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ qkv_new, float* __restrict__ kv,
+                                                          const int32_t* __restrict__ pos, int t_cap, int H, int d,
+                                                          float* __restrict__ out) {
+    extern __shared__ float lds[];                     // q [hd] | scores [t_cap] | partial out [4][hd] | red [8]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int hd = d / H;
+    float* qs = lds;
+    float* sc = lds + hd;
+    float* po = sc + t_cap;
+    float* red = po + 4 * hd;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = pos[b];
+    if (p < 0 || p >= t_cap) {                         // embed_pos_ln_kernel poisoned this row already
+        for (int c = tid; c < hd; c += 256) out[(long long)b * d + h * hd + c] = __builtin_nanf("");
+        return;
+    }
+    float* kvb = kv + (long long)b * t_cap * 2 * d;    // this sequence: rows of [K (d) | V (d)]
+    const float* nq = qkv_new + (long long)b * 3 * d + h * hd;
+    for (int c = tid; c < hd; c += 256) {
+        qs[c] = nq[c];
+        kvb[(long long)p * 2 * d + h * hd + c] = nq[d + c];
+        kvb[(long long)p * 2 * d + d + h * hd + c] = nq[2 * d + c];
+    }
+    __syncthreads();
+    const int n = p + 1;
+    const float scale = sqrtf((float)hd);
+    for (int t = wid; t < n; t += 4) {
+        const float* kr = kvb + (long long)t * 2 * d + h * hd;
+        float a = 0.f;
+        for (int c = lane; c < hd; c += 64) a += kr[c] * qs[c];
+        a = wave_sum(a);
+        if (lane == 0) sc[t] = a / scale;              // divided like the reference (:143)
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = tid; t < n; t += 256) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int t = tid; t < n; t += 256) {
+        const float e = __expf(sc[t] - m);
+        sc[t] = e;
+        l += e;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wid] = l;
+    __syncthreads();
+    l = (red[4] + red[5]) + (red[6] + red[7]);
+    float acc[DEC_MAXC] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = wid; t < n; t += 4) {
+        const float* vr = kvb + (long long)t * 2 * d + d + h * hd;
+        const float e = sc[t];
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i)
+            if (lane + 64 * i < hd) acc[i] += e * vr[lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < DEC_MAXC; ++i)
+        if (lane + 64 * i < hd) po[wid * hd + lane + 64 * i] = acc[i];
+    __syncthreads();
+    for (int c = tid; c < hd; c += 256)
+        out[(long long)b * d + h * hd + c] = ((po[c] + po[hd + c]) + (po[2 * hd + c] + po[3 * hd + c])) / l;
+}
+
+int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t* pos, int B, int t_cap, int H, int d,
+                            float* out, hipStream_t s) {
+    const int hd = d / H;
+    R4D_REQUIRE(hd * H == d && hd <= 64 * DEC_MAXC, "decode attention: head_dim=%d (max %d)", hd, 64 * DEC_MAXC);
+    R4D_REQUIRE(t_cap >= 1 && t_cap <= 8192, "decode attention: t_cap=%d", t_cap);
+    if (B <= 0) return R4D_OK;
+    // algorithmic bytes: the cached K and V rows of every head (upper bound t_cap/2 on average is unknown here: count
+    // the new row only; callers that profile use the HIP-event time)
+    ProfScope prof(PK_DECODE_ATTN, 16.0 * B * d, s);
+    const size_t lds = ((size_t)hd + t_cap + 4 * hd + 8) * sizeof(float);
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(256), lds, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
+    R4D_CHECK_LAUNCH("decode_attention");
+    return R4D_OK;
+}
+
 // In-place causal softmax of the scaled scores S[z][i][0..i] (z = batch*head), one wavefront per query
 // row.  The reference masks with w*b - 1e4*(1-b) (modeling_gpt2.py:146) and soft-maxes all T keys (:152):
 // masked terms are exp(-1e4 - max) == 0 in fp32 whenever the row max exceeds -9896, so only keys j <= i

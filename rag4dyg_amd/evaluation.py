@@ -1,10 +1,12 @@
 """SimpleDyG greedy link-prediction evaluation, forward passes on the gfx950 kernels.
 
 Mirrors ``utils/Evaluation_SimpleDyG.py``: ``Evaluation`` (natural-log NDCG@k, Jaccard, recall, precision, MAP) and
-``get_eval_metrics`` -- per test sequence a batch-1 greedy decode that re-runs the FULL forward on the growing
-sequence each step (no KV cache, exactly like the reference, :126-134), stops on ``<|endoftext|>`` (val: after 10
-tokens; test: at ``n_ctx - len(spl_tokens)``), then scores the predicted node list against the ground truth.
-Only the last position's logits are needed, so the tied lm_head GEMM runs on one row per step.
+``get_eval_metrics`` -- greedy decode per test sequence, stop on ``<|endoftext|>`` (val: after 10 tokens; test: at
+``n_ctx - len(spl_tokens)``), then the predicted node list is scored against the ground truth.  ``greedy_decode`` is the
+reference's loop verbatim (batch 1, FULL forward on the growing sequence each step, no KV cache, :126-134);
+``greedy_decode_batch`` -- what ``get_eval_metrics`` runs -- decodes ``--per_gpu_eval_batch_size`` sequences together with
+the key/value cache (``r4d_gpt2_decode_step_f32``).  Only the last position's logits are needed, so the tied lm_head
+GEMM runs on one row per sequence and step.
 Reference quirk kept: ``get_eval_metrics`` always reads ``args.eval_data_file`` / ``eval_data_gt_file``, also in
 mode="test" (:57-58).
 """
@@ -77,6 +79,49 @@ def greedy_decode(model, tokenizer, indexed_tokens, mode, max_len, n_spl, device
     return indexed_tokens
 
 
+@torch.no_grad()
+def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, device):
+    """``greedy_decode`` for many sequences at once with the key/value cache (``GPT2Model.prefill`` / ``decode_step``):
+    the prompts are right-padded to the longest and prefilled in one forward, then every token is one cached step over
+    all sequences.  Same ids as the one-at-a-time loop up to fp32 summation order (the reference re-runs the full
+    forward per token, ``Evaluation_SimpleDyG.py:126-134``)."""
+    tr = model.transformer
+    wte = tr.wte.weight
+    n = len(token_lists)
+    if n == 0:
+        return []
+    eos = tokenizer.encode("<|endoftext|>")
+    toks = [list(t) for t in token_lists]
+    tmax = max(len(t) for t in toks)
+    budget = 11 if mode == "val" else max(1, max_len - n_spl - min(len(t) for t in toks))
+    cap = min(tmax + budget + 1, tr.wpe.num_embeddings)
+    ids = torch.zeros(n, tmax, dtype=torch.long, device=device)
+    for i, t in enumerate(toks):
+        ids[i, :len(t)] = torch.tensor(t, dtype=torch.long, device=device)
+    cache = tr.new_kv_cache(n, cap, device)
+    hidden = tr.prefill(cache, input_ids=ids)
+    lens = torch.tensor([len(t) for t in toks], dtype=torch.int32, device=device)
+    last = hidden[torch.arange(n, device=device), (lens - 1).long()]
+    active = [True] * n
+    gen_len = [0] * n
+    while True:
+        nxt = torch.argmax(ops.lm_logits(last.contiguous(), wte), dim=1)
+        for i, v in enumerate(nxt.tolist()):
+            if not active[i]:
+                continue
+            toks[i].append(v)
+            gen_len[i] += 1
+            stop = (gen_len[i] > 10) if mode == "val" else (len(toks[i]) >= max_len - n_spl)
+            if stop or v in eos or len(toks[i]) >= cap:
+                active[i] = False
+        if not any(active):
+            break
+        act = torch.tensor(active, device=device)
+        last = tr.decode_step(cache, torch.where(act, lens, torch.zeros_like(lens)), input_ids=nxt)
+        lens = lens + act.to(torch.int32)
+    return toks
+
+
 def get_eval_metrics(args, model, tokenizer, step, mode="val"):
     """Drop-in for ``utils/Evaluation_SimpleDyG.get_eval_metrics`` (:53-211): NDCG@5 / Jaccard over the file pair,
     results CSV + per-sample JSON under ``<output_dir>/results[_seed_jac]/<mode>_score``."""
@@ -101,6 +146,7 @@ def get_eval_metrics(args, model, tokenizer, step, mode="val"):
     top_k_scores = {metric: len(topk) * [0] for metric in metric_terms}
     generated_dict = {}
     num_user_test = 0
+    jobs = []
     for i, (input_text, text_gt) in enumerate(zip(data, data_gt)):
         generated_dict[i] = {}
         user_id = input_text.split()[2]
@@ -113,20 +159,24 @@ def get_eval_metrics(args, model, tokenizer, step, mode="val"):
         if len(indexed_tokens) > MAX_LEN:
             print('len_input: ', len(indexed_tokens))
             indexed_tokens = indexed_tokens[-1000:]
-        len_input = len(indexed_tokens)
-        out_ids = greedy_decode(model, tokenizer, indexed_tokens, mode, MAX_LEN, len(spl_tokens), device)
-        predicted_list = tokenizer.decode(out_ids).split()[len_input:]
-        predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
-        for topi, k in enumerate(topk):
-            try:
-                top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
-            except ZeroDivisionError:
-                pass
-            top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
-        generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
-                                  'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
-                                  'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
-                                  'num_user_test': str(num_user_test)})
+        jobs.append((i, input_text, user_id, target_list, indexed_tokens, num_user_test))
+    bs = max(1, int(getattr(args, "per_gpu_eval_batch_size", 32) or 32))
+    for b0 in range(0, len(jobs), bs):              # independent sequences: one cached decode step serves a whole batch
+        chunk = jobs[b0:b0 + bs]
+        outs = greedy_decode_batch(model, tokenizer, [j[4] for j in chunk], mode, MAX_LEN, len(spl_tokens), device)
+        for (i, input_text, user_id, target_list, indexed_tokens, nut), out_ids in zip(chunk, outs):
+            predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
+            predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
+            for topi, k in enumerate(topk):
+                try:
+                    top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
+                except ZeroDivisionError:
+                    pass
+                top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
+            generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
+                                      'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
+                                      'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
+                                      'num_user_test': str(nut)})
     for metric in metric_terms:
         for topi, _k in enumerate(topk):
             top_k_scores[metric][topi] = round(top_k_scores[metric][topi] / max(num_user_test, 1), 4)

@@ -158,6 +158,45 @@ def fusion_rows(args, model, tokenizer, dataset, idxs_sim, top_k):
 
 
 @torch.no_grad()
+def fusion_rows_batch(args, model, tokenizer, dataset, index_lists, top_k):
+    """``fusion_rows`` of many queries -> [n, r, d].  One-layer graph pooling (the shipped configuration) collapses
+    algebraically: mean_i (A_norm (X W^T) + b)_i = sum_j c_j (X W^T)_j + b with c_j = (1/n) sum_i A_norm[i,j]
+    = d_j^-1/2 (d_j^-1/2 + sum_{i in N(j)} d_i^-1/2) / n, so the whole batch is ONE gather, ONE projection GEMM over the
+    concatenated nodes and ONE [n_queries, n_nodes] x [n_nodes, d] GEMM with the block-diagonal pooling weights -- no
+    per-query adjacency matrices.  Other configurations fall back to the per-query path."""
+    gnn = getattr(model, "gnn_fusion", None)
+    if not (args.fusion == "graphpooling" and gnn is not None and gnn.n_layers == 1):
+        return torch.stack([fusion_rows(args, model, tokenizer, dataset, ix, top_k) for ix in index_lists])
+    import numpy as np
+    wte = model.transformer.wte.weight
+    nodes_all, spans, weights = [], [], []
+    for ix in index_lists:
+        order, edges = star_union_graph(dataset.retrieval_sources, [int(v) for v in ix][:top_k])
+        n = len(order)
+        e = np.asarray([p for p in edges if p[0] != p[1]], dtype=np.int64).reshape(-1, 2)
+        deg = np.ones(n, dtype=np.float64)
+        np.add.at(deg, e[:, 0], 1.0)
+        np.add.at(deg, e[:, 1], 1.0)
+        dinv = deg ** -0.5
+        acc = dinv.copy()                                              # self loop
+        np.add.at(acc, e[:, 0], dinv[e[:, 1]])
+        np.add.at(acc, e[:, 1], dinv[e[:, 0]])
+        weights.append(dinv * acc / n)
+        spans.append((len(nodes_all), n))
+        nodes_all += order
+    ntot = (len(nodes_all) + 3) // 4 * 4                               # 16-byte GEMM rows
+    C = np.zeros((len(index_lists), ntot), dtype=np.float32)
+    for q, ((o, n), c) in enumerate(zip(spans, weights)):
+        C[q, o:o + n] = c
+    nodes_all += [0] * (ntot - len(nodes_all))                         # padding nodes carry weight 0
+    X = wte[torch.tensor(nodes_all, dtype=torch.long, device=wte.device)]
+    conv = gnn.convs[0]
+    Y = _linear(X, conv.lin)                                           # [ntot, d]
+    out = ops.conv1d(torch.from_numpy(C).to(wte.device), Y.contiguous(), conv.bias.contiguous())
+    return out.unsqueeze(1)
+
+
+@torch.no_grad()
 def fused_next_token(model, indexed_tokens, sim_rows):
     """argmax of the last position's logits of ``model(inputs_embeds=cat(H[:, :2], H_sim, H[:, 2:]))``
     (``utils/model.py:160-164,214-223``; ``Evaluation_generator.py:160``)."""
@@ -192,50 +231,59 @@ def greedy_decode_rag(args, model, tokenizer, dataset, indexed_tokens, index, mo
 
 @torch.no_grad()
 def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl):
-    """``greedy_decode_rag`` for MANY queries at once (the reference decodes one query at a time; the queries are
-    independent, so the evaluation is data-parallel over them).  Each step is ONE forward over the still-active queries
-    right-padded to the longest: with causal attention and absolute positions from 0 the padding behind a sequence
-    cannot reach its real positions, and only the hidden row at each query's own last position goes through the lm_head.
-    Token ids, the splice and the bookkeeping stay on the device; one host sync per step (the stop rules)."""
-    wte = model.transformer.wte.weight
+    """``greedy_decode_rag`` for MANY queries at once, with a key/value cache.
+
+    The reference decodes one query at a time and re-runs the full forward for every generated token
+    (``Evaluation_generator.py:141-167``).  The queries are independent and the model is causal, so here
+      * the fused prompts of all queries are right-padded to the longest and PREFILLED in one forward that also fills
+        the K/V cache (padding sits behind a sequence's real positions and can never reach them);
+      * every further token is ONE ``r4d_gpt2_decode_step_f32`` over all queries: one new row per query against its
+        cached keys/values (``modeling_gpt2.py:177-197`` ``layer_past`` semantics), lm_head on those rows only.
+    Same tokens as the one-at-a-time loop up to fp32 summation order.  Finished queries keep their slot (their rows
+    are ignored); one host sync per step for the stop rules."""
+    tr = model.transformer
+    wte = tr.wte.weight
     dev = wte.device
     n = len(token_lists)
     if n == 0:
         return []
-    sims = torch.stack([fusion_rows(args, model, tokenizer, dataset, ix, args.topK) for ix in index_lists])   # [n, r, d]
+    sims = fusion_rows_batch(args, model, tokenizer, dataset, index_lists, args.topK)                       # [n, r, d]
     r = sims.shape[1]
     eos = tokenizer.encode("<|endoftext|>")
     toks = [list(t) for t in token_lists]
-    cap = max(len(t) for t in toks) + r + 16
-    ids = torch.zeros(n, cap, dtype=torch.long, device=dev)            # augmented layout: [t0 t1 | r fused slots | t2 ...]
+    lens0 = [len(t) + r for t in toks]                                 # augmented prompt lengths
+    tmax = max(lens0)
+    budget = 11 if mode == "val" else max(1, max_len - n_spl - min(len(t) for t in toks))
+    cap = min(tmax + budget + 1, tr.wpe.num_embeddings)
+    ids = torch.zeros(n, tmax, dtype=torch.long, device=dev)           # augmented layout: [t0 t1 | r fused slots | t2 ...]
     for i, t in enumerate(toks):
         tt = torch.tensor(t, dtype=torch.long, device=dev)
         ids[i, :2] = tt[:2]
         ids[i, 2 + r:len(t) + r] = tt[2:]
-    lens = torch.tensor([len(t) + r for t in toks], dtype=torch.long, device=dev)
-    active = list(range(n))
+    H_aug = wte[ids]
+    H_aug[:, 2:2 + r] = sims
+    cache = tr.new_kv_cache(n, cap, dev)
+    hidden = tr.prefill(cache, inputs_embeds=H_aug.contiguous())       # [n, tmax, d]
+    lens = torch.tensor(lens0, dtype=torch.int32, device=dev)
+    last = hidden[torch.arange(n, device=dev), (lens - 1).long()]
+    active = [True] * n
     gen_len = [0] * n
-    while active:
-        a = torch.tensor(active, dtype=torch.long, device=dev)
-        la = lens[a]
-        tmax = int(la.max().item())
-        if tmax + 1 > ids.shape[1]:
-            ids = torch.nn.functional.pad(ids, (0, tmax + 64 - ids.shape[1]))
-        H_aug = wte[ids[a, :tmax]]                                     # [na, tmax, d]
-        H_aug[:, 2:2 + r] = sims[a]
-        hidden = model.transformer.encode(None, H_aug.contiguous(), want_hidden=True)["hidden"]
-        last = hidden[torch.arange(len(active), device=dev), la - 1]
+    while True:
         nxt = torch.argmax(ops.lm_logits(last.contiguous(), wte), dim=1)
-        ids[a, la] = nxt
-        lens[a] = la + 1
-        still = []
-        for i, v in zip(active, nxt.tolist()):
+        for i, v in enumerate(nxt.tolist()):
+            if not active[i]:
+                continue
             toks[i].append(v)
             gen_len[i] += 1
             stop = (gen_len[i] > 10) if mode == "val" else (len(toks[i]) >= max_len - n_spl)
-            if not stop and v not in eos:
-                still.append(i)
-        active = still
+            if stop or v in eos or len(toks[i]) + r >= cap:
+                active[i] = False
+        if not any(active):
+            break
+        act = torch.tensor(active, device=dev)
+        pos = torch.where(act, lens, torch.zeros_like(lens))           # finished slots rewrite their row 0: harmless
+        last = tr.decode_step(cache, pos, input_ids=nxt)
+        lens = lens + act.to(torch.int32)
     return toks
 
 

@@ -253,6 +253,52 @@ class GPT2Model(_PreTrained):
         out.update(hidden=hidden, meanpool=pool, layers=layers, qkv=qkv)
         return out
 
+    # ------------------------------------------------------------------ incremental decode (key/value cache)
+    def new_kv_cache(self, B, t_cap, device):
+        """[n_layer, B, t_cap, 2d] cache for ``decode_step`` (K row then V row per position)."""
+        return torch.empty(self.config.n_layer, B, t_cap, 2 * self.config.n_embd, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def prefill(self, kv_cache, input_ids=None, inputs_embeds=None):
+        """Full forward over a right-padded batch [B,T] that also fills rows [0,T) of ``kv_cache`` (the K / V columns of
+        every layer's c_attn output -- the model's ``presents``, ``modeling_gpt2.py:187``).  Returns hidden [B,T,d]."""
+        r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_qkv=True)
+        d = self.config.n_embd
+        T = r["qkv"].shape[2]
+        if T > kv_cache.shape[2] or r["qkv"].shape[1] != kv_cache.shape[1]:
+            raise ValueError(f"prefill: batch {tuple(r['qkv'].shape[1:3])} does not fit the cache {tuple(kv_cache.shape[1:3])}")
+        kv_cache[:, :, :T] = r["qkv"][..., d:]
+        return r["hidden"]
+
+    @torch.no_grad()
+    def decode_step(self, kv_cache, pos, input_ids=None, inputs_embeds=None):
+        """One new position per sequence (``r4d_gpt2_decode_step_f32``): ``pos`` int32 [B] = positions already cached;
+        row ``pos`` of the cache is written.  Returns the ln_f hidden row of the new position, [B, d]."""
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("decode_step: specify exactly one of input_ids and inputs_embeds")
+        L, B, t_cap, d2 = kv_cache.shape
+        d = self.config.n_embd
+        dev = kv_cache.device
+        if not kv_cache.is_cuda or kv_cache.dtype != torch.float32 or not kv_cache.is_contiguous() or d2 != 2 * d \
+                or L != self.config.n_layer:
+            raise _lib.R4DError("decode_step: kv_cache must be a contiguous fp32 GPU tensor [n_layer, B, t_cap, 2d]")
+        pos = pos.to(device=dev, dtype=torch.int32).contiguous()
+        if input_ids is not None:
+            input_ids = input_ids.to(device=dev, dtype=torch.int64).contiguous().view(B)
+        else:
+            inputs_embeds = inputs_embeds.to(device=dev, dtype=torch.float32).contiguous().view(B, d)
+        lib = _lib.load()
+        c, w, _keep = self._c_structs()
+        ws = ops.workspace(lib.r4d_gpt2_decode_workspace_bytes(ctypes.byref(c), B), dev, "gpt2_decode")
+        hidden = torch.empty(B, d, dtype=torch.float32, device=dev)
+        _lib.check(lib.r4d_gpt2_decode_step_f32(ctypes.byref(c), ctypes.byref(w),
+                                                input_ids.data_ptr() if input_ids is not None else None,
+                                                inputs_embeds.data_ptr() if inputs_embeds is not None else None,
+                                                pos.data_ptr(), kv_cache.data_ptr(), B, t_cap, hidden.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "gpt2_decode_step")
+        return hidden
+
     @torch.no_grad()
     def encode_groups_meanpool(self, batches):
         """Mean-pooled embeddings of several right-padded batches in one fused launch sequence

@@ -138,6 +138,46 @@ def test_attention_oracle_shapes(dev, B, T, H, hd, attn_mode):
     assert rel_err(out.numpy(), ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("L,H,d", [(2, 2, 64), (2, 8, 768), (1, 2, 512)])
+def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
+    """r4d_gpt2_decode_step_f32: ragged batch, prefill + 5 cached steps == the last row of a full forward over each
+    extended sequence (oracle AND the library's own full forward); an out-of-cache position poisons its row only."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    V, P, B, cap = 90, 128, 5, 64
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=L * 100 + H, random_affine=True)
+    m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    m = m.to(dev).eval()
+    tr = m.transformer
+    g = torch.Generator().manual_seed(d + H)
+    lens = [7, 33, 1, 20, 12]
+    seqs = [torch.randint(0, V, (n,), generator=g).tolist() for n in lens]
+    Tmax = max(lens)
+    ids = torch.zeros(B, Tmax, dtype=torch.int64)
+    for i, s_ in enumerate(seqs):
+        ids[i, :len(s_)] = torch.tensor(s_)
+    cache = tr.new_kv_cache(B, cap, dev)
+    tr.prefill(cache, input_ids=ids.to(dev))
+    for step in range(5):
+        new = torch.randint(0, V, (B,), generator=g)
+        pos = torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32)
+        if step == 3:                                      # second half of the steps through inputs_embeds
+            h = tr.decode_step(cache, pos, inputs_embeds=tr.wte.weight[new.to(dev)]).cpu()
+        else:
+            h = tr.decode_step(cache, pos, input_ids=new).cpu()
+        for i in range(B):
+            seqs[i].append(int(new[i]))
+            ref = gpt2_ref.gpt2_forward(sd, torch.tensor([seqs[i]]), H, want_logits=False)["hidden"][0, -1]
+            assert rel_err(h[i].numpy(), ref.numpy()) < 2e-5, (step, i)
+    full = tr.encode(torch.tensor([seqs[1]], device=dev))["hidden"][0, -1].cpu()
+    assert rel_err(h[1].numpy(), full.numpy()) < 1e-5
+    pos = torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32)
+    pos[2] = cap                                           # past the cache: that row is NaN, the others unaffected
+    h2 = tr.decode_step(cache, pos, input_ids=torch.zeros(B, dtype=torch.int64)).cpu()
+    assert torch.isnan(h2[2]).all() and not torch.isnan(h2[[0, 1, 3, 4]]).any()
+
+
 def test_lm_logits_odd_vocab(dev):
     from rag4dyg_amd import ops
     g = torch.Generator().manual_seed(3)

@@ -257,6 +257,12 @@ def test_simpledyg_greedy_eval_matches_oracle_decode(dev, tmp_path, monkeypatch)
             same += got == ref
             assert got[:len(ids)] == ids and len(got) > len(ids)
     assert same >= 11                                   # argmax can only differ at sub-1e-6 logit ties
+    from rag4dyg_amd.evaluation import greedy_decode_batch
+    prompts = [tok.encode(ln) for ln in lines[:9]]
+    for mode in ("val", "test"):                        # cached, batched decode == the reference's one-at-a-time loop
+        one = [greedy_decode(m, tok, p_, mode, P, 12, dev) for p_ in prompts]
+        many = greedy_decode_batch(m, tok, prompts, mode, P, 12, dev)
+        assert sum(a == b for a, b in zip(one, many)) >= len(prompts) - 1
     argv = (f"--dataset toy --timestamp 4 --output_dir {tmp_path}/out --model_type gpt2 --train_data_file "
             f"{base}/train.link_prediction --do_eval --eval_all_checkpoints --eval_data_file {base}/val.link_prediction "
             f"--eval_data_gt_file {base}/val_gt.link_prediction --block_size 128 --n_layer {L} --n_head {H} --n_embed {d}").split()
@@ -335,6 +341,9 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
     args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=topk)
     qs = [tok.encode(ln) for ln in lines[:9]]
     ixs = [rng.permutation(len(sources))[:9].tolist() for _ in qs]
+    rows_one = torch.stack([generator.fusion_rows(args, model, tok, ds, ix, topk) for ix in ixs])
+    rows_all = generator.fusion_rows_batch(args, model, tok, ds, ixs, topk)
+    assert rows_all.shape == rows_one.shape and rel_err(rows_all.cpu().numpy(), rows_one.cpu().numpy()) < 1e-5
     for mode in ("val", "test"):
         one = [generator.greedy_decode_rag(args, model, tok, ds, q, ix, mode, P, 12) for q, ix in zip(qs, ixs)]
         many = generator.greedy_decode_rag_batch(args, model, tok, ds, qs, ixs, mode, P, 12)
