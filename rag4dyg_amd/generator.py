@@ -301,8 +301,9 @@ class TextIndexScoreDataset:
             ego = int(line.split('<|history|>')[1].split(' ')[1])
             self.egoId[ego] = i
             self.egolist.append(ego)
-        self.index = [list(map(int, line.split())) for line in read_nonblank_lines(index_file_path)]
-        self.score = [list(map(float, line.split())) for line in read_nonblank_lines(score_file_path)]
+        from .retriever import read_matrix_rows              # binary side-car when this build wrote the files
+        self.index = read_matrix_rows(index_file_path, int)
+        self.score = read_matrix_rows(score_file_path, float)
         self.text = tokenizer(text_lines, add_special_tokens=True, max_length=block_size)["input_ids"]
         self.retrieval_sources = tokenizer(train_data, add_special_tokens=True, max_length=block_size)["input_ids"]
 

@@ -31,12 +31,43 @@ def hit_rate_at_k(predictions, targets, k=1):
 
 
 def save_index_score(index_rows, score_matrix, save_index_file, save_score_file, steps):
-    """Text layout of ``train/train_retriever.py:357-368`` (truncate at step 0, append afterwards, ``%.4f`` scores)."""
+    """Text layout of ``train/train_retriever.py:357-368`` (truncate at step 0, append afterwards, ``%.4f`` scores),
+    plus a BINARY SIDE-CAR per file (``<file>.bin``: raw little-endian rows, int32 indices / float32 scores, and
+    ``<file>.bin.json`` with dtype and row width) -- the text matrices are O(queries x pool) characters, the side-car is
+    what ``read_matrix_rows`` (and through it this build's generator stage) loads when it is present and complete."""
+    import json
     mode = 'w' if steps == 0 else 'a'
     with open(save_index_file, mode) as f, open(save_score_file, mode) as g:
         for i in range(score_matrix.shape[0]):
             f.write(' '.join([str(x) for x in index_rows[i]]) + '\n')
             g.write(' '.join([f"{x:.4f}" for x in score_matrix[i]]) + '\n')
+    for path, arr, dt in ((save_index_file, index_rows, np.int32), (save_score_file, score_matrix, np.float32)):
+        a = np.ascontiguousarray(arr, dtype=dt)
+        meta_path = path + ".bin.json"
+        meta = {"dtype": np.dtype(dt).name, "cols": int(a.shape[1]), "rows": 0}
+        if steps != 0 and os.path.exists(meta_path):
+            meta = json.load(open(meta_path))
+            if meta["cols"] != a.shape[1] or meta["dtype"] != np.dtype(dt).name:
+                raise ValueError(f"{path}.bin: row layout changed between steps")
+        with open(path + ".bin", 'wb' if steps == 0 else 'ab') as h:
+            h.write(a.tobytes())
+        meta["rows"] += int(a.shape[0])
+        with open(meta_path, "w") as h:
+            json.dump(meta, h)
+
+
+def read_matrix_rows(path, dtype):
+    """Rows of a ``*_index`` / ``*_score`` matrix as a list of lists: from the binary side-car when it exists, is at
+    least as new as the text file and has the size its header states; otherwise from the reference's text format."""
+    import json
+    b, m = path + ".bin", path + ".bin.json"
+    if os.path.exists(b) and os.path.exists(m) and os.path.getmtime(b) >= os.path.getmtime(path) - 1e-3:
+        meta = json.load(open(m))
+        a = np.fromfile(b, dtype=np.dtype(meta["dtype"]))
+        if a.size == meta["rows"] * meta["cols"]:
+            return a.reshape(meta["rows"], meta["cols"]).astype(dtype).tolist()
+    with open(path, encoding="utf-8") as f:
+        return [list(map(dtype, line.split())) for line in f.read().splitlines() if len(line) > 0 and not line.isspace()]
 
 
 def _unwrap(model):

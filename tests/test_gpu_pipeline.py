@@ -161,6 +161,14 @@ def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch
     res = tmp_path / "resources" / "retrieval_result" / "toy"
     idx_rows = np.array(_read_matrix(res / "test_index.gen", int))
     score_rows = np.array(_read_matrix(res / "test_score.gen"))
+    # binary side-cars: same rows as the text (scores to the text's 4 decimals); stale side-car is ignored
+    from rag4dyg_amd.retriever import read_matrix_rows
+    assert (res / "test_index.gen.bin").exists() and (res / "test_score.gen.bin.json").exists()
+    assert np.array_equal(np.array(read_matrix_rows(str(res / "test_index.gen"), int)), idx_rows)
+    assert np.abs(np.array(read_matrix_rows(str(res / "test_score.gen"), float)) - score_rows).max() <= 5.1e-5
+    with open(res / "test_index.gen.bin", "ab") as fh:
+        fh.write(b"\0\0\0\0")                                        # wrong size -> falls back to the text file
+    assert np.array_equal(np.array(read_matrix_rows(str(res / "test_index.gen"), int)), idx_rows)
     # oracle pipeline on the same text
     pool_ids = tok([ln.split('<|pre|>')[0].strip() for ln in train], max_length=512)["input_ids"]
     q_ids = tok(rd(os.path.join(base, "test.link_prediction")), max_length=512)["input_ids"]
