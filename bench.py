@@ -225,8 +225,11 @@ def main():
         v = prof[dom]
         traffic = None
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tf):              # PMC figure of a separate rocprofv3 pass: valid for the workload it profiled only
+            pmc = json.load(open(tf))
+            meta = pmc.get("_workload", {})
+            if meta.get("shape") == args.shape and meta.get("batches_per_step") == G and meta.get("n_gpus", 1) == world:
+                traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
         if dom.startswith(("gemm", "attn")):
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,

@@ -69,6 +69,9 @@ def bench_class(k):
 
 
 traffic = {bench_class(k): v for k, v in traffic.items() if not k.startswith(("at::", "__amd"))}
+# what tools/profile_bench.sh ran: bench.py only attaches these figures to a line of the same workload
+traffic["_workload"] = {"shape": "UCI_13", "batches_per_step": 4, "n_gpus": 1,
+                        "command": "bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1)[:3000])
