@@ -327,36 +327,94 @@ static int launch_kc(const GemmArgs& g, int cls, hipStream_t stream) {
     return R4D_OK;
 }
 
-// k-contiguous GEMM: requires g.b_trans (B is [N,K]) and no causal P.V trimming.
-int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("R4D_GEMM_KC_TILE");   // tuning aid: 0..3 forces a tile shape
-        forced = e ? atoi(e) : -1;
-    }
+// cost of one launch of `rows` x N with tile t, in (tile elements / efficiency) units: a CU works through its
+// ceil(blocks / 256) tiles at the tile's measured efficiency, derated when too few waves are resident
+static double kc_cost(const GemmArgs& g, int rows, int t, long long* per_cu_out = nullptr) {
+    const KcTile& c = kKc[t];
+    long long blocks = (long long)cdiv(rows, c.bm) * cdiv(g.N, c.bn) * g.nbatch;
+    if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(rows, c.bm) * g.nbatch / 2;
+    const long long per_cu = (blocks + 255) / 256;
+    const double conc = (double)(per_cu < c.blocks_per_cu ? per_cu : c.blocks_per_cu);
+    const double wps = conc * c.waves_per_block / 4.0;
+    // one 4-wave workgroup alone on a CU (one wave per SIMD) runs at ~0.8 of the two-per-SIMD rate (measured: a lone
+    // 64x64x2048 tile 43 us, a lone 128x64 80 us, a lone 8-wave 128x128 133 us)
+    const double eff = c.eff * (wps >= 2.0 ? 1.0 : 0.6 + 0.2 * wps);
+    if (per_cu_out) *per_cu_out = per_cu;
+    return (double)per_cu * c.bm * c.bn / eff;
+}
+
+static int kc_best_tile(const GemmArgs& g, int rows, double* cost_out) {
     int best = kNumKc - 1;
-    if (forced >= 0 && forced < kNumKc) best = forced;
-    else {
-        double best_cost = 1e300;
-        for (int t = 0; t < kNumKc; ++t) {
-            const KcTile& c = kKc[t];
-            if (c.eff <= 0.0) continue;
-            long long blocks = (long long)cdiv(g.M, c.bm) * cdiv(g.N, c.bn) * g.nbatch;
-            if (g.causal == CAUSAL_QK) blocks = blocks / 2 + (long long)cdiv(g.M, c.bm) * g.nbatch / 2;
-            const long long per_cu = (blocks + 255) / 256;
-            const double conc = (double)(per_cu < c.blocks_per_cu ? per_cu : c.blocks_per_cu);
-            const double wps = conc * c.waves_per_block / 4.0;
-            const double eff = c.eff * (wps >= 2.0 ? 1.0 : wps / 2.0);
-            const double cost = (double)per_cu * c.bm * c.bn / eff;
-            if (cost < best_cost) { best_cost = cost; best = t; }
-        }
+    double best_cost = 1e300;
+    for (int t = 0; t < kNumKc; ++t) {
+        if (kKc[t].eff <= 0.0) continue;
+        const double c = kc_cost(g, rows, t);
+        if (c < best_cost) { best_cost = c; best = t; }
     }
-    switch (best) {
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+
+static int kc_launch_tile(const GemmArgs& g, int t, hipStream_t stream) {
+    switch (t) {
         case 0: return launch_kc<128, 128, 32, 4, 2, 2>(g, kKc[0].cls, stream);
         case 1: return launch_kc<128, 128, 16, 4, 2, 4>(g, kKc[1].cls, stream);
         case 2: return launch_kc<128, 64, 16, 2, 2, 3>(g, kKc[2].cls, stream);
         default: return launch_kc<64, 64, 32, 2, 2, 2>(g, kKc[3].cls, stream);
     }
+}
+
+// k-contiguous GEMM: requires g.b_trans (B is [N,K]) and no causal P.V trimming.
+//
+// Tile quantisation: a launch takes ceil(tiles / 256) tile-times per CU, so 4.1 tiles per CU cost as much as 5
+// (measured: M = 33,600..38,400, N = 512 all take 625 us with the 128x128 tile).  When the last round is mostly empty
+// the rows are SPLIT: a main launch whose tile count fills whole rounds, and a second launch over the remaining rows
+// with whatever tile is cheapest for them (usually a smaller one that spreads over more CUs).  Plain (unbatched,
+// non-causal) GEMMs only; rows are independent, so the results are bit-identical to a single launch.
+int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
+    static int forced = -2, split = -1;
+    if (forced == -2) {
+        const char* e = getenv("R4D_GEMM_KC_TILE");   // tuning aid: 0..3 forces a tile shape (and no row split)
+        forced = e ? atoi(e) : -1;
+        const char* sp = getenv("R4D_GEMM_KC_SPLIT"); // tuning aid: 0 disables the row split
+        split = sp ? atoi(sp) : 1;
+    }
+    if (forced >= 0 && forced < kNumKc) return kc_launch_tile(g, forced, stream);
+    double single_cost;
+    const int single = kc_best_tile(g, g.M, &single_cost);
+    if (split && g.nbatch == 1 && g.causal == CAUSAL_NONE) {
+        // a second launch costs ~5 us of ramp-up/drain: in cost units (time * K), relative to a 128x128 tile at K = 512
+        // taking ~27 us alone on a CU (16384 / 0.91 units)
+        const double launch_overhead = 0.2 * (16384.0 / 0.91) * 512.0 / (double)g.K;
+        double best_cost = single_cost;
+        int best_t1 = -1, best_t2 = -1, best_m1 = 0;
+        for (int t1 = 0; t1 < kNumKc; ++t1) {
+            const KcTile& c = kKc[t1];
+            if (c.eff <= 0.0) continue;
+            const long long tiles_n = cdiv(g.N, c.bn);
+            const long long rounds = (long long)cdiv(g.M, c.bm) * tiles_n / 256;          // whole rounds available
+            if (rounds < 1) continue;
+            const long long tiles_m1 = rounds * 256 / tiles_n;                             // rows that fill them
+            const int m1 = (int)(tiles_m1 * c.bm);
+            if (m1 <= 0 || m1 >= g.M) continue;
+            double c2;
+            const int t2 = kc_best_tile(g, g.M - m1, &c2);
+            const double total = kc_cost(g, m1, t1) + c2 + launch_overhead;
+            if (total < best_cost) { best_cost = total; best_t1 = t1; best_t2 = t2; best_m1 = m1; }
+        }
+        if (best_t1 >= 0 && best_cost < 0.97 * single_cost) {
+            GemmArgs a = g, b = g;
+            a.M = best_m1;
+            b.M = g.M - best_m1;
+            b.A = g.A + (long long)best_m1 * g.lda;
+            b.C = g.C + (long long)best_m1 * g.ldc;
+            if (g.resid) b.resid = g.resid + (long long)best_m1 * g.ldr;
+            const int rc = kc_launch_tile(a, best_t1, stream);
+            if (rc) return rc;
+            return kc_launch_tile(b, best_t2, stream);
+        }
+    }
+    return kc_launch_tile(g, single, stream);
 }
 
 }  // namespace r4d

@@ -72,7 +72,9 @@ def test_conv1d_k_contiguous_tiles(dev):
     lib = _lib.load()
     _lib.check(lib.r4d_profile_enable(1), "profile_enable")
     try:
-        for (M, K, N) in [(16380, 64, 1530), (4090, 512, 1536), (130, 96, 250), (257, 1024, 100), (129, 32, 130)]:
+        # (33601, 512, 512) takes the ROW-SPLIT path: 4 full rounds of 128x128 tiles + the remaining rows in 64x64 tiles
+        for (M, K, N) in [(16380, 64, 1530), (4090, 512, 1536), (130, 96, 250), (257, 1024, 100), (129, 32, 130),
+                          (33601, 512, 512)]:
             g = torch.Generator().manual_seed(M + K + N)
             x = torch.randn(M, K, generator=g)
             w = torch.randn(K, N, generator=g) * 0.05
