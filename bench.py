@@ -29,7 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from rag4dyg_amd import _lib, ops, synth                      # noqa: E402
-from rag4dyg_amd.dist import all_gather_cat, sharded_topk      # noqa: E402
+from rag4dyg_amd.dist import PipelinedShardedTopK, all_gather_cat, sharded_topk      # noqa: E402
 from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG    # noqa: E402
 from rag4dyg_amd.retrieval import PoolIndex, encode_batches, right_pad_batches   # noqa: E402
 
@@ -176,13 +176,38 @@ def main():
     else:
         gather = all_gather_cat
 
+    def local_topk(q, p_, kk, off):
+        return ops.score_topk(q, p_, kk, off)[:2]
+
+    # N > 1 over RCCL: the two collectives of a step run asynchronously, each consumed one step later
+    # (rag4dyg_amd.dist.PipelinedShardedTopK), so ranks whose batches happen to be longer this step do not stall the
+    # others twice per step.  All K steps are still complete inside the timed region (flush before the closing sync).
+    # R4D_BENCH_PIPELINE=0 selects the step-synchronous form; a failing self-test falls back to it as well.
+    pipe = None
+    if world > 1 and backend == "nccl" and os.environ.get("R4D_BENCH_PIPELINE", "1") != "0":
+        try:
+            pipe = PipelinedShardedTopK(index.pool_hat, index.index_offset, k, local_topk, ops.merge_topk)
+            probe = ops.normalize_rows(torch.randn(QB * G, shape.n_embd, device=device))
+            got = [r for r in (pipe.submit(probe), pipe.submit(probe)) if r is not None] + pipe.flush()
+            torch.cuda.synchronize()
+            assert len(got) == 2 and got[0][1].shape == (QB * G * world, k)
+        except Exception as e:                                        # noqa: BLE001 -- never lose the run to the overlap
+            if rank == 0:
+                print(f"[bench] pipelined collectives unavailable ({type(e).__name__}: {e}); using the synchronous form",
+                      file=sys.stderr)
+            pipe = None
+
     def step(i):
         group = [q_batches[(i * G + j) % nqb] for j in range(G)]
         emb = model.encode_groups_meanpool(group)
         q_hat = ops.normalize_rows(emb)
+        if pipe is not None:
+            return pipe.submit(q_hat)
         q_all = gather(q_hat) if world > 1 else q_hat
-        return sharded_topk(q_all, index.pool_hat, index.index_offset, k,
-                            lambda q, p_, kk, off: ops.score_topk(q, p_, kk, off)[:2], ops.merge_topk)
+        return sharded_topk(q_all, index.pool_hat, index.index_offset, k, local_topk, ops.merge_topk)
+
+    def drain():
+        return pipe.flush() if pipe is not None else []
 
     def sync():
         torch.cuda.synchronize()
@@ -192,10 +217,14 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
+    tail = drain()                                                   # the last two steps' results: inside the timed region
+    if tail:
+        out = tail[-1]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -211,6 +240,7 @@ def main():
         lib.r4d_profile_enable(1)
         for i in range(args.steps):
             step(i)
+        drain()
         torch.cuda.synchronize()
         prof = read_profile()
         lib.r4d_profile_enable(0)
@@ -266,7 +296,9 @@ def main():
                                    f"resident {P}-row pool shard, top-{k}; N>1: RCCL all-gather of embeddings and per-shard top-k",
                        "query_batch": QB, "query_batches_per_step": G, "queries_per_step_per_gpu": QB * G,
                        "pool_rows_per_gpu": P, "pool_rows_total": P * world, "topk": k,
-                       "parallelism": f"pool-shard x{world}"},
+                       "parallelism": f"pool-shard x{world}",
+                       "collectives": ("none" if world == 1 else
+                                       "async, consumed one step later (3-stage pipeline)" if pipe is not None else "synchronous")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extras": {"encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),

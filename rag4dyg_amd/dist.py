@@ -61,3 +61,68 @@ def sharded_topk(q_hat_all, pool_hat_shard, shard_offset, k, local_topk, merge, 
     gv = all_gather_cat(vals.unsqueeze(0), group)          # [G,Q,k]
     gi = all_gather_cat(idx.unsqueeze(0), group)
     return merge(gv, gi)
+
+
+class PipelinedShardedTopK:
+    """``sharded_topk`` as a three-stage software pipeline over query batches (one batch per ``submit``).
+
+    A batch needs two collectives (query embeddings, then per-shard candidates).  Run synchronously, every rank waits for
+    the slowest rank TWICE per batch -- and ranks are unequal from batch to batch, because each pads its own query batches
+    to their own lengths.  Here both collectives are started asynchronously and consumed one ``submit`` later each:
+
+        submit(i):  merge(i-2)  <- candidates gathered during step i-1
+                    local scan + top-k of batch i-1 on the gathered queries, START the candidate all-gathers
+                    START the all-gather of batch i's query embeddings
+
+    so a rank only stalls when it is a whole step ahead of the slowest one.  ``submit`` returns the merged (vals, idx) of
+    the batch submitted two calls earlier (``None`` while the pipeline fills); ``flush()`` drains it and returns the
+    remaining results in order.  Same collectives in the same order on every rank; results identical to ``sharded_topk``.
+    """
+
+    def __init__(self, pool_hat_shard, shard_offset, k, local_topk, merge, group=None):
+        self.pool, self.offset, self.k = pool_hat_shard, shard_offset, k
+        self.local_topk, self.merge, self.group = local_topk, merge, group
+        self.world = dist.get_world_size(group)
+        self._q = None          # (work, gathered queries, keep-alive)
+        self._cand = None       # ((work, gathered vals, keep), (work, gathered idx, keep))
+
+    def _start_gather(self, t):
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+        return work, out, t
+
+    def _step(self, q_hat):
+        done = None
+        if self._cand is not None:
+            (wv, gv, _), (wi, gi, _) = self._cand
+            wv.wait(); wi.wait()
+            done = self.merge(gv, gi)                                   # [G,Q,k] each
+            self._cand = None
+        if self._q is not None:
+            w, q_all, _ = self._q
+            w.wait()
+            Q, n_local = q_all.shape[0], self.pool.shape[0]
+            kk = min(self.k, n_local)
+            vals = torch.full((Q, self.k), float("-inf"), dtype=torch.float32, device=q_all.device)
+            idx = torch.full((Q, self.k), torch.iinfo(torch.int64).max, dtype=torch.int64, device=q_all.device)
+            if kk > 0:
+                v, i = self.local_topk(q_all, self.pool, kk, self.offset)
+                vals[:, :kk] = v
+                idx[:, :kk] = i
+            self._cand = (self._start_gather(vals.unsqueeze(0)), self._start_gather(idx.unsqueeze(0)))
+            self._q = None
+        if q_hat is not None:
+            self._q = self._start_gather(q_hat)
+        return done
+
+    def submit(self, q_hat):
+        return self._step(q_hat)
+
+    def flush(self):
+        out = []
+        for _ in range(2):
+            r = self._step(None)
+            if r is not None:
+                out.append(r)
+        return out

@@ -261,6 +261,25 @@ def merge(gv, gi):
 vals, idx = sharded_topk(qh, ph[s:e], s, k, local_topk, merge)
 ref_v, ref_i = local_topk(qh, ph, k, 0)
 assert torch.equal(idx, ref_i) and torch.equal(vals, ref_v), (rank, idx, ref_i)
+# pipelined form: every rank contributes its OWN queries per batch; results arrive two submits later, in order
+from rag4dyg_amd.dist import PipelinedShardedTopK
+pipe = PipelinedShardedTopK(ph[s:e], s, k, local_topk, merge)
+gq = torch.Generator().manual_seed(100 + rank)
+mine = [torch.nn.functional.normalize(torch.randn(3, d, generator=gq), dim=1) for _ in range(5)]
+got = []
+for b in mine:
+    r = pipe.submit(b)
+    if r is not None: got.append(r)
+got += pipe.flush()
+assert len(got) == 5
+for j, (gv, gi) in enumerate(got):
+    allq = []
+    for r_ in range(world):                    # what every rank submitted as batch j
+        gg = torch.Generator().manual_seed(100 + r_)
+        allq.append([torch.nn.functional.normalize(torch.randn(3, d, generator=gg), dim=1) for _ in range(5)][j])
+    rv, ri = local_topk(torch.cat(allq), ph, k, 0)
+    assert torch.equal(gi, ri) and torch.equal(gv, rv), (rank, j)
+assert pipe.flush() == []
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
