@@ -66,6 +66,7 @@ struct RowTable {
     int seq_prefix[ATT_MAXG + 1];            // first sequence of each batch
     long long row_prefix[ATT_MAXG + 1];      // first token row of each batch
     long long part_prefix[ATT_MAXG + 1];     // first partial row (B * chunks) of each batch in the mean-pool scratch
+    __device__ __forceinline__ long long row0_of(int g, int bidx) const { return row_prefix[g] + (long long)bidx * T[g]; }
 };
 struct RowInputs { const int64_t* ids[ATT_MAXG]; const float* emb[ATT_MAXG]; };
 
@@ -326,6 +327,7 @@ int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStr
 // its rows (one wavefront per row), sums them per wave in registers, combines its 4 waves through LDS in a
 // fixed order and writes one partial row; (2) one workgroup per sequence adds the S partials in order and
 // divides by T.  No atomics -> bitwise reproducible.
+template <int NV>                                   // NV = ceil over the instantiation: values per lane (d <= 64*NV)
 __global__ __launch_bounds__(256) void lnf_partial_kernel(const RowTable G, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ b, int d,
                                                           float eps, float* __restrict__ hidden_out,
@@ -338,29 +340,45 @@ __global__ __launch_bounds__(256) void lnf_partial_kernel(const RowTable G, cons
     const int T = G.T[g], S = (T + LNF_ROWS_PER_CHUNK - 1) / LNF_ROWS_PER_CHUNK;
     if (chunk >= S) return;                            // grid.x covers the longest batch
     const int bidx = seq - G.seq_prefix[g];            // sequence within its batch
-    const long long row0 = G.row_prefix[g] + (long long)bidx * T;
+    const long long row0 = G.row0_of(g, bidx);
     const int nv = d >> 6;
     const int t0 = chunk * LNF_ROWS_PER_CHUNK, t1 = min(T, t0 + LNF_ROWS_PER_CHUNK);
-    float acc[MAXV];
+    constexpr int RPW = LNF_ROWS_PER_CHUNK / 4;        // rows per wave: ALL their loads are issued before the first
+    float v[RPW][NV];                                  // reduction (one row at a time left the kernel latency-bound)
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) acc[i] = 0.f;
-    for (int t = t0 + wid; t < t1; t += 4) {
-        const long long base = (row0 + t) * d;
-        float v[MAXV];
+    for (int r = 0; r < RPW; ++r) {
+        const int t = min(t0 + wid + 4 * r, T - 1);    // clamped: always valid; rows past t1 are dropped below
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) if (i < nv) v[i] = x[base + lane + 64 * i];
-        ln_row(v, nv, d, eps);
+        for (int i = 0; i < NV; ++i) v[r][i] = (i < nv) ? x[(row0 + t) * d + lane + 64 * i] : 0.f;
+    }
+    float acc[NV];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i < nv) {
-                const float y = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
-                if (hidden_out) hidden_out[base + lane + 64 * i] = y;
-                acc[i] += y;
-            }
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int t = t0 + wid + 4 * r;
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s_ += v[r][i];
+        const float mean = wave_sum(s_) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (i < nv) { const float c = v[r][i] - mean; q += c * c; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+        if (t < t1) {
+            const long long base = (row0 + t) * d;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i < nv) {
+                    const float y = (v[r][i] - mean) * rstd * w[lane + 64 * i] + b[lane + 64 * i];
+                    if (hidden_out) hidden_out[base + lane + 64 * i] = y;
+                    acc[i] += y;
+                }
+        }
     }
     if (!partial) return;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) if (i < nv) red[wid * d + lane + 64 * i] = acc[i];
+    for (int i = 0; i < NV; ++i) if (i < nv) red[wid * d + lane + 64 * i] = acc[i];
     __syncthreads();
     const long long prow = G.part_prefix[g] + (long long)bidx * S + chunk;
     for (int c = threadIdx.x; c < d; c += 256)
@@ -397,8 +415,11 @@ int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* 
     for (int g = 0; g < G.n; ++g) Tmax = G.T[g] > Tmax ? G.T[g] : Tmax;
     {
         ProfScope prof(PK_LNF_MEANPOOL, 4.0 * rows * d * (hidden_out ? 2 : 1) + 4.0 * parts * d, s);
-        hipLaunchKernelGGL(lnf_partial_kernel, dim3(cdiv(Tmax, LNF_ROWS_PER_CHUNK), nseq), dim3(256), 4 * d * sizeof(float), s,
-                           t, x, w, b, d, eps, hidden_out, pool_out ? scratch : nullptr);
+        const dim3 grid(cdiv(Tmax, LNF_ROWS_PER_CHUNK), nseq);
+        float* part = pool_out ? scratch : nullptr;
+        if (d <= 512) hipLaunchKernelGGL(lnf_partial_kernel<8>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
+        else if (d <= 1024) hipLaunchKernelGGL(lnf_partial_kernel<16>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
+        else hipLaunchKernelGGL(lnf_partial_kernel<32>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
         R4D_CHECK_LAUNCH("lnf_partial");
     }
     if (pool_out) {
