@@ -370,7 +370,9 @@ static int kc_launch_tile(const GemmArgs& g, int t, hipStream_t stream) {
 // (measured: M = 33,600..38,400, N = 512 all take 625 us with the 128x128 tile).  When the last round is mostly empty
 // the rows are SPLIT: a main launch whose tile count fills whole rounds, and a second launch over the remaining rows
 // with whatever tile is cheapest for them (usually a smaller one that spreads over more CUs).  Plain (unbatched,
-// non-causal) GEMMs only; rows are independent, so the results are bit-identical to a single launch.
+// non-causal) GEMMs only; rows are independent, so the results are bit-identical to a single launch.  (Measured and
+// dropped: running the remainder on a side stream, forked/joined with events, so that it overlaps the main launch --
+// 3 % SLOWER on the bench step; the event barriers cost more than the idle tail they remove.)
 int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
     static int forced = -2, split = -1;
     if (forced == -2) {
