@@ -307,7 +307,9 @@ static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8
     {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
 };
 // (measured and dropped: 4 waves with 64x64 wave tiles at BK 16 -- 140 TF asymptote but 121 TF at K = 512; 4 waves at
-// BK 32, one workgroup per CU -- 127 / 101 TF; BK 32 with TWO stages, two workgroups per CU -- 140 / 125 TF)
+// BK 32, one workgroup per CU -- 127 / 101 TF; BK 32 with TWO stages, two workgroups per CU -- 140 / 125 TF; a 256x128
+// macro-tile with 64x64 wave tiles, 8 waves, one workgroup per CU -- 138 / 113 TF: two co-resident workgroups are worth
+// more than fewer LDS reads per MFMA)
 constexpr int kNumKc = 4;
 
 template <int BM, int BN, int BK, int WGM, int WGN, int MINW>
