@@ -10,6 +10,9 @@
 // a time: its tokens are wave-uniform, every token is ONE broadcast LDS read of mask[token], and lane j
 // adds bit j -- the popcount of the intersection accumulates across the wave's 64 pairs at 2 VALU ops per
 // token.  |A|B| = |A| + |B| - |A&B|; the f64 division is correctly rounded == python's int/int.
+// (Measured and dropped: tables in GLOBAL memory so that tokens and masks come through scalar loads and a token costs one
+// v_addc_co_u32 with the mask as carry-in -- correct, but 2x SLOWER: random 8-byte lookups in a 95 KB table miss the scalar
+// cache and the dependent s_load chains (token -> mask) are latency-bound.)
 #include "common.h"
 
 #ifndef JAC_DBG
