@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...);
 // ------------------------------------------------------------------ launch profiler (profile.hip)
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
-    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32,
+    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
     PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
@@ -66,6 +66,11 @@ struct GemmArgs {
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given as [N,K]: k-contiguous kernel
+// gemm_skinny.hip: M <= 32 rows against a k-contiguous weight [N,K], K % 256 == 0 (decode step); split-K partials in scratch
+bool gemm_skinny_supported(int M, int K, int N);
+size_t gemm_skinny_scratch_floats(int K, int N);
+int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
+                       int epilogue, float* y, float* scratch, hipStream_t s);
 
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,

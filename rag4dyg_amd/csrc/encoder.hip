@@ -16,7 +16,9 @@ void set_error(const char* fmt, ...) {
 }
 
 static int conv1d(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K,
-                  int N, int epilogue, float* y, hipStream_t s) {
+                  int N, int epilogue, float* y, hipStream_t s, float* skinny_scratch = nullptr) {
+    if (skinny_scratch && wT && gemm_skinny_supported(M, K, N))        // decode step: a weight stream, not a tiled GEMM
+        return launch_gemm_skinny(x, wT, bias, resid, M, K, N, epilogue, y, skinny_scratch, s);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = x; g.C = y; g.bias = bias; g.resid = resid;
@@ -278,9 +280,19 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
                        workspace_bytes, (hipStream_t)stream);
 }
 
+// decode workspace: the per-row buffers of the encoder + the split-K scratch of the skinny GEMM (largest projection:
+// K = 4d, N = d and K = d, N = 4d both give (4d / 256) * 32 * 4d... the max of the four shapes is taken)
+static size_t decode_skinny_floats(int d) {
+    size_t m = 0;
+    const int shapes[4][2] = {{d, 3 * d}, {d, d}, {d, 4 * d}, {4 * d, d}};
+    for (auto& kn : shapes)
+        if (gemm_skinny_supported(1, kn[0], kn[1])) { const size_t f = gemm_skinny_scratch_floats(kn[0], kn[1]); if (f > m) m = f; }
+    return m;
+}
+
 size_t r4d_gpt2_decode_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B) {
     if (!cfg || B <= 0) return 0;
-    return carve(nullptr, (size_t)B, 0, 0, cfg->n_embd).bytes;
+    return carve(nullptr, (size_t)B, 0, decode_skinny_floats(cfg->n_embd), cfg->n_embd).bytes;
 }
 
 int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
@@ -295,11 +307,13 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
     R4D_REQUIRE(pos_d && kv_cache_d && out_hidden_d, "gpt2 decode: null pointer");
     R4D_REQUIRE(B >= 1 && t_cap >= 1, "gpt2 decode: B=%d t_cap=%d", B, t_cap);
     const int d = cfg->n_embd, H = cfg->n_head;
-    Workspace ws = carve(workspace_d, (size_t)B, 0, 0, d);
+    const size_t sk_floats = decode_skinny_floats(d);
+    Workspace ws = carve(workspace_d, (size_t)B, 0, sk_floats, d);
     if (!workspace_d || workspace_bytes < ws.bytes) {
         set_error("gpt2 decode: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
         return R4D_ERR_WORKSPACE;
     }
+    float* sk = (sk_floats && B <= 32) ? ws.pool : nullptr;         // M <= 32: the projections run as weight streams
     const size_t layer_stride = (size_t)B * t_cap * 2 * d;
     for (int l = 0; l < cfg->n_layer; ++l) {
         const r4d_gpt2_layer& L = w->layers[l];
@@ -311,13 +325,13 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         else
             rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
         if (rc) return rc;
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s, sk))) return rc;
         if ((rc = launch_decode_attention(ws.qkv, kv_cache_d + (size_t)l * layer_stride, pos_d, B, t_cap, H, d, ws.att, s)))
             return rc;
-        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
-        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s))) return rc;
-        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s, sk))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
     }
     return launch_layernorm(ws.x, w->ln_f_w, w->ln_f_b, B, d, cfg->ln_eps, out_hidden_d, s);
 }

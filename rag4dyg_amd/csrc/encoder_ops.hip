@@ -220,12 +220,24 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
     __syncthreads();
     const int n = p + 1;
     const float scale = sqrtf((float)hd);
-    for (int t = wid; t < n; t += 4) {
-        const float* kr = kvb + (long long)t * 2 * d + h * hd;
-        float a = 0.f;
-        for (int c = lane; c < hd; c += 64) a += kr[c] * qs[c];
-        a = wave_sum(a);
-        if (lane == 0) sc[t] = a / scale;              // divided like the reference (:143)
+    // four keys per trip: their K rows are requested together (one key at a time is a chain of dependent ~1 us loads)
+    constexpr int KU = 4;
+    for (int t0 = wid; t0 < n; t0 += 4 * KU) {
+        float kv_[KU][DEC_MAXC];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const float* kr = kvb + (long long)min(t0 + 4 * u, n - 1) * 2 * d + h * hd;
+#pragma unroll
+            for (int i = 0; i < DEC_MAXC; ++i) kv_[u][i] = (lane + 64 * i < hd) ? kr[lane + 64 * i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < DEC_MAXC; ++i) if (lane + 64 * i < hd) a += kv_[u][i] * qs[lane + 64 * i];
+            a = wave_sum(a);
+            if (lane == 0 && t0 + 4 * u < n) sc[t0 + 4 * u] = a / scale;     // divided like the reference (:143)
+        }
     }
     __syncthreads();
     float m = -INFINITY;
@@ -245,12 +257,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
     __syncthreads();
     l = (red[4] + red[5]) + (red[6] + red[7]);
     float acc[DEC_MAXC] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = wid; t < n; t += 4) {
-        const float* vr = kvb + (long long)t * 2 * d + d + h * hd;
-        const float e = sc[t];
+    for (int t0 = wid; t0 < n; t0 += 4 * KU) {
+        float vv[KU][DEC_MAXC], e[KU];
 #pragma unroll
-        for (int i = 0; i < DEC_MAXC; ++i)
-            if (lane + 64 * i < hd) acc[i] += e * vr[lane + 64 * i];
+        for (int u = 0; u < KU; ++u) {
+            const int t = t0 + 4 * u;
+            const float* vr = kvb + (long long)min(t, n - 1) * 2 * d + d + h * hd;
+            e[u] = t < n ? sc[t] : 0.f;
+#pragma unroll
+            for (int i = 0; i < DEC_MAXC; ++i) vv[u][i] = (lane + 64 * i < hd) ? vr[lane + 64 * i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)                   // same key order per wave as one key at a time
+#pragma unroll
+            for (int i = 0; i < DEC_MAXC; ++i) acc[i] += e[u] * vv[u][i];
     }
 #pragma unroll
     for (int i = 0; i < DEC_MAXC; ++i)

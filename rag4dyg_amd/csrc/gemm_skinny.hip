@@ -1,0 +1,113 @@
+// Skinny fp32 GEMM for the decode step: y[M,N] = epilogue(x[M,K] . wT[N,K]^T + bias), M <= 32 rows.
+//
+// With a handful of rows a Conv1D is a WEIGHT STREAM (K*N*4 bytes read once, ~0 reuse): the tiled kernels run it as
+// N/64 lone tiles with K-long serial loops (12-48 busy CUs, 33 us per projection at d = 768 -- 0.8 ms of a 1.1 ms decode
+// step).  This kernel is the pool-scan design (score.hip) pointed at a weight matrix: the rows of x take the place of
+// the queries (k-major in LDS, conflict-free fill and reads), every wavefront owns a 32-row tile of wT and streams it
+// with 16-byte loads, 16 loads in flight, exact-f32 MFMA 32x32x2 -- and K is SPLIT over gridDim.y slices of 256 so that
+// a 768 x 768 projection still spreads over 72 wavefronts.  Slice partials go to a caller-provided scratch and are
+// added in slice order by the epilogue kernel (bias / gelu_new / residual): deterministic, no atomics.
+#include "common.h"
+
+namespace r4d {
+
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+constexpr int SK_KC = 256;                              // k-slice per workgroup
+constexpr int SK_LDX = 33;                              // Xs row stride
+
+__device__ __forceinline__ float gelu_new_sk(float x) {   // same form as gemm_f32_kc.hip
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+}
+
+// partial[ks][m][n] = sum over k in slice ks of x[m,k] * wT[n,k]        (m < 32 padded with zero rows)
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ x, const float* __restrict__ wT, int M,
+                                                          int N, int K, float* __restrict__ partial) {
+    __shared__ float Xs[SK_KC * SK_LDX];               // [k][33]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.y * SK_KC;
+    for (int m = 0; m < 32; ++m) {
+        const bool ok = m < M;
+        const float* src = x + (long long)min(m, M - 1) * K + k0;
+        const float v = src[tid];                      // SK_KC == blockDim.x
+        Xs[tid * SK_LDX + m] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wid;
+    const int ntiles = (N + 31) / 32;
+    if (tile >= ntiles) return;
+    const int row = tile * 32 + li;
+    // k order as in pool_scan_kernel: lane half h of row j owns the 64-byte halves [32g + 16h, +16) of each 128-byte line
+    const float4* __restrict__ wrow =
+        reinterpret_cast<const float4*>(wT + (long long)min(row, N - 1) * K + k0) + 4 * lh;     // clamped: always valid
+    f32x16g acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NG = SK_KC / 32;                     // 8 groups of 32 k
+    float4 b[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];          // the whole slice of this row: 32 loads in flight
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* xa = Xs + (32 * g + 16 * lh + 4 * u) * SK_LDX + li;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[0], b[g][u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[SK_LDX], b[g][u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * SK_LDX], b[g][u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[3 * SK_LDX], b[g][u].w, acc, 0, 0, 0);
+        }
+    if (row < N) {
+        float* dst = partial + (long long)blockIdx.y * 32 * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            dst[(long long)m * N + row] = acc[r];      // rows m >= M are zero: written, never read
+        }
+    }
+}
+
+// y[m,n] = epilogue(sum_ks partial[ks][m][n] + bias[n] (+ resid[m,n])), slices added in order
+__global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(const float* __restrict__ partial, int KS, int M, int N,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ resid, int epilogue,
+                                                                   float* __restrict__ y) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float v = 0.f;
+    for (int ks = 0; ks < KS; ++ks) v += partial[((long long)ks * 32 + m) * N + n];
+    v += bias ? bias[n] : 0.f;
+    if (epilogue == EPI_GELU) v = gelu_new_sk(v);
+    else if (epilogue == EPI_RESIDUAL) v += resid[idx];
+    y[idx] = v;
+}
+
+size_t gemm_skinny_scratch_floats(int K, int N) { return (size_t)cdiv(K, SK_KC) * 32 * N; }
+
+bool gemm_skinny_supported(int M, int K, int N) { return M >= 1 && M <= 32 && K % SK_KC == 0 && K >= SK_KC && N >= 1; }
+
+int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
+                       int epilogue, float* y, float* scratch, hipStream_t s) {
+    R4D_REQUIRE(gemm_skinny_supported(M, K, N) && scratch, "skinny gemm: unsupported shape M=%d K=%d N=%d", M, K, N);
+    R4D_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wT % 16) == 0, "skinny gemm: operands must be 16-byte aligned");
+    const int KS = K / SK_KC;
+    {
+        // algorithmic bytes: the weight matrix once (+ x per slice, + partials)
+        ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + 4.0 * KS * 32.0 * N, s);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(cdiv(N, 32), 4), KS), dim3(256), 0, s, x, wT, M, N, K, scratch);
+        R4D_CHECK_LAUNCH("gemm_skinny");
+    }
+    {
+        ProfScope prof(PK_GEMM_SKINNY_EPI, 4.0 * KS * M * (double)N + 8.0 * M * N, s);
+        hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((unsigned)cdiv((long long)M * N, 256)), dim3(256), 0, s, scratch,
+                           KS, M, N, bias, resid, epilogue, y);
+        R4D_CHECK_LAUNCH("gemm_skinny_epilogue");
+    }
+    return R4D_OK;
+}
+
+}  // namespace r4d

@@ -63,7 +63,8 @@ def bench_class(k):
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
     return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
-            "lnf_partial_kernel<8>": "lnf_partial", "lnf_partial_kernel<16>": "lnf_partial", "lnf_partial_kernel<32>": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce",
+            "lnf_partial_kernel<8>": "lnf_partial", "lnf_partial_kernel<16>": "lnf_partial", "lnf_partial_kernel<32>": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce", "gemm_skinny_kernel": "gemm_skinny",
+            "gemm_skinny_epilogue_kernel": "gemm_skinny_epilogue", "decode_attn_kernel": "decode_attention",
             "normalize_rows_kernel": "normalize_rows", "topk_seg_kernel<float>": "topk_seg",
             "merge_topk_kernel": "merge_topk", "jaccard_lds_kernel": "jaccard"}.get(k, k)
 
