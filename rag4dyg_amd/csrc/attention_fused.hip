@@ -456,19 +456,19 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
                 const int sg = s0 + u;
                 if (sg < ngroups) {
                     const float4 pf = *reinterpret_cast<const float4*>(p_frag + 8 * sg);
-                    VBuf<VW> vc[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        vc[c] = vb[u][c];
-                        vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * (sg + VD) + c) * ld3 * 4);   // past the range: zeros
-                    }
+                    // the MFMAs read the prefetch registers DIRECTLY and the refill of the slot follows them in program
+                    // order: copying the slot first ("vc = vb[u]; vb[u].ld()") cost 69 v_mov per 24 MFMAs -- every one
+                    // of them taken from the matrix pipe's issue slots (rocprofv3: 1.74 VALU per MFMA in this kernel)
 #pragma unroll
                     for (int j = 0; j < VW; ++j) {
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0].v[j], pf.x, O[j], 0, 0, 0);
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[1].v[j], pf.y, O[j], 0, 0, 0);
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[2].v[j], pf.z, O[j], 0, 0, 0);
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[3].v[j], pf.w, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[u][0].v[j], pf.x, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[u][1].v[j], pf.y, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[u][2].v[j], pf.z, O[j], 0, 0, 0);
+                        O[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[u][3].v[j], pf.w, O[j], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * (sg + VD) + c) * ld3 * 4);   // past the range: zeros
                 }
             }
         }
