@@ -113,9 +113,14 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
     save_index_file = os.path.join(save_file_path, f'{stem}_index.gen')
     save_score_file = os.path.join(save_file_path, f'{stem}_score.gen')
 
-    # HOT LOOP 2 (:425-474)
-    for batch, score in zip(eval_dataloader, scores):
-        h_egos = model.encode_meanpool(batch.to(device))
+    # HOT LOOP 2 (:425-474).  The query batches are encoded up front in fused groups like the pool (every batch keeps
+    # its own padding, so each row equals ``model.encode_meanpool(batch)`` of the reference's per-batch call).
+    eval_batches = [batch.to(device) for batch in eval_dataloader]
+    query_embeddings = encode_batches(model, eval_batches)
+    row = 0
+    for batch, score in zip(eval_batches, scores):
+        h_egos = query_embeddings[row:row + batch.shape[0]]
+        row += batch.shape[0]
         score = score.to(device)
         _vals, top_idx, dot_products = index.search(h_egos, topk, want_scores=True)
         loss = torch.nn.functional.binary_cross_entropy_with_logits(dot_products, score)      # metric only (:439-441)
