@@ -49,11 +49,50 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
         if (i < nv) y_out[(long long)row * d + lane + 64 * i] = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
 }
 
+// Same, 16 bytes per lane and instruction (d % 256 == 0): lane owns columns 4*lane + 256*i .. +3
+template <int NQ>
+__global__ __launch_bounds__(256) void ln4_kernel(const float* __restrict__ x_in, int rows, int d, const float* __restrict__ w,
+                                                  const float* __restrict__ b, float eps, float* __restrict__ y_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nq = d >> 8;
+    const float4* xr = reinterpret_cast<const float4*>(x_in + (long long)row * d) + lane;
+    float4 v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) v[i] = (i < nq) ? xr[64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) s_ += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s_) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (i < nq) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    float4* yr = reinterpret_cast<float4*>(y_out + (long long)row * d) + lane;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (i < nq) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[lane + 64 * i], bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+            yr[64 * i] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                     (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+        }
+}
+
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
                      hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "layernorm: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (rows <= 0) return R4D_OK;
     ProfScope prof(PK_LAYERNORM, 8.0 * rows * d, s);            // bytes: read x + write y
+    const bool vec = d % 256 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
+    if (vec && d <= 512) hipLaunchKernelGGL(ln4_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
+    else if (vec && d <= 1024) hipLaunchKernelGGL(ln4_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
+    else if (vec) hipLaunchKernelGGL(ln4_kernel<8>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
+    else
     hipLaunchKernelGGL(ln_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
     R4D_CHECK_LAUNCH("layernorm");
     return R4D_OK;

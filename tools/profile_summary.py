@@ -62,6 +62,8 @@ def bench_class(k):
         return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
+    if k.startswith("ln4_kernel"):
+        return "layernorm"
     return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
             "lnf_partial_kernel<8>": "lnf_partial", "lnf_partial_kernel<16>": "lnf_partial", "lnf_partial_kernel<32>": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce", "gemm_skinny_kernel": "gemm_skinny",
             "gemm_skinny_epilogue_kernel": "gemm_skinny_epilogue", "decode_attn_kernel": "decode_attention",
