@@ -19,6 +19,10 @@
 #include <math.h>
 #include "common.h"
 
+#ifndef ATT_DBG
+#define ATT_DBG 0   // tuning aid (tools/kc_ablate.sh attention_fused.hip ATT_DBG n), column-split kernel: bit 0 skips the Q.K^T MFMA loop, bit 1 the P.V loop, bit 2 the two barriers of the softmax
+#endif
+
 namespace r4d {
 
 typedef float f32x16a __attribute__((ext_vector_type(16)));
@@ -386,15 +390,15 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
             for (int r = 0; r < 16; ++r) S[r] = 0.f;
             const int k_soff = st0 * ld3 * 4;
 #pragma unroll
-            for (int u = 0; u < NSTEP; ++u) {
+            for (int u = 0; u < ((ATT_DBG & 1) ? 1 : NSTEP); ++u) {
                 const f32x4a kv = __builtin_bit_cast(f32x4a, kb[u % KD]);
-                if (u + KD < NSTEP)
-                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
                 const float4 qf = *reinterpret_cast<const float4*>(q_frag + 8 * u);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf.x, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf.y, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf.z, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf.w, S, 0, 0, 0);
+                if (u + KD < NSTEP)                    // refill AFTER the slot's MFMAs in program order: no register copies
+                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
             }
             if (key0 + 31 > q0) {                      // the sub-tile touches the diagonal (or runs past T): mask
 #pragma unroll
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 #pragma unroll
             for (int c = 0; c < 4; ++c) vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * u + c) * ld3 * 4);
         if (lh == 0) red[wid * 32 + li] = mt;
-        __syncthreads();
+        if (!(ATT_DBG & 4)) __syncthreads();
         const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
         const float m_new = fmaxf(m_run, m_tile);      // finite from the first super-tile on (key 0 is never masked)
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
             ps += __shfl_xor(ps, 32, 64);
         }
         if (lh == 0) red[128 + wid * 32 + li] = ps;
-        __syncthreads();
+        if (!(ATT_DBG & 4)) __syncthreads();
         l_run = l_run * alpha + ((red[128 + li] + red[160 + li]) + (red[192 + li] + red[224 + li]));
         if (__any(alpha != 1.0f && m_run != -INFINITY)) {
 #pragma unroll
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
         }
-        for (int s0 = 0; s0 < ngroups; s0 += VD) {
+        for (int s0 = 0; s0 < ((ATT_DBG & 2) ? min(ngroups, 1) : ngroups); s0 += VD) {
 #pragma unroll
             for (int u = 0; u < VD; ++u) {
                 const int sg = s0 + u;
