@@ -17,7 +17,7 @@
 //   * three LDS stages, one barrier per k-tile, the next tile's first fragments read before the barrier, global
 //     loads in flight for a whole iteration (see the pipeline comment in the kernel).
 // Per wave and BK = 16 k-tile that leaves 16 MFMAs + 6 ds_read + 2 ds_write + 2 buffer_load + 5 VALU.
-// Measured (MI355X, 157.3 TF peak): 8192^3 143 TF (vendor hipBLASLt 154.6); M=35456 K=512 N=1536 130 TF (the
+// Measured (MI355X, 157.3 TF peak): 8192^3 143 TF (vendor hipBLASLt 154.6); M=35456 K=512 N=1536 137 TF (the
 // previous kernel 102; vendor 141).  XCD-aware grouped tile order and fused bias / gelu_new / residual / scale
 // epilogues as in gemm_f32.hip.
 #include <stdlib.h>
@@ -59,13 +59,28 @@ __device__ __forceinline__ float gelu_new_kc(float x) {
     return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
+typedef float f32x2k __attribute__((ext_vector_type(2)));
+// two outputs at a time: the polynomial part as packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 on gfx950),
+// only exp2 and rcp stay scalar -- 4.5 instead of 7 instructions per element
+__device__ __forceinline__ f32x2k gelu_new_kc2(f32x2k x) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    const f32x2k a = x * x * k1 + k0;
+    const f32x2k w = x * a;
+    f32x2k e;
+    e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);
+    e = e + 1.0f;
+    f32x2k r;
+    r.x = __frcp_rn(e.x); r.y = __frcp_rn(e.y);
+    return x * r;
+}
+
 struct KcShape {
     int M, N, K, lda, ldb, ldc, ldr, nb1, epilogue, causal;
     long long sA0, sA1, sB0, sB1, sC0, sC1;
     float scale_div;
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, int MINW>
+template <int BM, int BN, int BK, int WGM, int WGN, int MINW, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     const float* __restrict__ Ag, const float* __restrict__ Bg, float* __restrict__ Cg,
     const float* __restrict__ biasg, const float* __restrict__ residg, const KcShape g) {
@@ -261,12 +276,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     }
 #endif
     // epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) inside each 32x32 tile.
-    // At K = 512 the epilogue is what separates a launch (130 TF) from the k-loop asymptote (143): building without
-    // the C stores gives +6 %, without the whole epilogue +8 % (gelu: +12 %).  Measured and dropped: swapping the MFMA
-    // operands so that a lane holds four consecutive COLUMNS and storing float4 (8 stores per wave instead of 32: 0 to
-    // -2 %, each store then touches 32 B of 32 rows); staging loads in flight for two iterations instead of one (0).
+    // The epilogue kind is a TEMPLATE parameter and interior tiles take a path without bounds checks: with a runtime
+    // switch and per-element guards the 32 outputs of a lane cost ~2,800 instructions (ten branches each) -- at K = 512
+    // that, not the stores themselves, was the 8 % between a launch (130 TF) and the k-loop asymptote (143).
+    // (Measured and dropped earlier: float4 stores through swapped MFMA operands; two-iteration load prefetch.)
+    const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
+    if (interior) {
+        // byte offsets from the tile's origin: lane part once, the (compile-time row) * ld part on the scalar unit
+        const unsigned lane_c = (unsigned)(((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4);
+        const unsigned lane_r = (unsigned)(((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4);
+        char* ct = reinterpret_cast<char*>(C + (long long)m0 * g.ldc + n0);
+        const char* rt = (EPI == EPI_RESIDUAL) ? reinterpret_cast<const char*>(residg + (long long)m0 * g.ldr + n0) : nullptr;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j) {
+            const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float res[16];
+                if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned o = lane_r + (unsigned)(((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4);
+                        res[r] = *reinterpret_cast<const float*>(rt + o);
+                    }
+                }
+#pragma unroll
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    f32x2k v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
+                    if (EPI == EPI_GELU) v2 = gelu_new_kc2(v2);
+                    else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+                    else if (EPI == EPI_SCALE_DIV) { v2.x = v2.x / g.scale_div; v2.y = v2.y / g.scale_div; }
+                    else if (EPI == EPI_HALF_PLUS) { v2.x = (v2.x + 1.0f) / 2.0f; v2.y = (v2.y + 1.0f) / 2.0f; }
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = r2 + h2;
+                        const float v = h2 ? v2.y : v2.x;
+                        const unsigned o = lane_c + (unsigned)(((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4);
+#if KC_DBG & 16
+                        if (v == 12345.678f)                             // ablation: (almost) never true, keeps v alive
+#endif
+                        *reinterpret_cast<float*>(ct + o) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                                   // edge tiles: clamped reads, guarded stores
         const int col = n0 + wn * WN + j * 32 + li;
         const bool col_ok = col < g.N;
         const int colc = min(col, g.N - 1);
@@ -274,7 +331,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float res[16];
-            if (g.epilogue == EPI_RESIDUAL) {
+            if (EPI == EPI_RESIDUAL) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
@@ -285,12 +342,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bias;
-                if (g.epilogue == EPI_GELU) v = gelu_new_kc(v);
-                else if (g.epilogue == EPI_RESIDUAL) v += res[r];
-                else if (g.epilogue == EPI_SCALE_DIV) v = v / g.scale_div;
-                else if (g.epilogue == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+                if (EPI == EPI_GELU) v = gelu_new_kc(v);
+                else if (EPI == EPI_RESIDUAL) v += res[r];
+                else if (EPI == EPI_SCALE_DIV) v = v / g.scale_div;
+                else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
 #if KC_DBG & 16
-                if (v == 12345.678f)                                     // ablation: (almost) never true, keeps v alive
+                if (v == 12345.678f)
 #endif
                 if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
@@ -303,7 +360,7 @@ static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8
     {128, 128, PK_GEMM_KC_128x128x32, 1, 8, 0.0},    // BK 32, 108 KB, one workgroup per CU: 136 TF asymptote; the BK 16 form
                                                      // wins at every size, so eff 0 = only via R4D_GEMM_KC_TILE=0
     {128, 128, PK_GEMM_KC_128x128x16, 2, 8, 0.91},   // BK 16, three stages = 60 KB: two per CU
-    {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.86},     // BK 16, 45 KB: three per CU
+    {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.87},     // BK 16, 45 KB: three per CU
     {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
 };
 // (measured and dropped: 4 waves with 64x64 wave tiles at BK 16 -- 140 TF asymptote but 121 TF at K = 512; 4 waves at
@@ -323,8 +380,18 @@ static int launch_kc(const GemmArgs& g, int cls, hipStream_t stream) {
     sh.nb1 = g.nb1; sh.epilogue = g.epilogue; sh.causal = g.causal;
     sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
     sh.scale_div = g.scale_div;
-    hipLaunchKernelGGL((gemm_f32_kc_kernel<BM, BN, BK, WGM, WGN, MINW>), dim3(tiles, 1, g.nbatch), dim3(NTHREADS), 0,
-                       stream, g.A, g.B, g.C, g.bias, g.resid, sh);
+#define KC_LAUNCH_(E)                                                                              \
+    hipLaunchKernelGGL((gemm_f32_kc_kernel<BM, BN, BK, WGM, WGN, MINW, E>), dim3(tiles, 1, g.nbatch), dim3(NTHREADS), 0, \
+                       stream, g.A, g.B, g.C, g.bias, g.resid, sh)
+    switch (g.epilogue) {
+        case EPI_NONE: KC_LAUNCH_(EPI_NONE); break;
+        case EPI_GELU: KC_LAUNCH_(EPI_GELU); break;
+        case EPI_RESIDUAL: KC_LAUNCH_(EPI_RESIDUAL); break;
+        case EPI_SCALE_DIV: KC_LAUNCH_(EPI_SCALE_DIV); break;
+        case EPI_HALF_PLUS: KC_LAUNCH_(EPI_HALF_PLUS); break;
+        default: set_error("gemm_f32_kc: unknown epilogue %d", g.epilogue); return R4D_ERR_INVALID;
+    }
+#undef KC_LAUNCH_
     R4D_CHECK_LAUNCH("gemm_f32_kc");
     return R4D_OK;
 }
