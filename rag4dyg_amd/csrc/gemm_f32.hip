@@ -30,7 +30,7 @@ __device__ __forceinline__ float gelu_new_f(float x) {
     // the MFMA issue slots of the co-resident workgroup, the ocml tanhf form (~40) cost 15 % of a c_fc tile.
     // |error| < 3e-7 |x| (checked against the oracle at 1e-5 relative in tests/test_gpu_ops.py).
     const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
-    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
 template <int N>

@@ -56,7 +56,7 @@ __device__ __forceinline__ float gelu_new_kc(float x) {
     // the MFMA issue slots of the co-resident workgroup, the ocml tanhf form (~40) cost 15 % of a c_fc tile.
     // |error| < 3e-7 |x| (checked against the oracle at 1e-5 relative in tests/test_gpu_ops.py).
     const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
-    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
 typedef float f32x2k __attribute__((ext_vector_type(2)));
@@ -70,7 +70,7 @@ __device__ __forceinline__ f32x2k gelu_new_kc2(f32x2k x) {
     e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);
     e = e + 1.0f;
     f32x2k r;
-    r.x = __frcp_rn(e.x); r.y = __frcp_rn(e.y);
+    r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y);
     return x * r;
 }
 

@@ -17,7 +17,7 @@ constexpr int SK_LDX = 33;                              // Xs row stride
 
 __device__ __forceinline__ float gelu_new_sk(float x) {   // same form as gemm_f32_kc.hip
     const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
-    return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
 // partial[ks][m][n] = sum over k in slice ks of x[m,k] * wT[n,k]        (m < 32 padded with zero rows)
