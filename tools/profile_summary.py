@@ -27,6 +27,14 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
                 f"{r['MinNs']},{r['MaxNs']}\n")
 
+def _class_rows():
+    cls = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        c = bench_class(short(r["Name"]))
+        cls[c][0] += int(r["Calls"]); cls[c][1] += float(r["TotalDurationNs"])
+    return cls
+
+
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -57,7 +65,7 @@ def bench_class(k):
     m = re.match(r"gemm_f32_kernel<(\d+), (\d+), \d+, \d+, \d+, (false|true)>", k)
     if m:
         return f"gemm_f32_{m.group(1)}x{m.group(2)}_{'nt' if m.group(3) == 'true' else 'nn'}"
-    m = re.match(r"gemm_f32_kc_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+>", k)
+    m = re.match(r"gemm_f32_kc_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+(?:, \d+)?>", k)       # (+ epilogue kind)
     if m:
         return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
@@ -71,8 +79,29 @@ def bench_class(k):
             "merge_topk_kernel": "merge_topk", "jaccard_lds_kernel": "jaccard"}.get(k, k)
 
 
-traffic = {bench_class(k): v for k, v in traffic.items() if not k.startswith(("at::", "__amd"))}
+by_class = collections.defaultdict(lambda: collections.defaultdict(list))
+for k, cs in agg.items():
+    if k.startswith(("at::", "__amd")):
+        continue
+    for c, v in cs.items():
+        by_class[bench_class(k)][c] += v
+traffic = {}
+for k, cs in by_class.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        traffic[k] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_kib_raw": fe, "write_kib": wr}
+        if "TCC_HIT_sum" in cs:
+            h, m_ = sum(cs["TCC_HIT_sum"]), sum(cs["TCC_MISS_sum"])
+            traffic[k]["l2_hit_rate"] = h / max(h + m_, 1)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
+            traffic[k]["mfma_pipe_util"] = (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0) / (sum(cs["GRBM_GUI_ACTIVE"]) / 8.0)
 # what tools/profile_bench.sh ran: bench.py only attaches these figures to a line of the same workload
+with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "a") as f:
+    f.write("# the same trace aggregated per bench.py kernel class (template variants of one tile summed)\n")
+    f.write("class,calls,total_ns,avg_ns\n")
+    for c, (n, tot) in sorted(_class_rows().items(), key=lambda kv: -kv[1][1]):
+        if not c.startswith(("at::", "__amd")):
+            f.write(f"\"{c}\",{n},{tot:.0f},{tot / max(n, 1):.0f}\n")
 traffic["_workload"] = {"shape": "UCI_13", "batches_per_step": 4, "n_gpus": 1,
                         "command": "bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
