@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
         for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const int qidx = q0 + li;
-    const bool pow2_scale = (HD == 64 || HD == 256);
     const float inv_scale = 1.0f / scale;
 
     for (int kt = wid; kt <= qt; kt += 4) {
@@ -163,7 +162,9 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
             const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             // the reference DIVIDES by sqrt(hd) (:143); for a power-of-two scale (hd = 64, 256) the reciprocal
             // multiply is the same value bit for bit and saves a ~12-instruction f32 division per logit
-            const float s = pow2_scale ? S[r] * inv_scale : S[r] / scale;
+            // multiply by the rounded reciprocal: the IEEE division is ~10 instructions per logit (head_dim 32 / 96, where
+            // sqrt(hd) is not a power of two, differ from the reference's division by <= 1 ulp of the logit)
+            const float s = S[r] * inv_scale;
             S[r] = (key <= qidx) ? s : -INFINITY;
             mt = fmaxf(mt, S[r]);
         }
