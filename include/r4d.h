@@ -134,9 +134,9 @@ int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int3
                       float* logits_d, void* stream);
 
 /* Attention implementation switch: -1 = auto (default) / 1 = fused flash-style kernels wherever instantiated
- * (head_dim in {32,64,96}: key-split kernel; {128,256}: column-split kernel; scores never leave the CU),
+ * (head_dim in {32,64}: key-split kernel; {96,128,256}: column-split kernel; scores never leave the CU),
  * 0 = three launches (batched Q.K^T GEMM, causal softmax, P.V GEMM; also the fallback for other head dims),
- * 2 = fused with the key-split kernel forced at head_dim 128/256 (A/B tuning).  Same results to fp32 rounding. */
+ * 2 = fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning).  Same results to fp32 rounding. */
 int r4d_set_attention_fused(int32_t mode);
 
 /* --- single ops, exported for per-op parity tests (same kernels the encoder launches) --- */

@@ -317,11 +317,12 @@ struct VBuf<2> {
 template <int HD>
 __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __restrict__ qkv, const AttnGroups G, int d, int H, int ntq,
                                                                float qscale, float* __restrict__ out) {
-    constexpr int CW = HD / 4;                         // head columns owned by one wave
+    constexpr int CW = HD >= 128 ? HD / 4 : 32;        // head columns owned by one wave (hd 96: three waves own 32 each,
+    constexpr int NPV = HD / CW;                       //   the fourth only takes part in Q.K^T and the softmax)
     constexpr int VW = CW / 32;                        // floats per lane per V load = O^T tiles per wave (1 or 2)
     constexpr int NSTEP = HD / 8;                      // 16-byte K loads (and Q reads) per key row
     constexpr int LDQ = HD + 4, LDP = 132;             // row strides (floats): 16-lane b128 groups hit 16 distinct slots
-    constexpr int KD = 8;                              // K loads in flight per lane
+    constexpr int KD = NSTEP < 8 ? NSTEP : 8;          // K loads in flight per lane
     constexpr int VD = 3;                              // V key-groups (8 keys) in flight
     extern __shared__ float lds[];
     float* Qs = lds;                                   // [32][LDQ]  Q * log2(e)/sqrt(hd)
@@ -415,10 +416,12 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
         const int ngroups = (min(128, key_limit - st0) + 7) >> 3;      // 8-key groups of the P.V phase, wave-uniform
         const int v_soff = st0 * ld3 * 4;
         VBuf<VW> vb[VD][4];
+        if (wid < NPV) {
 #pragma unroll
-        for (int u = 0; u < VD; ++u)
+            for (int u = 0; u < VD; ++u)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * u + c) * ld3 * 4);
+                for (int c = 0; c < 4; ++c) vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * u + c) * ld3 * 4);
+        }
         if (lh == 0) red[wid * 32 + li] = mt;
         if (!(ATT_DBG & 4)) __syncthreads();
         const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
         }
-        for (int s0 = 0; s0 < ((ATT_DBG & 2) ? min(ngroups, 1) : ngroups); s0 += VD) {
+        for (int s0 = 0; s0 < ((ATT_DBG & 2) ? min(ngroups, 1) : (wid < NPV ? ngroups : 0)); s0 += VD) {
 #pragma unroll
             for (int u = 0; u < VD; ++u) {
                 const int sg = s0 + u;
@@ -483,13 +486,15 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
     constexpr int LDO = HD + 1;
     {
         const float inv = 1.0f / l_run;
+        if (wid < NPV) {
 #pragma unroll
-        for (int j = 0; j < VW; ++j)
+            for (int j = 0; j < VW; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = wid * CW + VW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + j;
-                lds[li * LDO + c] = O[j][r] * inv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int c = wid * CW + VW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + j;
+                    lds[li * LDO + c] = O[j][r] * inv;
+                }
+        }
     }
     __syncthreads();
     for (int q = wid; q < 32; q += 4) {
@@ -570,7 +575,8 @@ int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const 
     switch (hd) {
         case 32: return launch_hd<32>(qkv, G, Tmax, flop, H, d, out, s);
         case 64: return launch_hd<64>(qkv, G, Tmax, flop, H, d, out, s);
-        case 96: return launch_hd<96>(qkv, G, Tmax, flop, H, d, out, s);
+        case 96: return g_attention_variant == 1 ? launch_hd<96>(qkv, G, Tmax, flop, H, d, out, s)
+                                                 : launch_colsplit<96>(qkv, G, Tmax, flop, H, d, out, s);
         case 128: return g_attention_variant == 1 ? launch_hd<128>(qkv, G, Tmax, flop, H, d, out, s)
                                                   : launch_colsplit<128>(qkv, G, Tmax, flop, H, d, out, s);
         case 256: return g_attention_variant == 1 ? launch_hd<256>(qkv, G, Tmax, flop, H, d, out, s)

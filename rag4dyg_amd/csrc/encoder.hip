@@ -41,7 +41,7 @@ int g_attention_fused = -1;           // -1 auto (by head_dim), 0 three launches
 
 static int attention(const float* qkv, int B, int T, int H, int d, float* a_out, float* scores, hipStream_t s) {
     // Measured on MI355X (tools/attn_bench.py, B=128, T=128..300): the fused kernels are 1.15-2.7x faster than the
-    // three-launch form at every instantiated head_dim (key-split kernel for hd <= 96, column-split for 128 / 256),
+    // three-launch form at every instantiated head_dim (key-split kernel for hd 32 / 64, column-split for 96 / 128 / 256),
     // so auto == fused; head dims without an instantiation fall through to the GEMM form.
     const bool fused = g_attention_fused != 0;
     if (fused) {
@@ -125,7 +125,7 @@ extern "C" {
 
 int r4d_abi_version(void) { return R4D_ABI_VERSION; }
 int r4d_set_attention_fused(int32_t mode) {
-    // mode 2: fused with the key-split kernel forced at head_dim 128/256 (A/B tuning); 1: fused (column-split there)
+    // mode 2: fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning); 1: fused (column-split there)
     g_attention_variant = (mode == 2) ? 1 : 0;
     g_attention_fused = mode < 0 ? -1 : (mode != 0);
     return R4D_OK;
