@@ -16,8 +16,8 @@
 //     and the k-tile in the SCALAR offset;
 //   * three LDS stages, one barrier per k-tile, the next tile's first fragments read before the barrier, global
 //     loads in flight for a whole iteration (see the pipeline comment in the kernel).
-// Per wave and BK = 16 k-tile that leaves 16 MFMAs + 6 ds_read + 2 ds_write + 2 buffer_load + 5 VALU.
-// Measured (MI355X, 157.3 TF peak): 8192^3 143 TF (vendor hipBLASLt 154.6); M=35456 K=512 N=1536 137 TF (the
+// Per wave and BK = 16 k-tile that leaves 16 MFMAs + 6 ds_read + 2 ds_write + 2 buffer_load and NO VALU.
+// Measured (MI355X, 157.3 TF peak): 8192^3 148 TF (vendor hipBLASLt 154.6); M=35456 K=512 N=1536 137 TF (the
 // previous kernel 102; vendor 141).  XCD-aware grouped tile order and fused bias / gelu_new / residual / scale
 // epilogues as in gemm_f32.hip.
 #include <stdlib.h>
@@ -244,11 +244,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                         \
         KC_DBG_BARRIER(__syncthreads();)                                                           \
     }
-    // (rolled loop, runtime stages: three v_add per iteration.  Unrolling by three for immediate LDS offsets measured
-    // 4-5 % SLOWER with if-regions for the remainder, and with breaks hipcc renames the accumulators per exit and
-    // spills 170 registers.)
-    int cur = 0, nxt = 1, wr = 2;                                    // stages of k-tiles kt, kt+1, kt+2
-    for (int kt = 0; kt < nkt; ++kt) {
+    // The loop is unrolled by three so that the stages are compile-time constants (every LDS address = base register +
+    // immediate: no VALU at all in the body) and the 0..2 remaining k-tiles run through a rolled copy with runtime stages.
+    // 8192^3: 142.7 -> 147.6 TF.  (Two earlier forms of the same idea LOST: if-regions for the remainder inside the
+    // unrolled body, -4 %; breaks out of it, accumulators renamed per exit and 170 registers spilled.)
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 3) {                                  // compile-time stages: LDS addresses are base + immediate
+        KC_ITER(0, 1, 2)
+        { const int kt0_ = kt; (void)kt0_; }
+        { ++kt; KC_ITER(1, 2, 0) }
+        { ++kt; KC_ITER(2, 0, 1) }
+        kt -= 2;
+    }
+    int cur = 0, nxt = 1, wr = 2;                                    // (kt is a multiple of 3 here) remaining 0..2 k-tiles
+    for (; kt < nkt; ++kt) {
         KC_ITER(cur, nxt, wr)
         const int t_ = cur; cur = nxt; nxt = wr; wr = t_;
     }
@@ -359,8 +368,8 @@ struct KcTile { int bm, bn, cls, blocks_per_cu, waves_per_block; double eff; };
 static const KcTile kKc[] = {   // eff = measured k-loop asymptote / 157.3 TF (8192^3, tools/gemm_bench.py shape 14)
     {128, 128, PK_GEMM_KC_128x128x32, 1, 8, 0.0},    // BK 32, 108 KB, one workgroup per CU: 136 TF asymptote; the BK 16 form
                                                      // wins at every size, so eff 0 = only via R4D_GEMM_KC_TILE=0
-    {128, 128, PK_GEMM_KC_128x128x16, 2, 8, 0.91},   // BK 16, three stages = 60 KB: two per CU
-    {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.87},     // BK 16, 45 KB: three per CU
+    {128, 128, PK_GEMM_KC_128x128x16, 2, 8, 0.94},   // BK 16, three stages = 60 KB: two per CU
+    {128, 64, PK_GEMM_KC_128x64x16, 3, 4, 0.88},     // BK 16, 45 KB: three per CU
     {64, 64, PK_GEMM_KC_64x64x32, 2, 4, 0.82},       // BK 32, 54 KB: two per CU
 };
 // (measured and dropped: 4 waves with 64x64 wave tiles at BK 16 -- 140 TF asymptote but 121 TF at K = 512; 4 waves at
