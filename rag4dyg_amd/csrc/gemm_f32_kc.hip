@@ -291,11 +291,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
     // (Measured and dropped earlier: float4 stores through swapped MFMA operands; two-iteration load prefetch.)
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
     if (interior) {
-        // byte offsets from the tile's origin: lane part once, the (compile-time row) * ld part on the scalar unit
-        const unsigned lane_c = (unsigned)(((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4);
-        const unsigned lane_r = (unsigned)(((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4);
-        char* ct = reinterpret_cast<char*>(C + (long long)m0 * g.ldc + n0);
-        const char* rt = (EPI == EPI_RESIDUAL) ? reinterpret_cast<const char*>(residg + (long long)m0 * g.ldr + n0) : nullptr;
+        // buffer stores / loads from the tile's origin: the lane's byte offset is computed once (voffset), the
+        // (compile-time row) * ld part lives on the scalar unit (soffset) -- one VALU instruction per element (the bias add)
+        const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
+        const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
@@ -304,10 +308,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
                 float res[16];
                 if (EPI == EPI_RESIDUAL) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned o = lane_r + (unsigned)(((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4);
-                        res[r] = *reinterpret_cast<const float*>(rt + o);
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
                 }
 #pragma unroll
                 for (int r2 = 0; r2 < 16; r2 += 2) {
@@ -320,11 +323,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f32_kc_kernel(
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = r2 + h2;
                         const float v = h2 ? v2.y : v2.x;
-                        const unsigned o = lane_c + (unsigned)(((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4);
 #if KC_DBG & 16
                         if (v == 12345.678f)                             // ablation: (almost) never true, keeps v alive
 #endif
-                        *reinterpret_cast<float*>(ct + o) = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
+                                                              ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
                     }
                 }
             }
