@@ -20,7 +20,7 @@
 #include "common.h"
 
 #ifndef ATT_DBG
-#define ATT_DBG 0   // tuning aid (tools/kc_ablate.sh attention_fused.hip ATT_DBG n), column-split kernel: bit 0 skips the Q.K^T MFMA loop, bit 1 the P.V loop, bit 2 the two barriers of the softmax
+#define ATT_DBG 0   // tuning aid (tools/kc_ablate.sh attention_fused.hip ATT_DBG n), column-split kernel: bit 0 skips the Q.K^T MFMA loop, bit 1 the P.V loop, bit 2 the two barriers of the softmax, bit 3 the K loads after the first eight, bit 4 the V loads after the first three groups
 #endif
 
 namespace r4d {
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf.y, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf.z, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf.w, S, 0, 0, 0);
-                if (u + KD < NSTEP)                    // refill AFTER the slot's MFMAs in program order: no register copies
+                if (!(ATT_DBG & 8) && u + KD < NSTEP)  // refill AFTER the slot's MFMAs in program order: no register copies
                     kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
             }
             if (key0 + 31 > q0) {                      // the sub-tile touches the diagonal (or runs past T): mask
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
         m_run = m_new;
         // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P[q][key], 8 keys per group:
         // lane half lh handles keys 8s + 4lh + c (c = 0..3) -- the four components of its ds_read_b128 of P
-        if (st0 + 128 + wid * 32 < key_limit) {         // this wave's K rows of the next super-tile
+        if (!(ATT_DBG & 8) && st0 + 128 + wid * 32 < key_limit) {         // this wave's K rows of the next super-tile
             const int kn_soff = (st0 + 128) * ld3 * 4;
 #pragma unroll
             for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * (sg + VD) + c) * ld3 * 4);   // past the range: zeros
+                        if (!(ATT_DBG & 16)) vb[u][c].ld(v_rsrc, v_voff, v_soff + (8 * (sg + VD) + c) * ld3 * 4);   // past the range: zeros
                 }
             }
         }
