@@ -3,7 +3,7 @@
 // With a handful of rows a Conv1D is a WEIGHT STREAM (K*N*4 bytes read once, ~0 reuse): the tiled kernels run it as
 // N/64 lone tiles with K-long serial loops (12-48 busy CUs, 33 us per projection at d = 768 -- 0.8 ms of a 1.1 ms decode
 // step).  This kernel is the pool-scan design (score.hip) pointed at a weight matrix: the rows of x take the place of
-// the queries (k-major in LDS, conflict-free fill and reads), every wavefront owns a 32-row tile of wT and streams it
+// the queries (row-major in LDS, one ds_read_b128 per four MFMAs), every wavefront owns a 32-row tile of wT and streams it
 // with 16-byte loads, 16 loads in flight, exact-f32 MFMA 32x32x2 -- and K is SPLIT over gridDim.y slices of 256 so that
 // a 768 x 768 projection still spreads over 72 wavefronts.  Slice partials go to a caller-provided scratch and are
 // added in slice order by the epilogue kernel (bias / gelu_new / residual): deterministic, no atomics.
@@ -13,7 +13,7 @@ namespace r4d {
 
 typedef float f32x16g __attribute__((ext_vector_type(16)));
 constexpr int SK_KC = 256;                              // k-slice per workgroup
-constexpr int SK_LDX = 33;                              // Xs row stride
+constexpr int SK_LDX = SK_KC + 4;                       // Xs row stride (floats): conflict-free b128 reads
 
 __device__ __forceinline__ float gelu_new_sk(float x) {   // same form as gemm_f32_kc.hip
     const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
@@ -23,15 +23,15 @@ __device__ __forceinline__ float gelu_new_sk(float x) {   // same form as gemm_f
 // partial[ks][m][n] = sum over k in slice ks of x[m,k] * wT[n,k]        (m < 32 padded with zero rows)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ x, const float* __restrict__ wT, int M,
                                                           int N, int K, float* __restrict__ partial) {
-    __shared__ float Xs[SK_KC * SK_LDX];               // [k][33]
+    __shared__ __attribute__((aligned(16))) float Xs[32 * SK_LDX];     // [32 rows][SK_KC + 4], k contiguous
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int k0 = blockIdx.y * SK_KC;
-    for (int m = 0; m < 32; ++m) {
+    for (int m = wid; m < 32; m += 4) {                // one x row per wave and trip, 16 bytes per lane
         const bool ok = m < M;
-        const float* src = x + (long long)min(m, M - 1) * K + k0;
-        const float v = src[tid];                      // SK_KC == blockDim.x
-        Xs[tid * SK_LDX + m] = ok ? v : 0.f;
+        float4 v = reinterpret_cast<const float4*>(x + (long long)min(m, M - 1) * K + k0)[lane];      // SK_KC / 4 == 64
+        if (!ok) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+        *reinterpret_cast<float4*>(Xs + m * SK_LDX + 4 * lane) = v;
     }
     __syncthreads();
     const int tile = blockIdx.x * 4 + wid;
@@ -50,15 +50,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];          // the whole slice of this row: 32 loads in flight
+    const float* xfrag = Xs + li * SK_LDX + 16 * lh;   // + 32g + 4u: ONE ds_read_b128 per four MFMAs
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* xa = Xs + (32 * g + 16 * lh + 4 * u) * SK_LDX + li;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[0], b[g][u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[SK_LDX], b[g][u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * SK_LDX], b[g][u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[3 * SK_LDX], b[g][u].w, acc, 0, 0, 0);
+            const float4 xa = *reinterpret_cast<const float4*>(xfrag + 32 * g + 4 * u);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, b[g][u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, b[g][u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, b[g][u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, b[g][u].w, acc, 0, 0, 0);
         }
     if (row < N) {
         float* dst = partial + (long long)blockIdx.y * 32 * N;

@@ -3,6 +3,7 @@
 // Reference: train/train_retriever.py:433-438 (normalise, matmul, (x+1)/2) and :357-358,461-467 (argsort).
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace r4d {
@@ -36,63 +37,68 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 constexpr int SCAN_U = 8;
 
-constexpr int SCAN_LDQ = 33;                          // Qs row stride: conflict-free fill AND fragment reads
-
-__global__ __launch_bounds__(256) void pool_scan_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
+// Q tile layout in LDS: ROW-major [32 queries][d + 4] (k contiguous).  A lane's MFMA A operands for four consecutive
+// MFMAs are then ONE ds_read_b128 (16-lane groups hit 16 distinct 16-byte slots: stride 4 banks), matching the four k
+// of its 16-byte pool load; the k-major layout needed a ds_read2_b32 + lgkmcnt(0) wait in front of every MFMA pair.
+template <int NW>                                    // wavefronts per workgroup (they share the Q tile)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void pool_scan_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
                                                         int Q, int N, int d, float* __restrict__ scores) {
-    extern __shared__ float Qs[];                       // [d][33]
+    extern __shared__ float Qs[];                       // [32][d + 4]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.y * 32;
-    for (int q = 0; q < 32; ++q) {
+    const int ldq = d + 4;
+    for (int q = wid; q < 32; q += NW) {                // one query row per wave and trip, 16-byte pieces
         const bool ok = q0 + q < Q;
-        const float* src = qhat + (long long)min(q0 + q, Q - 1) * d;
-        for (int k = tid; k < d; k += 256) {
-            const float v = src[k];
-            Qs[k * SCAN_LDQ + q] = ok ? v : 0.f;
+        const float4* src = reinterpret_cast<const float4*>(qhat + (long long)min(q0 + q, Q - 1) * d);
+        for (int k4 = lane; k4 < d / 4; k4 += 64) {
+            float4 v = src[k4];
+            if (!ok) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+            *reinterpret_cast<float4*>(Qs + q * ldq + 4 * k4) = v;
         }
     }
     __syncthreads();
     const int ntiles = (N + 31) / 32;
     // k order: lane half h of row j owns the 64-byte halves [32g + 16h, 32g + 16h + 16) of the row, i.e. the lane
-    // pair (j,0),(j,1) consumes each 128-byte line of the row at once (four 16-byte loads per lane per line) instead
-    // of revisiting it over four loop trips; component c of load u of group g is k = 32g + 16h + 4u + c on BOTH
-    // operands.  d % 32 == 0 here (r4d_score_topk_f32 falls back to the GEMM otherwise).
+    // pair (j,0),(j,1) consumes each 128-byte line of the row at once (four 16-byte loads per lane per line);
+    // component c of load u of group g is k = 32g + 16h + 4u + c on BOTH operands.  d % 32 == 0 here
+    // (r4d_score_topk_f32 falls back to the GEMM otherwise).
     const int ngroups = d / 32;
-    for (int t = blockIdx.x * 4 + wid; t < ntiles; t += gridDim.x * 4) {
+    const float* qfrag = Qs + li * ldq + 16 * lh;       // + 32g + 4u
+    for (int t = blockIdx.x * NW + wid; t < ntiles; t += gridDim.x * NW) {
         const int row = t * 32 + li;
         const float4* __restrict__ prow =
             reinterpret_cast<const float4*>(pool + (long long)min(row, N - 1) * d) + 4 * lh;   // clamped: always valid
         f32x16s acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // two groups (2 x 64 B per lane) per buffer, ping-pong: 16 loads = 256 B per lane in flight
-        float4 b0[8], b1[8];
+        // NB groups (NB x 64 B per lane) in flight; the slot of group g is refilled with group g + NB right after its
+        // MFMAs (program order: no register copies).  NB = 3 and no Q look-ahead keep the kernel under 128 registers:
+        // four waves per SIMD (two 8-wave workgroups per CU) hide more latency than a deeper per-wave queue.
+        constexpr int NB = NW == 8 ? 3 : 4;
+        float4 b[NB][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b0[u] = prow[8 * min(u >> 2, ngroups - 1) + (u & 3)];
-        for (int g0 = 0; g0 < ngroups; g0 += 4) {
+        for (int s_ = 0; s_ < NB; ++s_)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) b1[u] = prow[8 * min(g0 + 2 + (u >> 2), ngroups - 1) + (u & 3)];
+            for (int u = 0; u < 4; ++u) b[s_][u] = prow[8 * min(s_, ngroups - 1) + u];
+        for (int g0 = 0; g0 < ngroups; g0 += NB) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (g0 + (u >> 2) < ngroups) {
-                    const float* qa = Qs + (32 * (g0 + (u >> 2)) + 16 * lh + 4 * (u & 3)) * SCAN_LDQ + li;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b0[u].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b0[u].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b0[u].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[3 * SCAN_LDQ], b0[u].w, acc, 0, 0, 0);
-                }
-            }
+            for (int s_ = 0; s_ < NB; ++s_) {
+                const int g = g0 + s_;
+                if (g < ngroups) {                      // wave-uniform
+                    float4 qa[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) b0[u] = prow[8 * min(g0 + 4 + (u >> 2), ngroups - 1) + (u & 3)];
+                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4*>(qfrag + 32 * g + 4 * u);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (g0 + 2 + (u >> 2) < ngroups) {
-                    const float* qa = Qs + (32 * (g0 + 2 + (u >> 2)) + 16 * lh + 4 * (u & 3)) * SCAN_LDQ + li;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0], b1[u].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[SCAN_LDQ], b1[u].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * SCAN_LDQ], b1[u].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[3 * SCAN_LDQ], b1[u].w, acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].x, b[s_][u].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].y, b[s_][u].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].z, b[s_][u].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].w, b[s_][u].w, acc, 0, 0, 0);
+                    }
+                    const int gl = min(g + NB, ngroups - 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[s_][u] = prow[8 * gl + u];
                 }
             }
         }
@@ -107,11 +113,13 @@ __global__ __launch_bounds__(256) void pool_scan_kernel(const float* __restrict_
 }
 
 static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, int d, float* scores, hipStream_t s) {
-    const size_t lds = (size_t)d * SCAN_LDQ * sizeof(float);
+    const size_t lds = (size_t)32 * (d + 4) * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute((const void*)pool_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)pool_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    140 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)pool_scan_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     140 * 1024) != hipSuccess) {
                 set_error("pool_scan: cannot raise dynamic LDS limit");
                 return R4D_ERR_HIP;
@@ -121,10 +129,17 @@ static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, 
     }
     const int ntiles = cdiv(N, 32);
     const int blocks_per_cu = lds > 80 * 1024 ? 1 : 2;
-    const int gx = max(1, min(cdiv(ntiles, 4), 256 * blocks_per_cu));
     // algorithmic bytes (SURVEY 8d B_score): pool read once + queries + score rows out
     ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
-    hipLaunchKernelGGL(pool_scan_kernel, dim3(gx, cdiv(Q, 32)), dim3(256), lds, s, qhat, pool, Q, N, d, scores);
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("R4D_SCAN_WAVES"); nw = e ? atoi(e) : 8; }   // tuning aid: 4 or 8
+    if (nw == 8 && ntiles >= 8 * 256) {
+        const int gx = max(1, min(cdiv(ntiles, 8), 256 * blocks_per_cu));
+        hipLaunchKernelGGL(pool_scan_kernel<8>, dim3(gx, cdiv(Q, 32)), dim3(512), lds, s, qhat, pool, Q, N, d, scores);
+    } else {
+        const int gx = max(1, min(cdiv(ntiles, 4), 256 * blocks_per_cu));
+        hipLaunchKernelGGL(pool_scan_kernel<4>, dim3(gx, cdiv(Q, 32)), dim3(256), lds, s, qhat, pool, Q, N, d, scores);
+    }
     R4D_CHECK_LAUNCH("pool_scan");
     return R4D_OK;
 }
