@@ -128,6 +128,51 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
                              int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
                              void* stream);
 
+/*
+ * Greedy decoding with the loop state ON THE DEVICE -- the reference's greedy loops (utils/Evaluation_SimpleDyG.py:126-145,
+ * utils/Evaluation_generator.py:153-175: argmax of the last position's logits, append, stop rules) as one launch
+ * sequence per token with no host round trip, so that a step can be captured once and replayed as a HIP graph
+ * (a cached step is launch-latency-bound: ~70 small kernels).  One step =
+ *     logits = last . wte^T  ->  per sequence: v = argmax (lowest index among equal maxima);
+ *     if active: out_tokens[b][gen_len++] = v;  active &= !(gen_len >= max_gen || v in eos || gen_len >= out_cap
+ *                                                          || lens + 1 >= min(len_limit, t_cap))
+ *     next = v;  pos = active ? lens : 0;  lens += active        (finished sequences keep their slot and are ignored)
+ *     last = r4d_gpt2_decode_step_f32(ids = next, pos)
+ * All arrays are device memory owned by the caller and must stay valid (and in place) for the life of a graph:
+ *   last_d [B,d] f32 in/out (ln_f row of the newest position)   logits_d [B,V] f32 scratch (the step's logits)
+ *   next_d [B] i64   lens_d [B] i32 (positions cached; in/out)   pos_d [B] i32   active_d [B] i32 (in/out, 1 = running)
+ *   gen_len_d [B] i32 (in/out)   out_tokens_d [B,out_cap] i32   params_d int32[8] (below)
+ */
+typedef struct r4d_greedy_state {
+    float* last_d;
+    float* logits_d;
+    int64_t* next_d;
+    int32_t* lens_d;
+    int32_t* pos_d;
+    int32_t* active_d;
+    int32_t* gen_len_d;
+    int32_t* out_tokens_d;
+    const int32_t* params_d; /* device int32[8], read every step (so one captured graph serves every batch):
+                              *   [0] max_gen    stop after this many generated tokens
+                              *   [1] len_limit  stop once lens + 1 >= min(len_limit, t_cap) (the cache row written next is lens)
+                              *   [2] n_eos 0..4, [3..6] eos ids: stop after generating any of them;  [7] reserved */
+    int32_t out_cap;         /* row length of out_tokens_d */
+} r4d_greedy_state;
+typedef struct r4d_decode_graph r4d_decode_graph;      /* opaque: a captured, instantiated greedy step */
+
+size_t r4d_gpt2_greedy_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B);
+/* one step, launched kernel by kernel on `stream` */
+int r4d_gpt2_greedy_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_greedy_state* st,
+                             float* kv_cache_d, int32_t B, int32_t t_cap, void* workspace_d, size_t workspace_bytes,
+                             void* stream);
+/* capture the same step into a HIP graph (nothing runs); every pointer reachable from the arguments is baked in */
+int r4d_gpt2_greedy_graph_create(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_greedy_state* st,
+                                 float* kv_cache_d, int32_t B, int32_t t_cap, void* workspace_d, size_t workspace_bytes,
+                                 r4d_decode_graph** out_graph);
+/* replay it n_steps times on `stream` (asynchronous) */
+int r4d_decode_graph_launch(r4d_decode_graph* graph, int32_t n_steps, void* stream);
+void r4d_decode_graph_destroy(r4d_decode_graph* graph);
+
 /* lm_logits = hidden @ wte^T  (tied lm_head, modeling_gpt2.py:585; modeling_rag.py:675).
  * hidden_d [M,d], wte_d [V,d] -> logits_d [M,V]. */
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d,

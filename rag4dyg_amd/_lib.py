@@ -27,6 +27,11 @@ class GPT2LayerC(Structure):
                                          "c_attn_wT", "attn_proj_wT", "c_fc_wT", "mlp_proj_wT")]
 
 
+class GreedyStateC(Structure):
+    _fields_ = [(n, c_void_p) for n in ("last_d", "logits_d", "next_d", "lens_d", "pos_d", "active_d", "gen_len_d",
+                                         "out_tokens_d", "params_d")] + [("out_cap", c_int32)]
+
+
 class GPT2WeightsC(Structure):
     _fields_ = [("wte", c_void_p), ("wpe", c_void_p), ("ln_f_w", c_void_p), ("ln_f_b", c_void_p),
                 ("layers", POINTER(GPT2LayerC))]
@@ -47,6 +52,13 @@ PROTOTYPES = {
     "r4d_gpt2_decode_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32]),
     "r4d_gpt2_decode_step_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), _P, _P, _P, _P, c_int32, c_int32,
                                            _P, _P, c_size_t, _P]),
+    "r4d_gpt2_greedy_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32]),
+    "r4d_gpt2_greedy_step_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GreedyStateC), _P, c_int32,
+                                           c_int32, _P, c_size_t, _P]),
+    "r4d_gpt2_greedy_graph_create": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GreedyStateC), _P,
+                                               c_int32, c_int32, _P, c_size_t, POINTER(_P)]),
+    "r4d_decode_graph_launch": (c_int32, [_P, c_int32, _P]),
+    "r4d_decode_graph_destroy": (None, [_P]),
     "r4d_lm_logits_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_layernorm_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),
     "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),

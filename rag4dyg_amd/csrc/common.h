@@ -18,6 +18,15 @@ void set_error(const char* fmt, ...);
         }                                          \
     } while (0)
 
+#define R4D_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            r4d::set_error("%s: %s", #call, hipGetErrorString(e_));                    \
+            return R4D_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
 #define R4D_CHECK_LAUNCH(name)                                                         \
     do {                                                                               \
         hipError_t e_ = hipGetLastError();                                             \
@@ -31,7 +40,7 @@ void set_error(const char* fmt, ...);
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
     PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
-    PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN,
+    PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN, PK_GREEDY_ADVANCE,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
 extern bool g_prof_on;
@@ -69,8 +78,10 @@ int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given a
 // gemm_skinny.hip: M <= 32 rows against a k-contiguous weight [N,K], K % 256 == 0 (decode step); split-K partials in scratch
 bool gemm_skinny_supported(int M, int K, int N);
 size_t gemm_skinny_scratch_floats(int K, int N);
+bool gemm_skinny_fuses_ln(int M, int K, int N);       // y = epilogue(LayerNorm(x) . wT^T + bias) in one launch
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
-                       int epilogue, float* y, float* scratch, hipStream_t s);
+                       int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
+                       const float* ln_b = nullptr, float ln_eps = 0.f);
 
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
@@ -94,6 +105,13 @@ int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32
 // one query per (sequence, head) against the cached keys/values; writes the new K/V row into the cache first
 int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t* pos, int B, int t_cap, int H, int d,
                             float* out, hipStream_t s);
+// device-side greedy loop state (encoder_ops.hip: greedy_advance_kernel; r4d.h: r4d_greedy_state)
+struct GreedyState {
+    int64_t* next; int32_t* lens; int32_t* pos; int32_t* active; int32_t* gen_len; int32_t* out_tokens;
+    const int32_t* params;       // device int32[8]: max_gen, len_limit, n_eos, eos[0..3], 0
+    int out_cap, t_cap;
+};
+int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s);
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
 int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,

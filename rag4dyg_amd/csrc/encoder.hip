@@ -319,21 +319,125 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         const r4d_gpt2_layer& L = w->layers[l];
         R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
                     "gpt2 decode: null weight in layer %d", l);
+        // M <= 32 and d in {512, 768}: LayerNorm runs inside the projection that reads it (gemm_skinny8_kernel) -- x stays
+        // the un-normalised residual stream and two launches per layer disappear
+        const bool fuse_ln = sk && L.c_attn_wT && L.c_fc_wT && gemm_skinny_fuses_ln(B, d, 3 * d);
         if (l == 0)
             rc = launch_embed_pos_layernorm(ids_d, inputs_embeds_d, pos_d, w->wte, w->wpe, cfg->vocab, cfg->n_positions,
                                             t_cap, B, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s);
-        else
+        else if (!fuse_ln)
             rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
         if (rc) return rc;
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s, sk))) return rc;
+        if (fuse_ln && l > 0)
+            rc = launch_gemm_skinny(ws.x, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, L.ln_1_w,
+                                    L.ln_1_b, cfg->ln_eps);
+        else
+            rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s, sk);
+        if (rc) return rc;
         if ((rc = launch_decode_attention(ws.qkv, kv_cache_d + (size_t)l * layer_stride, pos_d, B, t_cap, H, d, ws.att, s)))
             return rc;
         if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
-        if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
-        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s, sk))) return rc;
+        if (fuse_ln) {
+            rc = launch_gemm_skinny(ws.x, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, sk, s, L.ln_2_w, L.ln_2_b,
+                                    cfg->ln_eps);
+        } else {
+            if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
+            rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s, sk);
+        }
+        if (rc) return rc;
         if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
     }
     return launch_layernorm(ws.x, w->ln_f_w, w->ln_f_b, B, d, cfg->ln_eps, out_hidden_d, s);
+}
+
+static size_t greedy_pool_floats(const r4d_gpt2_config* cfg) {
+    const size_t a = decode_skinny_floats(cfg->n_embd);
+    const size_t b = gemm_skinny_supported(1, cfg->n_embd, cfg->vocab) ? gemm_skinny_scratch_floats(cfg->n_embd, cfg->vocab) : 0;
+    return a > b ? a : b;
+}
+
+size_t r4d_gpt2_greedy_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B) {
+    if (!cfg || B <= 0) return 0;
+    return carve(nullptr, (size_t)B, 0, greedy_pool_floats(cfg), cfg->n_embd).bytes;
+}
+
+int r4d_gpt2_greedy_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_greedy_state* st,
+                             float* kv_cache_d, int32_t B, int32_t t_cap, void* workspace_d, size_t workspace_bytes,
+                             void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    R4D_REQUIRE(w && w->wte && st && st->last_d && st->logits_d, "gpt2 greedy: null pointer");
+    R4D_REQUIRE(B >= 1 && t_cap >= 1, "gpt2 greedy: B=%d t_cap=%d", B, t_cap);
+    const int d = cfg->n_embd, V = cfg->vocab;
+    Workspace ws = carve(workspace_d, (size_t)B, 0, greedy_pool_floats(cfg), d);
+    if (!workspace_d || workspace_bytes < ws.bytes) {
+        set_error("gpt2 greedy: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
+        return R4D_ERR_WORKSPACE;
+    }
+    if (B <= 32 && gemm_skinny_supported(B, d, V))                   // lm_head on B rows: a weight stream like the projections
+        rc = launch_gemm_skinny(st->last_d, w->wte, nullptr, nullptr, B, d, V, EPI_NONE, st->logits_d, ws.pool, s);
+    else
+        rc = r4d_lm_logits_f32(st->last_d, w->wte, B, V, d, st->logits_d, stream);
+    if (rc) return rc;
+    GreedyState g;
+    g.next = st->next_d; g.lens = st->lens_d; g.pos = st->pos_d; g.active = st->active_d; g.gen_len = st->gen_len_d;
+    g.out_tokens = st->out_tokens_d; g.params = st->params_d; g.out_cap = st->out_cap; g.t_cap = t_cap;
+    if ((rc = launch_greedy_advance(st->logits_d, B, V, g, s))) return rc;
+    return r4d_gpt2_decode_step_f32(cfg, w, st->next_d, nullptr, st->pos_d, kv_cache_d, B, t_cap, st->last_d, workspace_d,
+                                    workspace_bytes, stream);
+}
+
+struct r4d_decode_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int r4d_gpt2_greedy_graph_create(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_greedy_state* st,
+                                 float* kv_cache_d, int32_t B, int32_t t_cap, void* workspace_d, size_t workspace_bytes,
+                                 r4d_decode_graph** out_graph) {
+    R4D_REQUIRE(out_graph, "gpt2 greedy graph: null out_graph");
+    *out_graph = nullptr;
+    R4D_REQUIRE(!g_prof_on, "gpt2 greedy graph: switch the launch profiler off before capturing");
+    hipStream_t cap = nullptr;                                       // the caller's stream may be the null stream: not capturable
+    R4D_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(cap);
+        set_error("gpt2 greedy graph: begin capture: %s", hipGetErrorString(e));
+        return R4D_ERR_HIP;
+    }
+    const int rc = r4d_gpt2_greedy_step_f32(cfg, w, st, kv_cache_d, B, t_cap, workspace_d, workspace_bytes, cap);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(cap, &graph);                            // always end the capture, also after an error
+    (void)hipStreamDestroy(cap);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess || !graph) {
+        set_error("gpt2 greedy graph: end capture: %s", hipGetErrorString(e));
+        return R4D_ERR_HIP;
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        set_error("gpt2 greedy graph: instantiate: %s", hipGetErrorString(e));
+        return R4D_ERR_HIP;
+    }
+    *out_graph = new r4d_decode_graph{graph, exec};
+    return R4D_OK;
+}
+
+int r4d_decode_graph_launch(r4d_decode_graph* graph, int32_t n_steps, void* stream) {
+    R4D_REQUIRE(graph && graph->exec && n_steps >= 0, "decode graph: null graph or n_steps=%d", n_steps);
+    for (int i = 0; i < n_steps; ++i) R4D_HIP(hipGraphLaunch(graph->exec, (hipStream_t)stream));
+    return R4D_OK;
+}
+
+void r4d_decode_graph_destroy(r4d_decode_graph* graph) {
+    if (!graph) return;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
 }
 
 int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int32_t V, int32_t d, float* logits_d,

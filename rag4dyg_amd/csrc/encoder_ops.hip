@@ -227,110 +227,173 @@ int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32
 }
 
 // Decode attention: ONE query (the new position) per (sequence, head) against that sequence's cached keys / values
-// -- Attention._attn with a one-row query and layer_past (modeling_gpt2.py:140-160,177-197).  HBM-bound: every cached
-// K and V row of the head is read once.  The block first appends the new K / V row to the cache, then
-//   pass 1: wave w scores keys w, w+4, ... (lanes stride the head dim, wave-shuffle reduce), logits / sqrt(hd) to LDS;
-//   block max / sum; pass 2: wave w accumulates exp(s - max) * V over its keys, lanes own the head columns;
-//   the four partial sums are combined through LDS.  No masking needed: only positions <= pos exist.
-constexpr int DEC_MAXC = 4;                            // head_dim <= 256 = 64 lanes x 4
-__global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ qkv_new, float* __restrict__ kv,
+// -- Attention._attn with a one-row query and layer_past (modeling_gpt2.py:140-160,177-197).  HBM-bound in principle
+// (every cached K and V row of the head is read once) but LATENCY-bound in practice: the first version (4 waves, one
+// key per wave and load, 4 keys in flight, a score pass and a value pass) took 71 us per layer at ~100 cached
+// positions -- 2 x n/16 dependent round trips to memory.  Now: a key is owned by a GROUP of GL lanes (16 bytes per lane:
+// a head row of <= 128 floats is one load of 32 lanes), 512 threads = 16 groups, each with U = 8 keys AND their values
+// in flight (128 positions per trip), one pass with an online softmax per group (logits DIVIDED by sqrt(hd) as the
+// reference does, :143), the 16 group states merged through LDS in group order.  The new position's K / V row is
+// appended to the cache by group 0 and taken from registers, not read back.  No masking: only positions <= pos exist.
+template <int GL>
+__global__ __launch_bounds__(512) void decode_attn_kernel(const float* __restrict__ qkv_new, float* __restrict__ kv,
                                                           const int32_t* __restrict__ pos, int t_cap, int H, int d,
                                                           float* __restrict__ out) {
-    extern __shared__ float lds[];                     // q [hd] | scores [t_cap] | partial out [4][hd] | red [8]
+    constexpr int NGRP = 512 / GL, U = 8;
+    __shared__ float4 pacc[NGRP][GL];
+    __shared__ float pm[NGRP], pl[NGRP];
     const int h = blockIdx.x, b = blockIdx.y;
     const int hd = d / H;
-    float* qs = lds;
-    float* sc = lds + hd;
-    float* po = sc + t_cap;
-    float* red = po + 4 * hd;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, grp = tid / GL, gl = tid % GL;
+    const bool on = 4 * gl < hd;                       // head_dim % 4 == 0: a lane owns 4 whole columns or none
     const int p = pos[b];
     if (p < 0 || p >= t_cap) {                         // embed_pos_ln_kernel poisoned this row already
-        for (int c = tid; c < hd; c += 256) out[(long long)b * d + h * hd + c] = __builtin_nanf("");
+        for (int c = tid; c < hd; c += 512) out[(long long)b * d + h * hd + c] = __builtin_nanf("");
         return;
     }
-    float* kvb = kv + (long long)b * t_cap * 2 * d;    // this sequence: rows of [K (d) | V (d)]
+    typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
+    typedef float f32x4d __attribute__((ext_vector_type(4)));
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* kvb = kv + (long long)b * t_cap * 2 * d + h * hd;          // this sequence and head: rows of [K (d) | V (d)]
     const float* nq = qkv_new + (long long)b * 3 * d + h * hd;
-    for (int c = tid; c < hd; c += 256) {
-        qs[c] = nq[c];
-        kvb[(long long)p * 2 * d + h * hd + c] = nq[d + c];
-        kvb[(long long)p * 2 * d + d + h * hd + c] = nq[2 * d + c];
-    }
-    __syncthreads();
-    const int n = p + 1;
+    // lanes past the head (hd = 96: 24 of 32) repeat its last 16 bytes with a ZERO query fragment: plain loads without
+    // selects (a conditional float4 load compiles to four flat dword loads through a select of addresses)
+    const int glc = min(gl, hd / 4 - 1);
+    float4 q4 = reinterpret_cast<const float4*>(nq)[glc];
+    if (!on) q4 = z4;
     const float scale = sqrtf((float)hd);
-    // four keys per trip: their K rows are requested together (one key at a time is a chain of dependent ~1 us loads)
-    constexpr int KU = 4;
-    for (int t0 = wid; t0 < n; t0 += 4 * KU) {
-        float kv_[KU][DEC_MAXC];
+    float m = -INFINITY, l = 0.f;
+    float4 acc = z4;
+    auto group_sum = [](float v) {
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const float* kr = kvb + (long long)min(t0 + 4 * u, n - 1) * 2 * d + h * hd;
+        for (int o = GL / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    if (grp == 0) {                                    // the new position: append to the cache, start from registers
+        const float4 k4 = reinterpret_cast<const float4*>(nq + d)[glc];
+        const float4 v4 = reinterpret_cast<const float4*>(nq + 2 * d)[glc];
+        reinterpret_cast<float4*>(kvb + (long long)p * 2 * d)[glc] = k4;          // idle lanes rewrite the same 16 bytes
+        reinterpret_cast<float4*>(kvb + (long long)p * 2 * d + d)[glc] = v4;
+        m = group_sum((k4.x * q4.x + k4.y * q4.y) + (k4.z * q4.z + k4.w * q4.w)) / scale;
+        l = 1.f;
+        acc = v4;
+    }
+    // cached rows through a buffer resource: 32-bit offsets (a sequence's cache is < 2 GB), one b128 load per K / V piece
+    const unsigned row_bytes = 2u * d * 4u;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(kvb, 0, (unsigned)t_cap * row_bytes - h * hd * 4u, 0x00020000);
+    const unsigned v_off = (unsigned)d * 4u + 16u * glc;
+    for (int t0 = 0; t0 < p; t0 += NGRP * U) {         // uniform trip count; a group's keys: t0 + u * NGRP + grp
+        u32x4d kr[U], vr[U];
 #pragma unroll
-            for (int i = 0; i < DEC_MAXC; ++i) kv_[u][i] = (lane + 64 * i < hd) ? kr[lane + 64 * i] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const unsigned ro = (unsigned)min(t0 + u * NGRP + grp, p - 1) * row_bytes;
+            kr[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ro + 16u * glc, 0, 0);
+            vr[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ro + v_off, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < DEC_MAXC; ++i) if (lane + 64 * i < hd) a += kv_[u][i] * qs[lane + 64 * i];
-            a = wave_sum(a);
-            if (lane == 0 && t0 + 4 * u < n) sc[t0 + 4 * u] = a / scale;     // divided like the reference (:143)
+        for (int u = 0; u < U; ++u) {
+            const f32x4d k4 = __builtin_bit_cast(f32x4d, kr[u]), v4 = __builtin_bit_cast(f32x4d, vr[u]);
+            const float sv = group_sum((k4.x * q4.x + k4.y * q4.y) + (k4.z * q4.z + k4.w * q4.w)) / scale;
+            if (t0 + u * NGRP + grp < p) {
+                const float mn = fmaxf(m, sv);
+                const float corr = __expf(m - mn), e = __expf(sv - mn);
+                l = l * corr + e;
+                acc.x = acc.x * corr + e * v4.x;
+                acc.y = acc.y * corr + e * v4.y;
+                acc.z = acc.z * corr + e * v4.z;
+                acc.w = acc.w * corr + e * v4.w;
+                m = mn;
+            }
         }
     }
+    pacc[grp][gl] = acc;
+    if (gl == 0) { pm[grp] = m; pl[grp] = l; }
     __syncthreads();
-    float m = -INFINITY;
-    for (int t = tid; t < n; t += 256) m = fmaxf(m, sc[t]);
-    m = wave_max(m);
-    if (lane == 0) red[wid] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float l = 0.f;
-    for (int t = tid; t < n; t += 256) {
-        const float e = __expf(sc[t] - m);
-        sc[t] = e;
-        l += e;
-    }
-    l = wave_sum(l);
-    if (lane == 0) red[4 + wid] = l;
-    __syncthreads();
-    l = (red[4] + red[5]) + (red[6] + red[7]);
-    float acc[DEC_MAXC] = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = wid; t0 < n; t0 += 4 * KU) {
-        float vv[KU][DEC_MAXC], e[KU];
+    if (grp == 0 && on) {                              // merge the group states in group order
+        float M = pm[0];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int t = t0 + 4 * u;
-            const float* vr = kvb + (long long)min(t, n - 1) * 2 * d + d + h * hd;
-            e[u] = t < n ? sc[t] : 0.f;
+        for (int g = 1; g < NGRP; ++g) M = fmaxf(M, pm[g]);
+        float L = 0.f;
+        float4 o = z4;
 #pragma unroll
-            for (int i = 0; i < DEC_MAXC; ++i) vv[u][i] = (lane + 64 * i < hd) ? vr[lane + 64 * i] : 0.f;
+        for (int g = 0; g < NGRP; ++g) {
+            const float w = __expf(pm[g] - M);         // groups that saw no key: exp(-inf) == 0
+            const float4 a = pacc[g][gl];
+            L += pl[g] * w;
+            o.x += a.x * w; o.y += a.y * w; o.z += a.z * w; o.w += a.w * w;
         }
-#pragma unroll
-        for (int u = 0; u < KU; ++u)                   // same key order per wave as one key at a time
-#pragma unroll
-            for (int i = 0; i < DEC_MAXC; ++i) acc[i] += e[u] * vv[u][i];
+        o.x /= L; o.y /= L; o.z /= L; o.w /= L;
+        reinterpret_cast<float4*>(out + (long long)b * d + h * hd)[gl] = o;
     }
-#pragma unroll
-    for (int i = 0; i < DEC_MAXC; ++i)
-        if (lane + 64 * i < hd) po[wid * hd + lane + 64 * i] = acc[i];
-    __syncthreads();
-    for (int c = tid; c < hd; c += 256)
-        out[(long long)b * d + h * hd + c] = ((po[c] + po[hd + c]) + (po[2 * hd + c] + po[3 * hd + c])) / l;
 }
 
 int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t* pos, int B, int t_cap, int H, int d,
                             float* out, hipStream_t s) {
     const int hd = d / H;
-    R4D_REQUIRE(hd * H == d && hd <= 64 * DEC_MAXC, "decode attention: head_dim=%d (max %d)", hd, 64 * DEC_MAXC);
-    R4D_REQUIRE(t_cap >= 1 && t_cap <= 8192, "decode attention: t_cap=%d", t_cap);
+    R4D_REQUIRE(hd * H == d && hd % 4 == 0 && hd <= 256, "decode attention: head_dim=%d (multiple of 4, max 256)", hd);
+    R4D_REQUIRE(d % 4 == 0 && t_cap >= 1, "decode attention: d=%d t_cap=%d", d, t_cap);
     if (B <= 0) return R4D_OK;
     // algorithmic bytes: the cached K and V rows of every head (upper bound t_cap/2 on average is unknown here: count
     // the new row only; callers that profile use the HIP-event time)
     ProfScope prof(PK_DECODE_ATTN, 16.0 * B * d, s);
-    const size_t lds = ((size_t)hd + t_cap + 4 * hd + 8) * sizeof(float);
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(256), lds, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
+    if (hd <= 128) hipLaunchKernelGGL(decode_attn_kernel<32>, dim3(H, B), dim3(512), 0, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
+    else hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(H, B), dim3(512), 0, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
     R4D_CHECK_LAUNCH("decode_attention");
+    return R4D_OK;
+}
+
+// Greedy bookkeeping of one decode step, on the device (one workgroup per sequence): argmax of the sequence's logits
+// (lowest index among equal maxima) and the stop rules of the reference's greedy loops
+// (Evaluation_SimpleDyG.py:126-145, Evaluation_generator.py:153-175) -- so that a step needs no host round trip and
+// the whole step can be replayed as a captured graph.
+__global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __restrict__ logits, int V, GreedyState st) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* row = logits + (long long)b * V;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < V; j += 256) {
+        const float v = row[j];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = j; }      // ascending j per thread: first maximum kept
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < 4; ++w)
+        if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    int a = st.active[b];
+    const int len = st.lens[b];
+    if (a) {
+        int g = st.gen_len[b];
+        if (g < st.out_cap) st.out_tokens[(long long)b * st.out_cap + g] = bi;
+        ++g;
+        st.gen_len[b] = g;
+        const int max_gen = st.params[0], len_limit = min(st.params[1], st.t_cap), n_eos = min(st.params[2], 4);
+        bool stop = g >= max_gen || g >= st.out_cap || len + 1 >= len_limit;      // the cache row written next is `len`
+        for (int e = 0; e < n_eos; ++e) stop |= bi == st.params[3 + e];
+        if (stop) a = 0;
+        st.active[b] = a;
+    }
+    st.next[b] = bi;
+    st.pos[b] = a ? len : 0;                     // finished sequences rewrite their row 0: harmless, they are never read again
+    st.lens[b] = len + a;
+}
+
+int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s) {
+    R4D_REQUIRE(logits && st.next && st.lens && st.pos && st.active && st.gen_len && st.out_tokens && st.params,
+                "greedy advance: null pointer");
+    R4D_REQUIRE(V >= 1 && st.out_cap >= 1 && st.t_cap >= 1, "greedy advance: V=%d out_cap=%d t_cap=%d", V, st.out_cap, st.t_cap);
+    if (B <= 0) return R4D_OK;
+    ProfScope prof(PK_GREEDY_ADVANCE, 4.0 * B * (double)V, s);
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(B), dim3(256), 0, s, logits, V, st);
+    R4D_CHECK_LAUNCH("greedy_advance");
     return R4D_OK;
 }
 

@@ -7,6 +7,17 @@
 // with 16-byte loads, 16 loads in flight, exact-f32 MFMA 32x32x2 -- and K is SPLIT over gridDim.y slices of 256 so that
 // a 768 x 768 projection still spreads over 72 wavefronts.  Slice partials go to a caller-provided scratch and are
 // added in slice order by the epilogue kernel (bias / gelu_new / residual): deterministic, no atomics.
+//
+// Measured on the decode step (L6 d768, 32 sequences): that first kernel took 14.8 us per projection and its epilogue
+// 6.8 us -- neither launch-bound (the floor is 2.8 us per launch, 1.8 us per graph node: tools/launch_floor.hip) nor
+// bandwidth-bound (7 MB in 15 us), but a LATENCY CHAIN: stage x, barrier, one round trip for the weights, then 128
+// dependent 32x32x2 MFMAs (64 cycles each = 3.4 us) in a single accumulator.  gemm_skinny8_kernel shortens the chain and
+// drops launches: EIGHT wavefronts share a 32-row tile of wT and split its k range (slices of 512 or 768: 16 or 24 MFMAs
+// per wave), x fragments come straight from L2 with the same 16-byte pattern as the weights (no staging, no barrier
+// before the MFMAs), the eight partial tiles meet in LDS, and when one slice covers K the bias / gelu_new / residual
+// epilogue and -- for the two projections that read a LayerNorm -- the LayerNorm itself (row statistics recomputed
+// per workgroup from the L2-resident x, applied to the fragments) run in the same launch.  K = 4d (mlp c_proj) still
+// splits over gridDim.y and keeps the epilogue kernel.
 #include "common.h"
 
 namespace r4d {
@@ -87,16 +98,148 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(const float* 
     y[idx] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------- 8-wave kernel
+constexpr int S8_NW = 8;
+constexpr int S8_LDR = 33;                             // partial-tile row stride in LDS (floats)
+
+__device__ __forceinline__ float wave_sum_sk(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid (ceil(N/32), KS), 512 threads.  Slice length SL = 8 * 32 * NG.  KS == 1: y = epilogue(x' . wT^T + bias) with
+// x' = LN ? LayerNorm(x; ln_w, ln_b, eps) : x.   KS > 1: partial[ks][m][n] (m < 32) for gemm_skinny_epilogue_kernel.
+template <int NG, bool LN>
+__global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* __restrict__ x, const float* __restrict__ wT,
+                                                                  int M, int N, int K, const float* __restrict__ bias,
+                                                                  const float* __restrict__ resid, int epilogue,
+                                                                  float* __restrict__ y, float* __restrict__ partial,
+                                                                  const float* __restrict__ ln_w,
+                                                                  const float* __restrict__ ln_b, float eps) {
+    constexpr int KW = 32 * NG, SL = S8_NW * KW;
+    __shared__ float red[S8_NW * 32 * S8_LDR];
+    __shared__ float stat[64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.y * SL + wid * KW;
+    const int row = blockIdx.x * 32 + li;
+    // k order as in pool_scan_kernel: lane half h of a row owns the 64-byte halves [32g + 16h, +16) of each 128-byte line
+    const float4* __restrict__ wrow = reinterpret_cast<const float4*>(wT + (long long)min(row, N - 1) * K + k0) + 4 * lh;
+    const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + (long long)min(li, M - 1) * K + k0) + 4 * lh;
+    float4 b[NG][4], a[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];          // weights first: the long (HBM) latency
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[g][u] = xrow[8 * g + u];          // rows >= M repeat row M-1: computed, never stored
+    if (LN) {                                          // K == SL: wave w owns the statistics of rows w, w+8, w+16, w+24
+        float4 v[4][NG];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                v[rr][j] = reinterpret_cast<const float4*>(x + (long long)min(wid + 8 * rr, M - 1) * K)[lane + 64 * j];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) s_ += (v[rr][j].x + v[rr][j].y) + (v[rr][j].z + v[rr][j].w);
+            const float mean = wave_sum_sk(s_) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const float a0 = v[rr][j].x - mean, a1 = v[rr][j].y - mean, a2 = v[rr][j].z - mean, a3 = v[rr][j].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            const float rstd = rsqrtf(wave_sum_sk(q) / (float)K + eps);
+            if (lane == 0) { stat[wid + 8 * rr] = mean; stat[32 + wid + 8 * rr] = rstd; }
+        }
+        __syncthreads();
+        const float mean = stat[li], rstd = stat[32 + li];
+        const float4* __restrict__ gw = reinterpret_cast<const float4*>(ln_w + k0) + 4 * lh;
+        const float4* __restrict__ gb = reinterpret_cast<const float4*>(ln_b + k0) + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 w4 = gw[8 * g + u], b4 = gb[8 * g + u];
+                a[g][u].x = (a[g][u].x - mean) * rstd * w4.x + b4.x;
+                a[g][u].y = (a[g][u].y - mean) * rstd * w4.y + b4.y;
+                a[g][u].z = (a[g][u].z - mean) * rstd * w4.z + b4.z;
+                a[g][u].w = (a[g][u].w - mean) * rstd * w4.w + b4.w;
+            }
+    }
+    f32x16g acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].x, b[g][u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].y, b[g][u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].z, b[g][u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].w, b[g][u].w, acc, 0, 0, 0);
+        }
+    float* mine = red + wid * 32 * S8_LDR;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lh) * S8_LDR + li] = acc[r];
+    __syncthreads();
+    const int n = blockIdx.x * 32 + li;                // thread -> (m, n): 32 consecutive n per row, 16 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int m = (tid >> 5) + 16 * pass;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < S8_NW; ++w) v += red[(w * 32 + m) * S8_LDR + li];       // wave order: deterministic
+        if (n >= N) continue;
+        if (partial) {
+            partial[((long long)blockIdx.y * 32 + m) * N + n] = v;                  // rows m >= M: written, never read
+        } else if (m < M) {
+            v += bias ? bias[n] : 0.f;
+            if (epilogue == EPI_GELU) v = gelu_new_sk(v);
+            else if (epilogue == EPI_RESIDUAL) v += resid[(long long)m * N + n];
+            y[(long long)m * N + n] = v;
+        }
+    }
+}
+
+static int skinny8_ng(int K) { return K % 768 == 0 ? 3 : (K % 512 == 0 ? 2 : 0); }       // 0: the 4-wave kernel
+
+bool gemm_skinny_fuses_ln(int M, int K, int N) { return gemm_skinny_supported(M, K, N) && (K == 768 || K == 512); }
+
 size_t gemm_skinny_scratch_floats(int K, int N) { return (size_t)cdiv(K, SK_KC) * 32 * N; }
 
 bool gemm_skinny_supported(int M, int K, int N) { return M >= 1 && M <= 32 && K % SK_KC == 0 && K >= SK_KC && N >= 1; }
 
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
-                       int epilogue, float* y, float* scratch, hipStream_t s) {
+                       int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w, const float* ln_b,
+                       float ln_eps) {
     R4D_REQUIRE(gemm_skinny_supported(M, K, N) && scratch, "skinny gemm: unsupported shape M=%d K=%d N=%d", M, K, N);
     R4D_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wT % 16) == 0, "skinny gemm: operands must be 16-byte aligned");
-    const int KS = K / SK_KC;
-    {
+    R4D_REQUIRE(!ln_w || (ln_b && gemm_skinny_fuses_ln(M, K, N)), "skinny gemm: no fused LayerNorm for K=%d", K);
+    const int ng = skinny8_ng(K);
+    int KS;
+    if (ng) {                                          // 8 waves per 32-row tile of wT
+        const int SL = S8_NW * 32 * ng;
+        KS = K / SL;
+        float* partial = KS > 1 ? scratch : nullptr;
+        ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + (KS > 1 ? 4.0 * KS * 32.0 * N : 4.0 * M * N), s);
+        const dim3 grid(cdiv(N, 32), KS), block(64 * S8_NW);
+#define SK8_(NG_, LN_)                                                                                                    \
+    hipLaunchKernelGGL((gemm_skinny8_kernel<NG_, LN_>), grid, block, 0, s, x, wT, M, N, K, bias, resid, epilogue, y, partial, \
+                       ln_w, ln_b, ln_eps)
+        if (ng == 3) { if (ln_w) SK8_(3, true); else SK8_(3, false); }
+        else         { if (ln_w) SK8_(2, true); else SK8_(2, false); }
+#undef SK8_
+        R4D_CHECK_LAUNCH("gemm_skinny8");
+        if (KS == 1) return R4D_OK;
+    } else {
+        KS = K / SK_KC;
         // algorithmic bytes: the weight matrix once (+ x per slice, + partials)
         ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + 4.0 * KS * 32.0 * N, s);
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(cdiv(N, 32), 4), KS), dim3(256), 0, s, x, wT, M, N, K, scratch);

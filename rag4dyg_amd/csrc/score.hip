@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 //   * exact-f32 MFMA 32x32x2 accumulates S[32 q x 32 rows]; the epilogue applies (x+1)/2 and writes 128-byte
 //     row segments of the score matrix, from which topk_seg_kernel selects.
 typedef float f32x16s __attribute__((ext_vector_type(16)));
-constexpr int SCAN_U = 8;
+
 
 // Q tile layout in LDS: ROW-major [32 queries][d + 4] (k contiguous).  A lane's MFMA A operands for four consecutive
 // MFMAs are then ONE ds_read_b128 (16-lane groups hit 16 distinct 16-byte slots: stride 4 banks), matching the four k

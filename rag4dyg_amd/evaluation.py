@@ -98,27 +98,16 @@ def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, dev
     ids = torch.zeros(n, tmax, dtype=torch.long, device=device)
     for i, t in enumerate(toks):
         ids[i, :len(t)] = torch.tensor(t, dtype=torch.long, device=device)
-    cache = tr.new_kv_cache(n, cap, device)
-    hidden = tr.prefill(cache, input_ids=ids)
+    dec = tr.greedy_decoder(n, cap)
+    hidden = tr.prefill(dec.cache, input_ids=ids)
     lens = torch.tensor([len(t) for t in toks], dtype=torch.int32, device=device)
     last = hidden[torch.arange(n, device=device), (lens - 1).long()]
-    active = [True] * n
-    gen_len = [0] * n
-    while True:
-        nxt = torch.argmax(ops.lm_logits(last.contiguous(), wte), dim=1)
-        for i, v in enumerate(nxt.tolist()):
-            if not active[i]:
-                continue
-            toks[i].append(v)
-            gen_len[i] += 1
-            stop = (gen_len[i] > 10) if mode == "val" else (len(toks[i]) >= max_len - n_spl)
-            if stop or v in eos or len(toks[i]) >= cap:
-                active[i] = False
-        if not any(active):
-            break
-        act = torch.tensor(active, device=device)
-        last = tr.decode_step(cache, torch.where(act, lens, torch.zeros_like(lens)), input_ids=nxt)
-        lens = lens + act.to(torch.int32)
+    # the reference's stop rules (Evaluation_SimpleDyG.py:135-145) evaluated on the device after every token:
+    # val: 11 tokens; test: <|endoftext|> or len(tokens) >= n_ctx - len(spl_tokens); always: the cache is full
+    limit = cap if mode == "val" else min(cap, max_len - n_spl)
+    gen = dec.run(last, lens, 11 if mode == "val" else cap, limit, eos)
+    for t, g in zip(toks, gen):
+        t.extend(g)
     return toks
 
 

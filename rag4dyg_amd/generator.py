@@ -240,7 +240,7 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
       * every further token is ONE ``r4d_gpt2_decode_step_f32`` over all queries: one new row per query against its
         cached keys/values (``modeling_gpt2.py:177-197`` ``layer_past`` semantics), lm_head on those rows only.
     Same tokens as the one-at-a-time loop up to fp32 summation order.  Finished queries keep their slot (their rows
-    are ignored); one host sync per step for the stop rules."""
+    are ignored); argmax and the stop rules run on the device (``GreedyDecoder``), one captured graph per token."""
     tr = model.transformer
     wte = tr.wte.weight
     dev = wte.device
@@ -262,28 +262,15 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
         ids[i, 2 + r:len(t) + r] = tt[2:]
     H_aug = wte[ids]
     H_aug[:, 2:2 + r] = sims
-    cache = tr.new_kv_cache(n, cap, dev)
-    hidden = tr.prefill(cache, inputs_embeds=H_aug.contiguous())       # [n, tmax, d]
+    dec = tr.greedy_decoder(n, cap)
+    hidden = tr.prefill(dec.cache, inputs_embeds=H_aug.contiguous())   # [n, tmax, d]
     lens = torch.tensor(lens0, dtype=torch.int32, device=dev)
     last = hidden[torch.arange(n, device=dev), (lens - 1).long()]
-    active = [True] * n
-    gen_len = [0] * n
-    while True:
-        nxt = torch.argmax(ops.lm_logits(last.contiguous(), wte), dim=1)
-        for i, v in enumerate(nxt.tolist()):
-            if not active[i]:
-                continue
-            toks[i].append(v)
-            gen_len[i] += 1
-            stop = (gen_len[i] > 10) if mode == "val" else (len(toks[i]) >= max_len - n_spl)
-            if stop or v in eos or len(toks[i]) + r >= cap:
-                active[i] = False
-        if not any(active):
-            break
-        act = torch.tensor(active, device=dev)
-        pos = torch.where(act, lens, torch.zeros_like(lens))           # finished slots rewrite their row 0: harmless
-        last = tr.decode_step(cache, pos, input_ids=nxt)
-        lens = lens + act.to(torch.int32)
+    # stop rules of Evaluation_generator.py:168-175 in augmented positions (r fused rows sit inside every prompt)
+    limit = cap if mode == "val" else min(cap, max_len - n_spl + r)
+    gen = dec.run(last, lens, 11 if mode == "val" else cap, limit, eos)
+    for t, g in zip(toks, gen):
+        t.extend(g)
     return toks
 
 

@@ -299,6 +299,19 @@ class GPT2Model(_PreTrained):
                    "gpt2_decode_step")
         return hidden
 
+    def greedy_decoder(self, B, t_cap):
+        """A ``GreedyDecoder`` with room for ``B`` sequences of ``t_cap`` positions, reused across batches (its captured
+        graph and buffers are keyed by (B, rounded t_cap))."""
+        t_cap = (int(t_cap) + 127) // 128 * 128
+        cache = self.__dict__.setdefault("_greedy_decoders", {})
+        fits = [k for k in cache if k[0] == B and k[1] >= t_cap]
+        if fits:
+            return cache[min(fits)]
+        for k in [k for k in cache if k[0] == B]:                            # a larger cache replaces the smaller ones
+            cache.pop(k).close()
+        dec = cache[(B, t_cap)] = GreedyDecoder(self, B, t_cap)
+        return dec
+
     @torch.no_grad()
     def encode_groups_meanpool(self, batches):
         """Mean-pooled embeddings of several right-padded batches in one fused launch sequence
@@ -348,6 +361,93 @@ class GPT2Model(_PreTrained):
         if self.output_hidden_states:
             outputs = outputs + (tuple(r["layers"][i] for i in range(self.config.n_layer)) + (r["hidden"],),)
         return outputs
+
+
+class GreedyDecoder:
+    """Greedy decoding with the loop state on the device (``r4d_gpt2_greedy_step_f32``): logits of the newest position,
+    argmax, the stop rules of the reference's loops (``Evaluation_SimpleDyG.py:126-145``,
+    ``Evaluation_generator.py:153-175``) and one key/value-cached step, per token, WITHOUT a host round trip -- replayed as
+    a captured HIP graph (``r4d_gpt2_greedy_graph_create``; ``R4D_DECODE_GRAPH=0`` launches the same kernels one by
+    one).  Owns the key/value cache ``self.cache`` [n_layer, B, t_cap, 2d]: prefill into it, then ``run``."""
+
+    def __init__(self, transformer, B, t_cap):
+        self.tr = transformer
+        dev = transformer.wte.weight.device
+        cfg = transformer.config
+        d, V = cfg.n_embd, transformer.wte.num_embeddings
+        self.B, self.t_cap, self.device = B, t_cap, dev
+        self.cache = transformer.new_kv_cache(B, t_cap, dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.last = torch.zeros(B, d, dtype=torch.float32, device=dev)
+        self.logits = torch.empty(B, V, dtype=torch.float32, device=dev)
+        self.next = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.lens, self.pos = torch.zeros(B, **i32), torch.zeros(B, **i32)
+        self.active, self.gen_len = torch.zeros(B, **i32), torch.zeros(B, **i32)
+        self.out = torch.zeros(B, t_cap, **i32)
+        self.params = torch.zeros(8, **i32)
+        lib = _lib.load()
+        c, _, _ = transformer._c_structs()
+        self.ws = torch.empty(max(int(lib.r4d_gpt2_greedy_workspace_bytes(ctypes.byref(c), B)), 256), dtype=torch.uint8,
+                              device=dev)
+        self.state = _lib.GreedyStateC(self.last.data_ptr(), self.logits.data_ptr(), self.next.data_ptr(),
+                                       self.lens.data_ptr(), self.pos.data_ptr(), self.active.data_ptr(),
+                                       self.gen_len.data_ptr(), self.out.data_ptr(), self.params.data_ptr(), t_cap)
+        self._graph = None
+        self._graph_key = None
+        self.use_graph = os.environ.get("R4D_DECODE_GRAPH", "1") != "0"
+
+    def close(self):
+        if self._graph is not None:
+            _lib.load().r4d_decode_graph_destroy(self._graph)
+            self._graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _steps(self, n):
+        lib = _lib.load()
+        c, w, layers = self.tr._c_structs()
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.use_graph:
+            key = bytes(w) + bytes(layers)                          # every weight pointer the graph has baked in
+            if self._graph is None or key != self._graph_key:
+                self.close()
+                g = ctypes.c_void_p()
+                _lib.check(lib.r4d_gpt2_greedy_graph_create(ctypes.byref(c), ctypes.byref(w), ctypes.byref(self.state),
+                                                            self.cache.data_ptr(), self.B, self.t_cap, self.ws.data_ptr(),
+                                                            self.ws.numel(), ctypes.byref(g)), "gpt2_greedy_graph_create")
+                self._graph, self._graph_key = g, key
+            _lib.check(lib.r4d_decode_graph_launch(self._graph, n, stream), "decode_graph_launch")
+        else:
+            for _ in range(n):
+                _lib.check(lib.r4d_gpt2_greedy_step_f32(ctypes.byref(c), ctypes.byref(w), ctypes.byref(self.state),
+                                                        self.cache.data_ptr(), self.B, self.t_cap, self.ws.data_ptr(),
+                                                        self.ws.numel(), stream), "gpt2_greedy_step")
+
+    @torch.no_grad()
+    def run(self, last, lens, max_gen, len_limit, eos=(), poll=8):
+        """Generate from the prefilled cache.  ``last`` [B,d]: ln_f row of every sequence's last prompt position;
+        ``lens`` [B]: positions cached.  A sequence stops after ``max_gen`` tokens, after any id in ``eos``, or once its
+        length reaches ``len_limit``.  Returns the generated ids per sequence (lists of ints)."""
+        eos = [int(e) for e in eos][:4]
+        self.last.copy_(last)
+        self.lens.copy_(lens.to(torch.int32))
+        self.active.fill_(1)
+        self.gen_len.zero_()
+        self.params.copy_(torch.tensor([int(max_gen), int(min(len_limit, self.t_cap)), len(eos)] + eos + [0] * (5 - len(eos)),
+                                       dtype=torch.int32))
+        n, done = (int(max_gen) if max_gen <= 16 else poll), 0
+        while True:
+            self._steps(n)
+            done += n
+            if done > self.t_cap or not bool(self.active.any()):    # one host sync per `poll` tokens
+                break
+            n = poll
+        out, g = self.out.cpu(), self.gen_len.cpu()
+        return [out[i, :int(g[i])].tolist() for i in range(self.B)]
 
 
 class _LMHeadBase(_PreTrained):

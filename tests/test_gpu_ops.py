@@ -180,6 +180,72 @@ def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
     assert torch.isnan(h2[2]).all() and not torch.isnan(h2[[0, 1, 3, 4]]).any()
 
 
+@pytest.mark.parametrize("L,H,d,B", [(2, 2, 64, 5), (2, 8, 768, 32), (1, 2, 512, 33)])
+def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B):
+    """GreedyDecoder (argmax + stop rules on the device; captured HIP graph and kernel-by-kernel) generates exactly what
+    a host loop over decode_step / lm_logits / argmax generates: max-token, end-of-sequence and length stops, ragged
+    prompts, B <= 32 (skinny lm_head) and B > 32 (tiled), a decoder reused for a second batch."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd import ops
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    V, P = 90, 128
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=L * 10 + H, random_affine=True)
+    m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    m = m.to(dev).eval()
+    tr = m.transformer
+    g = torch.Generator().manual_seed(B + d)
+
+    def host_loop(seqs, max_gen, limit, eos, cap):
+        n, tmax = len(seqs), max(len(s_) for s_ in seqs)
+        ids = torch.zeros(n, tmax, dtype=torch.int64)
+        for i, s_ in enumerate(seqs):
+            ids[i, :len(s_)] = torch.tensor(s_)
+        cache = tr.new_kv_cache(n, cap, dev)
+        hidden = tr.prefill(cache, input_ids=ids.to(dev))
+        lens = torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32, device=dev)
+        last = hidden[torch.arange(n, device=dev), (lens - 1).long()]
+        out, active = [[] for _ in seqs], [True] * n
+        while True:
+            nxt = torch.argmax(ops.lm_logits(last.contiguous(), tr.wte.weight), dim=1)
+            for i, v in enumerate(nxt.tolist()):
+                if active[i]:
+                    out[i].append(v)
+                    if len(out[i]) >= max_gen or v in eos or len(seqs[i]) + len(out[i]) >= limit:
+                        active[i] = False
+            if not any(active):
+                return out
+            act = torch.tensor(active, device=dev)
+            last = tr.decode_step(cache, torch.where(act, lens, torch.zeros_like(lens)), input_ids=nxt)
+            lens = lens + act.to(torch.int32)
+
+    def device_loop(seqs, max_gen, limit, eos, cap):
+        n, tmax = len(seqs), max(len(s_) for s_ in seqs)
+        ids = torch.zeros(n, tmax, dtype=torch.int64)
+        for i, s_ in enumerate(seqs):
+            ids[i, :len(s_)] = torch.tensor(s_)
+        dec = tr.greedy_decoder(n, cap)
+        hidden = tr.prefill(dec.cache, input_ids=ids.to(dev))
+        lens = torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32, device=dev)
+        last = hidden[torch.arange(n, device=dev), (lens - 1).long()]
+        return dec.run(last, lens, max_gen, min(limit, cap), eos, poll=3)
+
+    for trial, (max_gen, limit, cap) in enumerate([(11, 10 ** 6, 64), (10 ** 6, 40, 64), (10 ** 6, 10 ** 6, 48)]):
+        seqs = [torch.randint(0, V, (int(n),), generator=g).tolist() for n in torch.randint(1, 34, (B,), generator=g)]
+        want = host_loop(seqs, max_gen, min(limit, cap), [], cap)
+        eos = sorted({w[min(2, len(w) - 1)] for w in want[:3]})       # ids some sequences really generate: early stops
+        want = host_loop(seqs, max_gen, min(limit, cap), eos, cap)
+        assert any(len(w) <= 3 for w in want)
+        for graph in ("1", "0"):
+            monkeypatch.setenv("R4D_DECODE_GRAPH", graph)
+            tr.__dict__.pop("_greedy_decoders", None)
+            got = device_loop(seqs, max_gen, limit, eos, cap)
+            assert got == want, (trial, graph)
+            if trial == 0:                                            # same decoder (and graph), next batch
+                seqs2 = [s_[::-1] for s_ in seqs]
+                assert device_loop(seqs2, max_gen, limit, eos, cap) == host_loop(seqs2, max_gen, min(limit, cap), eos, cap)
+
+
 def test_lm_logits_odd_vocab(dev):
     from rag4dyg_amd import ops
     g = torch.Generator().manual_seed(3)
