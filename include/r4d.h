@@ -107,6 +107,18 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
                                float* out_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
 
+/* The same launch sequence with every output of r4d_gpt2_encode_f32: batches given as ids (ids_d) OR as embeddings
+ * (embeds_d: HOST array of device f32 [Bs[g], Ts[g], d] pointers), exactly one of the two non-NULL.  Rows of all
+ * batches are concatenated in order (batch g starts at row sum_{j<g} Bs[j]*Ts[j]):
+ *   out_hidden_d   f32 [rows, d] or NULL     out_meanpool_d f32 [sum(Bs), d] or NULL (at least one of the two)
+ *   out_qkv_d      f32 [n_layer, rows, 3d] or NULL (c_attn output per layer: the K / V rows a decode cache starts from)
+ * Used to prefill a RAGGED set of prompts grouped by length: a causal model never lets right-padding reach a real
+ * position, so each group only needs padding to its own longest member. */
+int r4d_gpt2_encode_groups_ex_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
+                                  const int64_t* const* ids_d, const float* const* embeds_d, const int32_t* Bs,
+                                  const int32_t* Ts, float* out_hidden_d, float* out_meanpool_d, float* out_qkv_d,
+                                  void* workspace_d, size_t workspace_bytes, void* stream);
+
 /*
  * Incremental decode with a key/value cache -- the model's `past` mechanism (`layer_past` concatenation,
  * modeling_gpt2.py:177-197; `past` / `presents`, :400-509), which the reference's greedy loops never use

@@ -280,6 +280,22 @@ int r4d_gpt2_encode_groups_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
                        workspace_bytes, (hipStream_t)stream);
 }
 
+int r4d_gpt2_encode_groups_ex_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
+                                  const int64_t* const* ids_d, const float* const* embeds_d, const int32_t* Bs,
+                                  const int32_t* Ts, float* out_hidden_d, float* out_meanpool_d, float* out_qkv_d,
+                                  void* workspace_d, size_t workspace_bytes, void* stream) {
+    R4D_REQUIRE(n_groups >= 1 && n_groups <= 4096 && Bs && Ts, "gpt2 groups: bad arguments");
+    R4D_REQUIRE((ids_d != nullptr) != (embeds_d != nullptr), "gpt2 groups: specify exactly one of ids_d and embeds_d");
+    std::vector<Group> gs((size_t)n_groups);
+    size_t row0 = 0, seq0 = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        gs[g] = Group{ids_d ? ids_d[g] : nullptr, embeds_d ? embeds_d[g] : nullptr, Bs[g], Ts[g], row0, seq0};
+        if (Bs[g] > 0 && Ts[g] > 0) { row0 += (size_t)Bs[g] * Ts[g]; seq0 += (size_t)Bs[g]; }
+    }
+    return encode_impl(cfg, w, gs.data(), n_groups, out_hidden_d, out_meanpool_d, nullptr, out_qkv_d, workspace_d,
+                       workspace_bytes, (hipStream_t)stream);
+}
+
 // decode workspace: the per-row buffers of the encoder + the split-K scratch of the skinny GEMM (largest projection:
 // K = 4d, N = d and K = d, N = 4d both give (4d / 256) * 32 * 4d... the max of the four shapes is taken)
 static size_t decode_skinny_floats(int d) {

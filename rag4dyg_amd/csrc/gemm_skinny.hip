@@ -119,7 +119,6 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
                                                                   const float* __restrict__ ln_b, float eps) {
     constexpr int KW = 32 * NG, SL = S8_NW * KW;
     __shared__ float red[S8_NW * 32 * S8_LDR];
-    __shared__ float stat[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int k0 = blockIdx.y * SL + wid * KW;
@@ -127,51 +126,71 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     // k order as in pool_scan_kernel: lane half h of a row owns the 64-byte halves [32g + 16h, +16) of each 128-byte line
     const float4* __restrict__ wrow = reinterpret_cast<const float4*>(wT + (long long)min(row, N - 1) * K + k0) + 4 * lh;
     const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + (long long)min(li, M - 1) * K + k0) + 4 * lh;
-    float4 b[NG][4], a[NG][4];
+    // EVERY global load of the kernel is issued here, before anything waits: weights (the long HBM latency), x fragments,
+    // LayerNorm gain / shift fragments, and the epilogue's bias / residual values -- one round trip instead of four
+    float4 b[NG][4], a[NG][4], gw[LN ? NG : 1][4], gb[LN ? NG : 1][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];          // weights first: the long (HBM) latency
+        for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[g][u] = xrow[8 * g + u];          // rows >= M repeat row M-1: computed, never stored
-    if (LN) {                                          // K == SL: wave w owns the statistics of rows w, w+8, w+16, w+24
-        float4 v[4][NG];
+    if (LN) {
+        const float4* __restrict__ gwp = reinterpret_cast<const float4*>(ln_w + k0) + 4 * lh;
+        const float4* __restrict__ gbp = reinterpret_cast<const float4*>(ln_b + k0) + 4 * lh;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int j = 0; j < NG; ++j)
-                v[rr][j] = reinterpret_cast<const float4*>(x + (long long)min(wid + 8 * rr, M - 1) * K)[lane + 64 * j];
+            for (int u = 0; u < 4; ++u) { gw[g][u] = gwp[8 * g + u]; gb[g][u] = gbp[8 * g + u]; }
+    }
+    const int n = blockIdx.x * 32 + li;                // epilogue: thread -> (m, n), 32 consecutive n per row, 16 rows per pass
+    const int nc = min(n, N - 1), m0 = min(tid >> 5, M - 1), m1 = min((tid >> 5) + 16, M - 1);
+    const bool fused = partial == nullptr;
+    const float bias_n = (fused && bias) ? bias[nc] : 0.f;
+    const float res0 = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)m0 * N + nc] : 0.f;
+    const float res1 = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)m1 * N + nc] : 0.f;
+    if (LN) {
+        // K == SL: the eight waves hold the eight k-pieces of the SAME 32 rows (row li per lane) -- row statistics from
+        // the fragments themselves: piece sums meet in LDS, mean first, then the centred squares (two-pass like ln4_kernel)
+        float s_ = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            float s_ = 0.f;
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int j = 0; j < NG; ++j) s_ += (v[rr][j].x + v[rr][j].y) + (v[rr][j].z + v[rr][j].w);
-            const float mean = wave_sum_sk(s_) / (float)K;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const float a0 = v[rr][j].x - mean, a1 = v[rr][j].y - mean, a2 = v[rr][j].z - mean, a3 = v[rr][j].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            const float rstd = rsqrtf(wave_sum_sk(q) / (float)K + eps);
-            if (lane == 0) { stat[wid + 8 * rr] = mean; stat[32 + wid + 8 * rr] = rstd; }
-        }
+            for (int u = 0; u < 4; ++u) s_ += (a[g][u].x + a[g][u].y) + (a[g][u].z + a[g][u].w);
+        s_ += __shfl_xor(s_, 32);
+        if (lh == 0) red[wid * 32 + li] = s_;
         __syncthreads();
-        const float mean = stat[li], rstd = stat[32 + li];
-        const float4* __restrict__ gw = reinterpret_cast<const float4*>(ln_w + k0) + 4 * lh;
-        const float4* __restrict__ gb = reinterpret_cast<const float4*>(ln_b + k0) + 4 * lh;
+        float mean = 0.f;
+#pragma unroll
+        for (int w = 0; w < S8_NW; ++w) mean += red[w * 32 + li];
+        mean /= (float)K;
+        float q = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 w4 = gw[8 * g + u], b4 = gb[8 * g + u];
-                a[g][u].x = (a[g][u].x - mean) * rstd * w4.x + b4.x;
-                a[g][u].y = (a[g][u].y - mean) * rstd * w4.y + b4.y;
-                a[g][u].z = (a[g][u].z - mean) * rstd * w4.z + b4.z;
-                a[g][u].w = (a[g][u].w - mean) * rstd * w4.w + b4.w;
+                a[g][u].x -= mean; a[g][u].y -= mean; a[g][u].z -= mean; a[g][u].w -= mean;
+                q += (a[g][u].x * a[g][u].x + a[g][u].y * a[g][u].y) + (a[g][u].z * a[g][u].z + a[g][u].w * a[g][u].w);
             }
+        q += __shfl_xor(q, 32);
+        if (lh == 0) red[256 + wid * 32 + li] = q;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; w < S8_NW; ++w) var += red[256 + w * 32 + li];
+        const float rstd = rsqrtf(var / (float)K + eps);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[g][u].x = a[g][u].x * rstd * gw[g][u].x + gb[g][u].x;
+                a[g][u].y = a[g][u].y * rstd * gw[g][u].y + gb[g][u].y;
+                a[g][u].z = a[g][u].z * rstd * gw[g][u].z + gb[g][u].z;
+                a[g][u].w = a[g][u].w * rstd * gw[g][u].w + gb[g][u].w;
+            }
+        __syncthreads();                               // red is reused for the partial tiles
     }
     f32x16g acc;
 #pragma unroll
@@ -189,7 +208,6 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lh) * S8_LDR + li] = acc[r];
     __syncthreads();
-    const int n = blockIdx.x * 32 + li;                // thread -> (m, n): 32 consecutive n per row, 16 rows per pass
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int m = (tid >> 5) + 16 * pass;
@@ -197,12 +215,12 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
 #pragma unroll
         for (int w = 0; w < S8_NW; ++w) v += red[(w * 32 + m) * S8_LDR + li];       // wave order: deterministic
         if (n >= N) continue;
-        if (partial) {
+        if (!fused) {
             partial[((long long)blockIdx.y * 32 + m) * N + n] = v;                  // rows m >= M: written, never read
         } else if (m < M) {
-            v += bias ? bias[n] : 0.f;
+            v += bias_n;
             if (epilogue == EPI_GELU) v = gelu_new_sk(v);
-            else if (epilogue == EPI_RESIDUAL) v += resid[(long long)m * N + n];
+            else if (epilogue == EPI_RESIDUAL) v += pass ? res1 : res0;
             y[(long long)m * N + n] = v;
         }
     }

@@ -82,8 +82,8 @@ def greedy_decode(model, tokenizer, indexed_tokens, mode, max_len, n_spl, device
 @torch.no_grad()
 def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, device):
     """``greedy_decode`` for many sequences at once with the key/value cache (``GPT2Model.prefill`` / ``decode_step``):
-    the prompts are right-padded to the longest and prefilled in one forward, then every token is one cached step over
-    all sequences.  Same ids as the one-at-a-time loop up to fp32 summation order (the reference re-runs the full
+    the prompts are prefilled in a few length-grouped forwards (``prefill_last``), then every token is one cached step
+    over all sequences, argmax and stop rules on the device (``GreedyDecoder``).  Same ids as the one-at-a-time loop up to fp32 summation order (the reference re-runs the full
     forward per token, ``Evaluation_SimpleDyG.py:126-134``)."""
     tr = model.transformer
     wte = tr.wte.weight
@@ -99,9 +99,8 @@ def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, dev
     for i, t in enumerate(toks):
         ids[i, :len(t)] = torch.tensor(t, dtype=torch.long, device=device)
     dec = tr.greedy_decoder(n, cap)
-    hidden = tr.prefill(dec.cache, input_ids=ids)
+    last = tr.prefill_last(dec.cache, [len(t) for t in toks], input_ids=ids)
     lens = torch.tensor([len(t) for t in toks], dtype=torch.int32, device=device)
-    last = hidden[torch.arange(n, device=device), (lens - 1).long()]
     # the reference's stop rules (Evaluation_SimpleDyG.py:135-145) evaluated on the device after every token:
     # val: 11 tokens; test: <|endoftext|> or len(tokens) >= n_ctx - len(spl_tokens); always: the cache is full
     limit = cap if mode == "val" else min(cap, max_len - n_spl)

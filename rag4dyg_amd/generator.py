@@ -235,8 +235,8 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
 
     The reference decodes one query at a time and re-runs the full forward for every generated token
     (``Evaluation_generator.py:141-167``).  The queries are independent and the model is causal, so here
-      * the fused prompts of all queries are right-padded to the longest and PREFILLED in one forward that also fills
-        the K/V cache (padding sits behind a sequence's real positions and can never reach them);
+      * the fused prompts of all queries are PREFILLED in a few length-grouped forwards that also fill the K/V cache
+        (padding sits behind a sequence's real positions and can never reach them, so grouping changes nothing);
       * every further token is ONE ``r4d_gpt2_decode_step_f32`` over all queries: one new row per query against its
         cached keys/values (``modeling_gpt2.py:177-197`` ``layer_past`` semantics), lm_head on those rows only.
     Same tokens as the one-at-a-time loop up to fp32 summation order.  Finished queries keep their slot (their rows
@@ -263,9 +263,8 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
     H_aug = wte[ids]
     H_aug[:, 2:2 + r] = sims
     dec = tr.greedy_decoder(n, cap)
-    hidden = tr.prefill(dec.cache, inputs_embeds=H_aug.contiguous())   # [n, tmax, d]
+    last = tr.prefill_last(dec.cache, lens0, inputs_embeds=H_aug)      # length-grouped forwards, cache rows [0, lens)
     lens = torch.tensor(lens0, dtype=torch.int32, device=dev)
-    last = hidden[torch.arange(n, device=dev), (lens - 1).long()]
     # stop rules of Evaluation_generator.py:168-175 in augmented positions (r fused rows sit inside every prompt)
     limit = cap if mode == "val" else min(cap, max_len - n_spl + r)
     gen = dec.run(last, lens, 11 if mode == "val" else cap, limit, eos)

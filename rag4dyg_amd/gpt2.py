@@ -270,6 +270,92 @@ class GPT2Model(_PreTrained):
         kv_cache[:, :, :T] = r["qkv"][..., d:]
         return r["hidden"]
 
+    @staticmethod
+    def length_buckets(lens, max_buckets=16, bucket_cost=48):
+        """Split sequences into <= ``max_buckets`` groups of similar length: minimises the padded positions
+        sum(count_b * longest_b) plus ``bucket_cost`` positions per group.  Returns lists of indices, longest group first."""
+        order = sorted(range(len(lens)), key=lambda i: -lens[i])
+        n = len(order)
+        if n == 0:
+            return []
+        INF = float("inf")
+        best = [[INF] * (n + 1) for _ in range(max_buckets + 1)]      # best[k][j]: first j sequences (longest first) in k groups
+        cut = [[0] * (n + 1) for _ in range(max_buckets + 1)]
+        best[0][0] = 0
+        for k in range(1, max_buckets + 1):
+            for j in range(1, n + 1):
+                for i in range(j):                                     # group = order[i:j], padded to lens[order[i]]
+                    c = best[k - 1][i] + (j - i) * lens[order[i]] + bucket_cost
+                    if c < best[k][j]:
+                        best[k][j], cut[k][j] = c, i
+        k = min(range(1, max_buckets + 1), key=lambda kk: best[kk][n])
+        groups, j = [], n
+        while j > 0:
+            i = cut[k][j]
+            groups.append(order[i:j])
+            j, k = i, k - 1
+        return groups[::-1]
+
+    @torch.no_grad()
+    def encode_groups(self, batches, embeds=False, want_hidden=True, want_qkv=False, want_meanpool=False):
+        """Several right-padded batches -- ids [B_g, T_g] or, with ``embeds``, embeddings [B_g, T_g, d] -- in ONE launch
+        sequence (``r4d_gpt2_encode_groups_ex_f32``): row-wise work runs over the concatenated rows, attention per batch.
+        Returns dict(hidden [rows, d], qkv [L, rows, 3d], meanpool [sum B, d], row0 = first row of every batch)."""
+        if not batches:
+            raise ValueError("encode_groups: no batches")
+        d, L = self.config.n_embd, self.config.n_layer
+        ts = []
+        for b in batches:
+            if not b.is_cuda:
+                raise _lib.R4DError("rag4dyg_amd runs on the GPU only: move inputs to 'cuda' (no CPU fallback)")
+            ts.append(b.to(torch.float32).contiguous() if embeds else b.view(-1, b.shape[-1]).to(torch.int64).contiguous())
+        n, dev = len(ts), ts[0].device
+        lib = _lib.load()
+        c, w, _keep = self._c_structs()
+        Bs = (ctypes.c_int32 * n)(*[int(t.shape[0]) for t in ts])
+        Ts = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in ts])
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        row0, rows = [], 0
+        for t in ts:
+            row0.append(rows)
+            rows += int(t.shape[0]) * int(t.shape[1])
+        ws = ops.workspace(lib.r4d_gpt2_groups_workspace_bytes(ctypes.byref(c), n, Bs, Ts), dev, "gpt2")
+        hidden = torch.empty(rows, d, dtype=torch.float32, device=dev) if want_hidden else None
+        pool = torch.empty(sum(int(t.shape[0]) for t in ts), d, dtype=torch.float32, device=dev) if want_meanpool else None
+        qkv = torch.empty(L, rows, 3 * d, dtype=torch.float32, device=dev) if want_qkv else None
+
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+        _lib.check(lib.r4d_gpt2_encode_groups_ex_f32(ctypes.byref(c), ctypes.byref(w), n, None if embeds else ptrs,
+                                                     ptrs if embeds else None, Bs, Ts, ptr(hidden), ptr(pool), ptr(qkv),
+                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "gpt2_encode_groups_ex")
+        return dict(hidden=hidden, qkv=qkv, meanpool=pool, row0=row0)
+
+    @torch.no_grad()
+    def prefill_last(self, kv_cache, lens, input_ids=None, inputs_embeds=None, max_buckets=16):
+        """``prefill`` for a RAGGED right-padded batch: the sequences are grouped by length (``length_buckets``), every
+        group is padded to its own longest member only, and all groups run in one launch sequence (``encode_groups``) -- a
+        causal model never lets padding reach a real position, so the cache rows [0, lens[i]) and the returned last real
+        hidden row of every sequence, [B, d], are those of one padded forward, for a fraction of the positions
+        (UCI-shaped prompts: 10.4 k padded positions -> 3.3 k)."""
+        src = input_ids if input_ids is not None else inputs_embeds
+        B, d, dev = src.shape[0], self.config.n_embd, src.device
+        if len(lens) != B or min(lens) < 1 or max(lens) > src.shape[1]:
+            raise ValueError("prefill_last: lens must hold one length in [1, T] per sequence")
+        if max(lens) > kv_cache.shape[2] or B != kv_cache.shape[1]:
+            raise ValueError(f"prefill_last: batch ({B}, {max(lens)}) does not fit the cache {tuple(kv_cache.shape[1:3])}")
+        groups = self.length_buckets(list(lens), max_buckets)
+        idxs = [torch.tensor(g, dtype=torch.long, device=dev) for g in groups]
+        tbs = [max(lens[i] for i in g) for g in groups]
+        r = self.encode_groups([src[ix, :tb] for ix, tb in zip(idxs, tbs)], embeds=input_ids is None, want_qkv=True)
+        last_rows = [0] * B
+        for g, ix, tb, r0 in zip(groups, idxs, tbs, r["row0"]):
+            kv_cache[:, ix, :tb] = r["qkv"][:, r0:r0 + len(g) * tb, d:].view(-1, len(g), tb, 2 * d)
+            for j, i in enumerate(g):
+                last_rows[i] = r0 + j * tb + lens[i] - 1
+        return r["hidden"][torch.tensor(last_rows, dtype=torch.long, device=dev)]
+
     @torch.no_grad()
     def decode_step(self, kv_cache, pos, input_ids=None, inputs_embeds=None):
         """One new position per sequence (``r4d_gpt2_decode_step_f32``): ``pos`` int32 [B] = positions already cached;

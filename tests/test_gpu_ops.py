@@ -246,6 +246,35 @@ def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B)
                 assert device_loop(seqs2, max_gen, limit, eos, cap) == host_loop(seqs2, max_gen, min(limit, cap), eos, cap)
 
 
+def test_prefill_last_length_groups_equal_padded_prefill(dev):
+    """prefill_last (length-grouped forwards) fills the same cache rows and returns the same last hidden rows as one
+    right-padded prefill, for ids and for inputs_embeds."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    L, H, d, V, P = 2, 8, 512, 90, 512
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=5, random_affine=True)
+    m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    tr = m.to(dev).eval().transformer
+    g = torch.Generator().manual_seed(9)
+    lens = [137, 9, 79, 83, 3, 120, 38, 1, 81, 221, 45, 39, 300]
+    B, T = len(lens), max(lens)
+    ids = torch.zeros(B, T, dtype=torch.int64)
+    for i, n in enumerate(lens):
+        ids[i, :n] = torch.randint(0, V, (n,), generator=g)
+    ids = ids.to(dev)
+    groups = tr.length_buckets(lens)
+    assert 1 < len(groups) <= 16 and sorted(i for grp in groups for i in grp) == list(range(B))
+    for kind in ("ids", "embeds"):
+        kw = {"input_ids": ids} if kind == "ids" else {"inputs_embeds": tr.wte.weight[ids]}
+        c0, c1 = tr.new_kv_cache(B, T + 8, dev).zero_(), tr.new_kv_cache(B, T + 8, dev).zero_()
+        hidden = tr.prefill(c0, **kw)
+        last = tr.prefill_last(c1, lens, **kw)
+        for i, n in enumerate(lens):
+            assert rel_err(last[i].cpu().numpy(), hidden[i, n - 1].cpu().numpy()) < 1e-5, (kind, i)
+            assert rel_err(c1[:, i, :n].cpu().numpy(), c0[:, i, :n].cpu().numpy()) < 1e-5, (kind, i)
+
+
 def test_lm_logits_odd_vocab(dev):
     from rag4dyg_amd import ops
     g = torch.Generator().manual_seed(3)

@@ -374,3 +374,24 @@ def test_evaluation_metrics_natural_log_ndcg():
     assert abs(got - want) < 1e-15
     assert E.recall_k(['1', '2'], ['2', '5'], 5) == 0.5 and E.precision_k(['1', '2'], ['2', '5'], 5) == 0.2
     assert E.map_k(['7', '2', '5'], ['2', '5'], 3) == 1 / 2 + 2 / 3
+
+
+def test_length_buckets_partition_and_cost():
+    """GPT2Model.length_buckets: a partition into <= max_buckets groups, never worse than one padded batch, optimal
+    against brute force on a small case."""
+    import itertools
+    from rag4dyg_amd.gpt2 import GPT2Model
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        lens = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(1, 33)))]
+        groups = GPT2Model.length_buckets(lens, max_buckets=4, bucket_cost=384)
+        assert sorted(i for g in groups for i in g) == list(range(len(lens))) and 1 <= len(groups) <= 4
+        cost = sum(len(g) * max(lens[i] for i in g) + 384 for g in groups)
+        assert cost <= len(lens) * max(lens) + 384
+    lens = [50, 7, 300, 45, 8, 299, 51]
+    order = sorted(lens, reverse=True)
+    best = min(sum((b - a) * order[a] + 100 for a, b in zip((0,) + cuts, cuts + (len(lens),)))
+               for k in range(0, 3) for cuts in itertools.combinations(range(1, len(lens)), k))
+    groups = GPT2Model.length_buckets(lens, max_buckets=3, bucket_cost=100)
+    assert sum(len(g) * max(lens[i] for i in g) + 100 for g in groups) == best
+    assert GPT2Model.length_buckets([]) == []

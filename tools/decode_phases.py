@@ -1,3 +1,6 @@
+"""Where a batch of the RAG generator's evaluation goes (UCI_13 shape, L6 H8 d768, top-7 graph pooling, val mode):
+fusion rows / prefill / decode steps, the decode step per kernel class (launch profiler), graph vs kernel-by-kernel.
+    python tools/decode_phases.py            (R4D_DECODE_GRAPH=0: no HIP graph)"""
 import sys, time, types, os
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -30,7 +33,7 @@ def timed(name, fn):
     return w
 gen.fusion_rows_batch = timed("fusion_rows_batch", gen.fusion_rows_batch)
 tr = model.transformer
-tr.prefill = timed("prefill", tr.prefill)
+tr.prefill_last = timed("prefill_last", tr.prefill_last)
 gpt2.GreedyDecoder.run = timed("decoder.run", gpt2.GreedyDecoder.run)
 gpt2.GreedyDecoder._steps = timed("  decoder._steps", gpt2.GreedyDecoder._steps)
 for rep in range(2):
