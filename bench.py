@@ -189,8 +189,10 @@ def main():
             pipe = PipelinedShardedTopK(index.pool_hat, index.index_offset, k, local_topk, ops.merge_topk)
             probe = ops.normalize_rows(torch.randn(QB * G, shape.n_embd, device=device))
             got = [r for r in (pipe.submit(probe), pipe.submit(probe)) if r is not None] + pipe.flush()
+            ref = sharded_topk(gather(probe), index.pool_hat, index.index_offset, k, local_topk, ops.merge_topk)
             torch.cuda.synchronize()
             assert len(got) == 2 and got[0][1].shape == (QB * G * world, k)
+            assert all(torch.equal(g_[0], ref[0]) and torch.equal(g_[1], ref[1]) for g_ in got), "pipelined != synchronous"
         except Exception as e:                                        # noqa: BLE001 -- never lose the run to the overlap
             if rank == 0:
                 print(f"[bench] pipelined collectives unavailable ({type(e).__name__}: {e}); using the synchronous form",
