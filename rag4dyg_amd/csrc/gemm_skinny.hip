@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------- 8-wave kernel
+#ifndef SK_DBG
+#define SK_DBG 0              // tuning aid (tools/kc_ablate.sh gemm_skinny.hip SK_DBG n): 1 no MFMAs, 2 no weight loads, 4 no x loads, 8 no LDS reduction
+#endif
 constexpr int S8_NW = 8;
 constexpr int S8_LDR = 33;                             // partial-tile row stride in LDS (floats)
 
@@ -132,11 +135,12 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b[g][u] = wrow[8 * g + u];
+        for (int u = 0; u < 4; ++u) b[g][u] = (SK_DBG & 2) ? make_float4(1.f, 2.f, 3.f, (float)tid) : wrow[8 * g + u];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[g][u] = xrow[8 * g + u];          // rows >= M repeat row M-1: computed, never stored
+        for (int u = 0; u < 4; ++u)                                     // rows >= M repeat row M-1: computed, never stored
+            a[g][u] = (SK_DBG & 4) ? make_float4(1.f, 2.f, 3.f, (float)tid) : xrow[8 * g + u];
     if (LN) {
         const float4* __restrict__ gwp = reinterpret_cast<const float4*>(ln_w + k0) + 4 * lh;
         const float4* __restrict__ gbp = reinterpret_cast<const float4*>(ln_b + k0) + 4 * lh;
@@ -199,11 +203,18 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (SK_DBG & 1) { acc[(4 * g + u) & 15] += a[g][u].x * b[g][u].x + a[g][u].y * b[g][u].y + a[g][u].z * b[g][u].z + a[g][u].w * b[g][u].w; continue; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].x, b[g][u].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].y, b[g][u].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].z, b[g][u].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u].w, b[g][u].w, acc, 0, 0, 0);
         }
+    if (SK_DBG & 8) {                                  // every wave stores its own tile: no LDS, no barrier
+        if (row < N && wid == 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[(long long)min((r & 3) + 8 * (r >> 2) + 4 * lh, M - 1) * N + row] = acc[r] + bias_n + res0;
+        return;
+    }
     float* mine = red + wid * 32 * S8_LDR;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lh) * S8_LDR + li] = acc[r];
