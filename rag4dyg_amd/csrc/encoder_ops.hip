@@ -331,7 +331,8 @@ int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t
                             float* out, hipStream_t s) {
     const int hd = d / H;
     R4D_REQUIRE(hd * H == d && hd % 4 == 0 && hd <= 256, "decode attention: head_dim=%d (multiple of 4, max 256)", hd);
-    R4D_REQUIRE(d % 4 == 0 && t_cap >= 1, "decode attention: d=%d t_cap=%d", d, t_cap);
+    R4D_REQUIRE(d % 4 == 0 && t_cap >= 1 && (size_t)t_cap * 2 * d * 4 < ((size_t)1 << 31),
+                "decode attention: d=%d t_cap=%d (a sequence's cache must stay below 2 GB)", d, t_cap);
     if (B <= 0) return R4D_OK;
     // algorithmic bytes: the cached K and V rows of every head (upper bound t_cap/2 on average is unknown here: count
     // the new row only; callers that profile use the HIP-event time)

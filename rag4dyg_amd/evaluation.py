@@ -14,6 +14,7 @@ import json
 import math
 import os
 
+import numpy as np
 import torch
 
 from . import ops
@@ -86,7 +87,6 @@ def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, dev
     over all sequences, argmax and stop rules on the device (``GreedyDecoder``).  Same ids as the one-at-a-time loop up to fp32 summation order (the reference re-runs the full
     forward per token, ``Evaluation_SimpleDyG.py:126-134``)."""
     tr = model.transformer
-    wte = tr.wte.weight
     n = len(token_lists)
     if n == 0:
         return []
@@ -95,9 +95,10 @@ def greedy_decode_batch(model, tokenizer, token_lists, mode, max_len, n_spl, dev
     tmax = max(len(t) for t in toks)
     budget = 11 if mode == "val" else max(1, max_len - n_spl - min(len(t) for t in toks))
     cap = min(tmax + budget + 1, tr.wpe.num_embeddings)
-    ids = torch.zeros(n, tmax, dtype=torch.long, device=device)
+    ids_h = np.zeros((n, tmax), dtype=np.int64)                        # built on the host: ONE upload
     for i, t in enumerate(toks):
-        ids[i, :len(t)] = torch.tensor(t, dtype=torch.long, device=device)
+        ids_h[i, :len(t)] = t
+    ids = torch.from_numpy(ids_h).to(device)
     dec = tr.greedy_decoder(n, cap)
     last = tr.prefill_last(dec.cache, [len(t) for t in toks], input_ids=ids)
     lens = torch.tensor([len(t) for t in toks], dtype=torch.int32, device=device)

@@ -19,6 +19,7 @@ Training (``train/train_generator.py``) is out of scope: ``main_generator.py --d
 import json
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -158,17 +159,13 @@ def fusion_rows(args, model, tokenizer, dataset, idxs_sim, top_k):
 
 
 @torch.no_grad()
-def fusion_rows_batch(args, model, tokenizer, dataset, index_lists, top_k):
-    """``fusion_rows`` of many queries -> [n, r, d].  One-layer graph pooling (the shipped configuration) collapses
-    algebraically: mean_i (A_norm (X W^T) + b)_i = sum_j c_j (X W^T)_j + b with c_j = (1/n) sum_i A_norm[i,j]
-    = d_j^-1/2 (d_j^-1/2 + sum_{i in N(j)} d_i^-1/2) / n, so the whole batch is ONE gather, ONE projection GEMM over the
-    concatenated nodes and ONE [n_queries, n_nodes] x [n_nodes, d] GEMM with the block-diagonal pooling weights -- no
-    per-query adjacency matrices.  Other configurations fall back to the per-query path."""
+def fusion_host_prep(args, model, dataset, index_lists, top_k):
+    """Host half of ``fusion_rows_batch`` for one-layer graph pooling: the union-of-stars graphs of all queries and their
+    pooling weights ``c`` (no GPU work -- the evaluation runs it for batch i+1 on a helper thread while batch i
+    decodes).  Returns (node ids, C [n_queries, n_nodes] float32) or None for the other fusion configurations."""
     gnn = getattr(model, "gnn_fusion", None)
     if not (args.fusion == "graphpooling" and gnn is not None and gnn.n_layers == 1):
-        return torch.stack([fusion_rows(args, model, tokenizer, dataset, ix, top_k) for ix in index_lists])
-    import numpy as np
-    wte = model.transformer.wte.weight
+        return None
     nodes_all, spans, weights = [], [], []
     for ix in index_lists:
         order, edges = star_union_graph(dataset.retrieval_sources, [int(v) for v in ix][:top_k])
@@ -189,7 +186,25 @@ def fusion_rows_batch(args, model, tokenizer, dataset, index_lists, top_k):
     for q, ((o, n), c) in enumerate(zip(spans, weights)):
         C[q, o:o + n] = c
     nodes_all += [0] * (ntot - len(nodes_all))                         # padding nodes carry weight 0
-    X = wte[torch.tensor(nodes_all, dtype=torch.long, device=wte.device)]
+    return np.asarray(nodes_all, dtype=np.int64), C
+
+
+@torch.no_grad()
+def fusion_rows_batch(args, model, tokenizer, dataset, index_lists, top_k, prep=None):
+    """``fusion_rows`` of many queries -> [n, r, d].  One-layer graph pooling (the shipped configuration) collapses
+    algebraically: mean_i (A_norm (X W^T) + b)_i = sum_j c_j (X W^T)_j + b with c_j = (1/n) sum_i A_norm[i,j]
+    = d_j^-1/2 (d_j^-1/2 + sum_{i in N(j)} d_i^-1/2) / n, so the whole batch is ONE gather, ONE projection GEMM over the
+    concatenated nodes and ONE [n_queries, n_nodes] x [n_nodes, d] GEMM with the block-diagonal pooling weights -- no
+    per-query adjacency matrices (``fusion_host_prep`` builds c; pass its result as ``prep`` when it was computed
+    ahead).  Other configurations fall back to the per-query path."""
+    if prep is None:
+        prep = fusion_host_prep(args, model, dataset, index_lists, top_k)
+    if prep is None:
+        return torch.stack([fusion_rows(args, model, tokenizer, dataset, ix, top_k) for ix in index_lists])
+    nodes, C = prep
+    wte = model.transformer.wte.weight
+    gnn = model.gnn_fusion
+    X = wte[torch.from_numpy(nodes).to(wte.device)]
     conv = gnn.convs[0]
     Y = _linear(X, conv.lin)                                           # [ntot, d]
     out = ops.conv1d(torch.from_numpy(C).to(wte.device), Y.contiguous(), conv.bias.contiguous())
@@ -230,7 +245,7 @@ def greedy_decode_rag(args, model, tokenizer, dataset, indexed_tokens, index, mo
 
 
 @torch.no_grad()
-def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl):
+def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl, prep=None):
     """``greedy_decode_rag`` for MANY queries at once, with a key/value cache.
 
     The reference decodes one query at a time and re-runs the full forward for every generated token
@@ -247,7 +262,7 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
     n = len(token_lists)
     if n == 0:
         return []
-    sims = fusion_rows_batch(args, model, tokenizer, dataset, index_lists, args.topK)                       # [n, r, d]
+    sims = fusion_rows_batch(args, model, tokenizer, dataset, index_lists, args.topK, prep)                 # [n, r, d]
     r = sims.shape[1]
     eos = tokenizer.encode("<|endoftext|>")
     toks = [list(t) for t in token_lists]
@@ -255,12 +270,11 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
     tmax = max(lens0)
     budget = 11 if mode == "val" else max(1, max_len - n_spl - min(len(t) for t in toks))
     cap = min(tmax + budget + 1, tr.wpe.num_embeddings)
-    ids = torch.zeros(n, tmax, dtype=torch.long, device=dev)           # augmented layout: [t0 t1 | r fused slots | t2 ...]
-    for i, t in enumerate(toks):
-        tt = torch.tensor(t, dtype=torch.long, device=dev)
-        ids[i, :2] = tt[:2]
-        ids[i, 2 + r:len(t) + r] = tt[2:]
-    H_aug = wte[ids]
+    ids_h = np.zeros((n, tmax), dtype=np.int64)                        # augmented layout: [t0 t1 | r fused slots | t2 ...]
+    for i, t in enumerate(toks):                                       # built on the host: ONE upload
+        ids_h[i, :2] = t[:2]
+        ids_h[i, 2 + r:len(t) + r] = t[2:]
+    H_aug = wte[torch.from_numpy(ids_h).to(dev)]
     H_aug[:, 2:2 + r] = sims
     dec = tr.greedy_decoder(n, cap)
     last = tr.prefill_last(dec.cache, lens0, inputs_embeds=H_aug)      # length-grouped forwards, cache rows [0, lens)
@@ -271,6 +285,25 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
     for t, g in zip(toks, gen):
         t.extend(g)
     return toks
+
+
+def decode_rag_batches(args, model, tokenizer, dataset, batches, mode, max_len, n_spl):
+    """``greedy_decode_rag_batch`` over a list of (token_lists, index_lists) batches, yielding each batch's outputs.  The
+    host half of the NEXT batch's fusion (graph construction, pure Python / numpy) runs on a helper thread while the
+    current batch decodes -- the main thread spends that time waiting for the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
+    if not batches:
+        return
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = pool.submit(fusion_host_prep, args, model, dataset, batches[0][1], args.topK)
+        for b, (toks, idxs) in enumerate(batches):
+            prep = fut.result()
+            if b + 1 < len(batches):
+                fut = pool.submit(fusion_host_prep, args, model, dataset, batches[b + 1][1], args.topK)
+            if prep is None:                                           # other fusion modes: everything in-line
+                yield greedy_decode_rag_batch(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl)
+            else:
+                yield greedy_decode_rag_batch(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl, prep)
 
 
 # ------------------------------------------------------------------------------------------------ dataset / eval
@@ -354,15 +387,16 @@ def get_eval_metrics_generator(args, epoch, model, tokenizer, step, mode="val", 
             indexed_tokens = indexed_tokens[-1000:]
         jobs.append((i, input_text, user_id, target_list, indexed_tokens, index, num_user_test))
     bs = max(1, int(getattr(args, "per_gpu_eval_batch_size", 32) or 32))
-    for b0 in range(0, len(jobs), bs):                  # the queries are independent: decode a batch of them per step
-        chunk = jobs[b0:b0 + bs]
-        if is_rag:
-            outs = greedy_decode_rag_batch(args, model, tokenizer, train_dataset, [j[4] for j in chunk],
-                                           [j[5] for j in chunk], mode, MAX_LEN, len(spl_tokens))
-        else:
-            from .evaluation import greedy_decode
-            outs = [greedy_decode(model, tokenizer, j[4], mode, MAX_LEN, len(spl_tokens), next(model.parameters()).device)
-                    for j in chunk]
+    chunks = [jobs[b0:b0 + bs] for b0 in range(0, len(jobs), bs)]      # the queries are independent: a batch per step
+    if is_rag:
+        results = decode_rag_batches(args, model, tokenizer, train_dataset,
+                                     [([j[4] for j in c], [j[5] for j in c]) for c in chunks], mode, MAX_LEN,
+                                     len(spl_tokens))
+    else:
+        from .evaluation import greedy_decode
+        dev0 = next(model.parameters()).device
+        results = ([greedy_decode(model, tokenizer, j[4], mode, MAX_LEN, len(spl_tokens), dev0) for j in c] for c in chunks)
+    for chunk, outs in zip(chunks, results):
         for (i, input_text, user_id, target_list, indexed_tokens, _ix, nut), out_ids in zip(chunk, outs):
             predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
             predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]

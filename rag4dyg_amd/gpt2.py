@@ -274,24 +274,30 @@ class GPT2Model(_PreTrained):
     def length_buckets(lens, max_buckets=16, bucket_cost=48):
         """Split sequences into <= ``max_buckets`` groups of similar length: minimises the padded positions
         sum(count_b * longest_b) plus ``bucket_cost`` positions per group.  Returns lists of indices, longest group first."""
+        import numpy as np
         order = sorted(range(len(lens)), key=lambda i: -lens[i])
         n = len(order)
         if n == 0:
             return []
-        INF = float("inf")
-        best = [[INF] * (n + 1) for _ in range(max_buckets + 1)]      # best[k][j]: first j sequences (longest first) in k groups
-        cut = [[0] * (n + 1) for _ in range(max_buckets + 1)]
-        best[0][0] = 0
-        for k in range(1, max_buckets + 1):
-            for j in range(1, n + 1):
-                for i in range(j):                                     # group = order[i:j], padded to lens[order[i]]
-                    c = best[k - 1][i] + (j - i) * lens[order[i]] + bucket_cost
-                    if c < best[k][j]:
-                        best[k][j], cut[k][j] = c, i
-        k = min(range(1, max_buckets + 1), key=lambda kk: best[kk][n])
-        groups, j = [], n
+        Ls = np.asarray([lens[i] for i in order], dtype=np.float64)
+        ii, jj = np.arange(n)[:, None], np.arange(1, n + 1)[None, :]
+        W = np.where(ii < jj, (jj - ii) * Ls[:, None] + bucket_cost, np.inf)       # cost of the group order[i:j]
+        prev = np.full(n + 1, np.inf)
+        prev[0] = 0.0
+        cuts, best_k, best_cost = [], 0, np.inf
+        for k in range(1, min(max_buckets, n) + 1):                                 # best[k][j] = min_i best[k-1][i] + W[i][j]
+            cand = prev[:n, None] + W
+            cut = cand.argmin(axis=0)
+            cur = np.concatenate(([np.inf], cand[cut, np.arange(n)]))
+            cuts.append(cut)
+            if cur[n] < best_cost:
+                best_k, best_cost = k, cur[n]
+            elif cur[n] > best_cost:
+                break                                                               # one more group only adds its cost
+            prev = cur
+        groups, j, k = [], n, best_k
         while j > 0:
-            i = cut[k][j]
+            i = int(cuts[k - 1][j - 1])
             groups.append(order[i:j])
             j, k = i, k - 1
         return groups[::-1]

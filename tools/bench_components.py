@@ -155,13 +155,13 @@ def generator():
     t0 = time.perf_counter()
     ntok1 = run_gpu(list(zip(queries[:16], idxs[:16])))
     el1 = time.perf_counter() - t0
-    gen.greedy_decode_rag_batch(args, model, tok, ds, queries[:8], idxs[:8], "val", 1024, 12)
+    gen.greedy_decode_rag_batch(args, model, tok, ds, queries[:32], idxs[:32], "val", 1024, 12)     # warm-up (decoder, graph)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ntok = 0
-    for b0 in range(0, len(queries), 32):                               # --per_gpu_eval_batch_size 32
-        outs = gen.greedy_decode_rag_batch(args, model, tok, ds, queries[b0:b0 + 32], idxs[b0:b0 + 32], "val", 1024, 12)
-        ntok += sum(len(o) - len(q) for o, q in zip(outs, queries[b0:b0 + 32]))
+    batches = [(queries[b0:b0 + 32], idxs[b0:b0 + 32]) for b0 in range(0, len(queries), 32)]     # --per_gpu_eval_batch_size 32
+    for (qs, _ix), outs in zip(batches, gen.decode_rag_batches(args, model, tok, ds, batches, "val", 1024, 12)):
+        ntok += sum(len(o) - len(q) for o, q in zip(outs, qs))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     t0 = time.perf_counter()
