@@ -3,12 +3,14 @@
 ``--do_eval`` loads every generator checkpoint under ``--output_dir`` (GPT-2 + ``gnn_fusion`` / ``mlp_fusion`` weights,
 ``main_generator.py:108-127``) and runs the reference's RAG evaluation -- graph-pooling or MLP fusion of the top-K
 retrieved training sequences (``*_index.gen`` written by this build's ``main_retriever.py``), greedy link prediction,
-R@5 / NDCG@5 / Jaccard (``utils/Evaluation_generator.py:49-265``) -- on the MI355X kernels.
+R@5 / NDCG@5 / Jaccard (``utils/Evaluation_generator.py:49-265``) -- on the MI355X kernels; launched with
+``python -m torch.distributed.run --nproc-per-node N`` the test queries are decoded data-parallel, one process per GPU.
 Generator TRAINING (``train/train_generator.py``, backward pass) is not part of this build and raises."""
 import glob
 import os
 
 import torch
+import torch.distributed
 
 from rag4dyg_amd.cli_args import GENERATOR, parse
 from rag4dyg_amd.generator import get_eval_metrics_generator
@@ -35,9 +37,17 @@ def main(argv=None):
         raise ValueError("--eval_data_file should be specified when do_eval is true")
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("main_generator: needs the MI355X (rag4dyg_amd has no CPU fallback)")
-    torch.cuda.set_device(max(args.local_rank, 0))
-    args.device = torch.device("cuda", max(args.local_rank, 0))
+    # one process per GPU: under `python -m torch.distributed.run --nproc-per-node N main_generator.py ...` the test
+    # queries are decoded data-parallel (generator.get_eval_metrics_generator); "nccl" IS RCCL on ROCm
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", max(args.local_rank, 0)))
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    args.device = torch.device("cuda", dev_index)
     args.n_gpu = 1
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend=os.environ.get("R4D_DIST_BACKEND", "nccl"))
+    rank0 = not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0
     torch.manual_seed(args.seed)
     args.run_name = run_name_of(args)
     model, tokenizer, model_class, args = get_model_tokenizer(args, MODEL_CLASSES)
@@ -54,7 +64,8 @@ def main(argv=None):
         if args.eval_all_checkpoints:
             checkpoints = list(os.path.dirname(c) for c in
                                sorted(glob.glob(args.output_dir + "/**/" + WEIGHTS_NAME, recursive=True)))
-        print("Evaluate the following checkpoints: {}".format(checkpoints))
+        if rank0:
+            print("Evaluate the following checkpoints: {}".format(checkpoints))
         for checkpoint in checkpoints:
             global_step = checkpoint.split("-")[-1] if len(checkpoints) > 1 else ""
             state_dict = torch.load(os.path.join(checkpoint, WEIGHTS_NAME), map_location="cpu", weights_only=True)
@@ -63,7 +74,8 @@ def main(argv=None):
             model.to(args.device)
             results[checkpoint] = get_eval_metrics_generator(args, 0, model, tokenizer, global_step, mode="test",
                                                              is_rag=True)
-            print(f"[{checkpoint}] {results[checkpoint]}")
+            if rank0:
+                print(f"[{checkpoint}] {results[checkpoint]}")
     return results
 
 

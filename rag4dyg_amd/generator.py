@@ -388,32 +388,48 @@ def get_eval_metrics_generator(args, epoch, model, tokenizer, step, mode="val", 
         jobs.append((i, input_text, user_id, target_list, indexed_tokens, index, num_user_test))
     bs = max(1, int(getattr(args, "per_gpu_eval_batch_size", 32) or 32))
     chunks = [jobs[b0:b0 + bs] for b0 in range(0, len(jobs), bs)]      # the queries are independent: a batch per step
+    # data-parallel over the test queries (one process per GPU, main_generator.py under torch.distributed.run): a rank
+    # decodes every world-th batch, the generated ids are all-gathered as objects, and EVERY rank then scores all queries
+    # in file order -- the sums are those of the single-process run, bit for bit
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    mine = chunks[rank::world]
     if is_rag:
         results = decode_rag_batches(args, model, tokenizer, train_dataset,
-                                     [([j[4] for j in c], [j[5] for j in c]) for c in chunks], mode, MAX_LEN,
+                                     [([j[4] for j in c], [j[5] for j in c]) for c in mine], mode, MAX_LEN,
                                      len(spl_tokens))
     else:
         from .evaluation import greedy_decode
         dev0 = next(model.parameters()).device
-        results = ([greedy_decode(model, tokenizer, j[4], mode, MAX_LEN, len(spl_tokens), dev0) for j in c] for c in chunks)
-    for chunk, outs in zip(chunks, results):
-        for (i, input_text, user_id, target_list, indexed_tokens, _ix, nut), out_ids in zip(chunk, outs):
-            predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
-            predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
-            for topi, k in enumerate(topk):
-                try:
-                    top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
-                except ZeroDivisionError:
-                    pass
-                top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
-                top_k_scores['R'][topi] += Eval.recall_k(predicted, target_list, k)
-            generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
-                                      'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
-                                      'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
-                                      'num_user_test': str(nut)})
+        results = ([greedy_decode(model, tokenizer, j[4], mode, MAX_LEN, len(spl_tokens), dev0) for j in c] for c in mine)
+    generated = {}
+    for chunk, outs in zip(mine, results):
+        for job, out_ids in zip(chunk, outs):
+            generated[job[0]] = [int(t) for t in out_ids]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, generated)
+        generated = {k: v for part in parts for k, v in part.items()}
+    for (i, input_text, user_id, target_list, indexed_tokens, _ix, nut) in jobs:
+        out_ids = generated[i]
+        predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
+        predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
+        for topi, k in enumerate(topk):
+            try:
+                top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
+            except ZeroDivisionError:
+                pass
+            top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
+            top_k_scores['R'][topi] += Eval.recall_k(predicted, target_list, k)
+        generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
+                                  'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
+                                  'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
+                                  'num_user_test': str(nut)})
     for metric in metric_terms:
         for topi, _k in enumerate(topk):
             top_k_scores[metric][topi] = round(top_k_scores[metric][topi] / max(num_user_test, 1), 4)
+    if rank != 0:                                       # rank 0 writes the files
+        return top_k_scores
     result_save_file = os.path.join(out_dir, mode + '_results_epoch.csv')
     if is_best:
         with open(result_save_file, 'w') as f:

@@ -2,12 +2,14 @@
 drop-in CLIs on a synthetic dataset written in the reference's file grammar, checked against the oracle."""
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import REPO, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -386,3 +388,20 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
     assert all(0.0 <= r[k][0] <= 1.0 for k in ("R", "NDCG", "jaccard"))
     outs = list((tmp_path / "rag_results" / "val_mode" / "toy" / "4").glob("*/results/test_score/eval_results.json"))
     assert len(outs) == 1
+    # data-parallel over the test queries: two processes (torch.distributed.run, gloo here: one GPU) decode every other
+    # batch of 4 and write the same predictions and metrics as the single-process run
+    single = json.load(open(outs[0]))
+    procs = []
+    for rk in range(2):           # what torch.distributed.run sets per rank (its own parser trips over the reference's `--m`)
+        env = dict(os.environ, R4D_DIST_BACKEND="gloo", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                   RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "main_generator.py")] + argv +
+                                      ["--per_gpu_eval_batch_size", "4"], cwd=tmp_path, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    done = [pr.communicate(timeout=600) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [e[-1500:] for _, e in done]
+    p = types.SimpleNamespace(stdout=done[0][0])
+    double = json.load(open(outs[0]))
+    assert double.keys() == single.keys() and len(single) == n_q
+    assert sum(double[k].get("predicted") == single[k].get("predicted") for k in single) >= len(single) - 1
+    assert f"'R': [{r['R'][0]}]" in p.stdout or sum(double[k] == single[k] for k in single) < len(single)
