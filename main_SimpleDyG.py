@@ -8,6 +8,7 @@ import glob
 import os
 
 import torch
+import torch.distributed
 
 from rag4dyg_amd.cli_args import SIMPLEDYG, parse
 from rag4dyg_amd.dataloader import LineByLineTextDataset, get_dataloader
@@ -45,9 +46,15 @@ def main(argv=None):
         raise ValueError("--eval_data_file should be specified when do_eval is true")
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("main_SimpleDyG: needs the MI355X (rag4dyg_amd has no CPU fallback)")
-    torch.cuda.set_device(max(args.local_rank, 0))
-    args.device = torch.device("cuda", max(args.local_rank, 0))
+    # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set): the evaluation's sequences are decoded
+    # data-parallel (rag4dyg_amd.evaluation.get_eval_metrics); "nccl" IS RCCL on ROCm
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev_index = int(os.environ.get("LOCAL_RANK", max(args.local_rank, 0))) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    args.device = torch.device("cuda", dev_index)
     args.n_gpu = 1
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend=os.environ.get("R4D_DIST_BACKEND", "nccl"))
     torch.manual_seed(args.seed)
     args.para_names = ['dataset', 'method', 'time', 'nlayer', 'nhead', 'nemb', 'bz', 'lr', 'seed']
     args.para_values = [args.dataset, 'SimpleDyG', args.timestamp, args.n_layer, args.n_head, args.n_embed,

@@ -8,7 +8,8 @@ Differences from the reference ``main()`` (``main_retriever.py:45-164``):
   * wandb is not imported (logging only); ``--model_name_or_path gpt2`` does not touch the network;
   * the eval batch stays ``per_gpu_eval_batch_size`` (32): ``n_gpu`` is pinned to 1 for BATCHING because a mean-
     pooled embedding depends on its padded batch (``train_retriever.py:420``) -- with 8 visible GPUs the reference
-    itself would batch 256 and produce different embeddings; multi-GPU here means pool sharding instead.
+    itself would batch 256 and produce different embeddings; multi-GPU here means pool sharding instead: started
+    once per GPU, the pool encode is split over the ranks by whole batches and all-gathered.
 """
 import glob
 import os
@@ -16,6 +17,7 @@ import random
 
 import numpy as np
 import torch
+import torch.distributed
 
 from rag4dyg_amd.cli_args import RETRIEVER, parse
 from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG, GPT2Model
@@ -50,10 +52,16 @@ def main(argv=None):
         raise ValueError("--eval_data_file should be specified when do_eval is true")
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("main_retriever: needs the MI355X (rag4dyg_amd has no CPU fallback)")
-    local = max(args.local_rank, 0)
+    # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, e.g. by torch.distributed.run): the pool encode
+    # is sharded over the ranks by whole reference batches (rag4dyg_amd.dist.encode_pool_sharded); "nccl" IS RCCL on ROCm
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", max(args.local_rank, 0))) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     args.device = torch.device("cuda", local)
     args.n_gpu = 1
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend=os.environ.get("R4D_DIST_BACKEND", "nccl"))
+        args.local_rank = -1                           # every rank evaluates; rank 0 writes the files
     lr_type = 'y' if args.learning_rate > 0 else 'n'
     ckpt = 1 if args.should_continue == 1 else 0
     args.para_names = ['d', 'alpha', 'eta', 'gamma', 'nl', 'nh', 'emb', 'bz', 'lr', 'lrdecay', 'tdecay', 'se', 'temp',

@@ -39,6 +39,49 @@ def all_gather_cat(t, group=None):
     return out
 
 
+def balanced_runs(costs, parts):
+    """Cut a sequence of item costs into ``parts`` contiguous runs of about equal total cost: run r ends at the first
+    item whose cumulative cost reaches (r+1)/parts of the total.  Returns [start, end) per run (runs may be empty)."""
+    total, cum, bounds, start, i = float(sum(costs)), 0.0, [], 0, 0
+    for r in range(parts):
+        target = total * (r + 1) / parts
+        while i < len(costs) and (cum < target or r == parts - 1):
+            cum += costs[i]
+            i += 1
+        bounds.append((start, i))
+        start = i
+    return bounds
+
+
+def all_gather_rows(t, counts, group=None):
+    """Concatenate row blocks of DIFFERENT heights (``counts[r]`` rows on rank r) along dim 0: one all-gather of blocks
+    padded to the tallest.  With the gloo backend (1-GPU rehearsal) the block is staged through host memory."""
+    world = dist.get_world_size(group)
+    tall = max(counts)
+    buf = torch.zeros((tall,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    buf[:t.shape[0]] = t
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:
+        out = all_gather_cat(buf.cpu(), group).to(t.device)
+    else:
+        out = all_gather_cat(buf, group)
+    return torch.cat([out[r * tall:r * tall + counts[r]] for r in range(world)])
+
+
+def encode_pool_sharded(encode, batches, group=None):
+    """Pool embeddings with the ENCODE sharded over the ranks: rank r encodes a contiguous run of whole reference batches
+    (a pool embedding depends on the batch it was padded with, so batches never split), then one all-gather hands every
+    rank the full [N, d] matrix in pool order.  ``encode(list of batches) -> [rows, d]``."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = balanced_runs([int(b.shape[0]) * int(b.shape[1]) for b in batches], world)     # equal padded positions
+    counts = [sum(int(b.shape[0]) for b in batches[s:e]) for s, e in bounds]
+    s, e = bounds[rank]
+    mine = encode(batches[s:e]) if e > s else None
+    if mine is None:
+        ref = encode(batches[:1])                                        # a rank without work still needs d and the dtype
+        mine = ref[:0]
+    return all_gather_rows(mine, counts, group)
+
+
 def sharded_topk(q_hat_all, pool_hat_shard, shard_offset, k, local_topk, merge, group=None):
     """Global top-k of every query against the sharded pool.
 

@@ -150,25 +150,40 @@ def get_eval_metrics(args, model, tokenizer, step, mode="val"):
             indexed_tokens = indexed_tokens[-1000:]
         jobs.append((i, input_text, user_id, target_list, indexed_tokens, num_user_test))
     bs = max(1, int(getattr(args, "per_gpu_eval_batch_size", 32) or 32))
-    for b0 in range(0, len(jobs), bs):              # independent sequences: one cached decode step serves a whole batch
-        chunk = jobs[b0:b0 + bs]
+    # independent sequences: one cached decode step serves a whole batch; started once per GPU (torch.distributed
+    # initialised by main_SimpleDyG.py) a rank decodes every world-th batch, the ids are all-gathered and EVERY rank
+    # scores all sequences in file order -- the sums of the single-process run
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    chunks = [jobs[b0:b0 + bs] for b0 in range(0, len(jobs), bs)]
+    generated = {}
+    for chunk in chunks[rank::world]:
         outs = greedy_decode_batch(model, tokenizer, [j[4] for j in chunk], mode, MAX_LEN, len(spl_tokens), device)
-        for (i, input_text, user_id, target_list, indexed_tokens, nut), out_ids in zip(chunk, outs):
-            predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
-            predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
-            for topi, k in enumerate(topk):
-                try:
-                    top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
-                except ZeroDivisionError:
-                    pass
-                top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
-            generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
-                                      'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
-                                      'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
-                                      'num_user_test': str(nut)})
+        for job, out_ids in zip(chunk, outs):
+            generated[job[0]] = [int(t) for t in out_ids]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, generated)
+        generated = {k: v for part in parts for k, v in part.items()}
+    for (i, input_text, user_id, target_list, indexed_tokens, nut) in jobs:
+        out_ids = generated[i]
+        predicted_list = tokenizer.decode(out_ids).split()[len(indexed_tokens):]
+        predicted = [t for t in predicted_list if t != user_id and t not in spl_tokens]
+        for topi, k in enumerate(topk):
+            try:
+                top_k_scores['NDCG'][topi] += Eval.ndcg_k(predicted, target_list, k)
+            except ZeroDivisionError:
+                pass
+            top_k_scores['jaccard'][topi] += Eval.jaccard(predicted, target_list)
+        generated_dict[i].update({'user_id': user_id, 'input': input_text, 'target_list': target_list,
+                                  'len input_text': len(input_text.split()), 'predicted_list_ori': predicted_list,
+                                  'predicted': predicted, 'NDCG@k': str(Eval.ndcg_k(predicted, target_list, 1)),
+                                  'num_user_test': str(nut)})
     for metric in metric_terms:
         for topi, _k in enumerate(topk):
             top_k_scores[metric][topi] = round(top_k_scores[metric][topi] / max(num_user_test, 1), 4)
+    if rank != 0:                                   # rank 0 writes the files
+        return top_k_scores
     result_save_file = os.path.join(save_score_path, mode + '_results_epoch.csv')
     if not os.path.exists(result_save_file):
         with open(result_save_file, 'w') as f:

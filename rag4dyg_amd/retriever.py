@@ -101,7 +101,15 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
     scores = DataLoader(scores, batch_size=args.eval_batch_size, shuffle=False, num_workers=0, drop_last=False)
 
     # HOT LOOP 1 (:414-422): pool embeddings, then one resident normalised index
-    train_embeddings = encode_batches(model, [batch.to(device) for batch in train_dataloader])    # fused groups
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+    rank0 = world == 1 or tdist.get_rank() == 0
+    if world > 1:        # one process per GPU: the pool ENCODE (the dominant cost) is sharded by whole batches, one all-gather
+        from .dist import encode_pool_sharded
+        train_embeddings = encode_pool_sharded(lambda bs: encode_batches(model, [b.to(device) for b in bs]),
+                                               list(train_dataloader))
+    else:
+        train_embeddings = encode_batches(model, [batch.to(device) for batch in train_dataloader])    # fused groups
     print('size of train_embeddings: ', train_embeddings.size())
     index = PoolIndex(train_embeddings)
     n_pool = len(index)
@@ -125,7 +133,7 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
         _vals, top_idx, dot_products = index.search(h_egos, topk, want_scores=True)
         loss = torch.nn.functional.binary_cross_entropy_with_logits(dot_products, score)      # metric only (:439-441)
         eval_loss += loss
-        if prefix == "best":
+        if prefix == "best" and rank0:
             if rank_output == "full":
                 index_rows = ops.argsort_desc(dot_products).cpu().numpy()
             else:
@@ -147,7 +155,7 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
     eval_metrics = {'hit@1': hit_1, 'hit@3': hit_3}
 
     result_save_file = os.path.join(save_file_path, "val_results.csv" if evaluate else "test_results.csv")
-    if prefix == "best":
+    if prefix == "best" and rank0:
         with open(result_save_file, "w") as f:                  # :485-495
             f.write(f"{'epoch'}, ")
             for param in args.para_names:
@@ -160,7 +168,7 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
             f.write('\n')
     if evaluate:
         return eval_metrics, eval_loss
-    if prefix == "best":                                        # :499-515 accumulate across runs
+    if prefix == "best" and rank0:                              # :499-515 accumulate across runs
         save_folder = 'topk_scores_seed_retrieval' if getattr(args, "run_seed", False) else 'topk_scores_finetune'
         os.makedirs(save_folder, exist_ok=True)
         result_save_test = os.path.join(save_folder, args.dataset + '_retrieval.csv')

@@ -191,6 +191,22 @@ def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch
     assert abs(hits[0] - ref_hits[0]) <= 0.03 and abs(hits[1] - ref_hits[1]) <= 0.03
     # tokenizer files written in the reference layout
     assert (tmp_path / "tokenizers" / "toy" / "4" / "tokenizer.json").exists()
+    # one process per GPU (two ranks, gloo on this one-GPU box): the pool encode is sharded by whole batches, every rank
+    # scores all queries, rank 0 writes -- same rankings and metrics as the single process
+    os.remove(res / "test_index.gen"); os.remove(res / "test_results.csv")
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, R4D_DIST_BACKEND="gloo", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                   RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "main_retriever.py")] + argv, cwd=tmp_path, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    done = [pr.communicate(timeout=600) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [e[-1500:] for _, e in done]
+    idx2 = np.array(_read_matrix(res / "test_index.gen", int))
+    assert idx2.shape == idx_rows.shape and (idx2[:, :5] == idx_rows[:, :5]).all(axis=1).mean() > 0.9
+    assert retrieval_ref.topk_matches_modulo_ties(S, idx2, 5, 1e-5)
+    assert np.abs(np.array(_read_matrix(res / "test_score.gen")) - score_rows).max() <= 1.01e-4
+    assert open(res / "test_results.csv").read() == csv
 
 
 _RANK_WORKER = r'''
@@ -283,6 +299,20 @@ def test_simpledyg_greedy_eval_matches_oracle_decode(dev, tmp_path, monkeypatch)
     assert (out_dir / "test_results_epoch.csv").exists() and (out_dir / "eval_results_0.json").exists()
     hdr = open(out_dir / "test_results_epoch.csv").readline()
     assert hdr.startswith("dataset,method,time,nlayer,nhead,nemb,bz,lr,seed,NDCG@5,jaccard@5")
+    # one process per GPU (two ranks, gloo on this one-GPU box): every other batch of 4 per rank, same predictions
+    single = json.load(open(out_dir / "eval_results_0.json"))
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, R4D_DIST_BACKEND="gloo", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                   RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "main_SimpleDyG.py")] + argv +
+                                      ["--per_gpu_eval_batch_size", "4"], cwd=tmp_path, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    done = [pr.communicate(timeout=600) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [e[-1500:] for _, e in done]
+    double = json.load(open(out_dir / "eval_results_0.json"))
+    assert double.keys() == single.keys()
+    assert sum(double[k].get("predicted") == single[k].get("predicted") for k in single) >= len(single) - 1
 
 
 def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch):

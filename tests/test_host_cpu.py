@@ -280,6 +280,16 @@ for j, (gv, gi) in enumerate(got):
     rv, ri = local_topk(torch.cat(allq), ph, k, 0)
     assert torch.equal(gi, ri) and torch.equal(gv, rv), (rank, j)
 assert pipe.flush() == []
+# pool ENCODE sharded by whole batches (main_retriever.py one process per GPU): ragged batches, more ranks than work
+from rag4dyg_amd.dist import balanced_runs, encode_pool_sharded
+gb = torch.Generator().manual_seed(5)
+batches = [torch.randint(0, 50, (int(b), int(t)), generator=gb) for b, t in [(32, 7), (32, 40), (32, 3), (9, 11)]]
+enc = lambda bs: torch.cat([b.float().mean(1, keepdim=True) * torch.arange(1, 5.0) for b in bs])     # [rows, 4]
+full = enc(batches)
+assert torch.equal(encode_pool_sharded(enc, batches), full)
+assert torch.equal(encode_pool_sharded(enc, batches[:1]), enc(batches[:1]))          # world - 1 ranks have nothing to encode
+runs = balanced_runs([b.numel() for b in batches], world)
+assert runs[0][0] == 0 and runs[-1][1] == len(batches) and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
