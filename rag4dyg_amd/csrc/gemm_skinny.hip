@@ -121,6 +121,12 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
                                                                   const float* __restrict__ ln_w,
                                                                   const float* __restrict__ ln_b, float eps) {
     constexpr int KW = 32 * NG, SL = S8_NW * KW;
+    // x goes through LDS: a fragment load straight from memory touches 32 cache lines for 1 KB, so each wave loads ITS
+    // k-piece of the 32 rows coalesced (PPR lanes x 16 bytes per row), parks it in a private padded region and reads the
+    // fragments back with conflict-free ds_read_b128 (measured: 385 -> 374 us per decode step; the ablation's 2.7 us per
+    // launch for the x loads was mostly their LATENCY in the chain, which staging does not remove)
+    constexpr int LDX = KW + 4, PPR = KW / 4, RPP = 64 / PPR, NPASS = 32 / RPP;
+    __shared__ __attribute__((aligned(16))) float xs_all[S8_NW * 32 * LDX];
     __shared__ float red[S8_NW * 32 * S8_LDR];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     const int row = blockIdx.x * 32 + li;
     // k order as in pool_scan_kernel: lane half h of a row owns the 64-byte halves [32g + 16h, +16) of each 128-byte line
     const float4* __restrict__ wrow = reinterpret_cast<const float4*>(wT + (long long)min(row, N - 1) * K + k0) + 4 * lh;
-    const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + (long long)min(li, M - 1) * K + k0) + 4 * lh;
+    float* xs = xs_all + wid * 32 * LDX;
+    const int pr = lane / PPR, pc = lane % PPR;        // NG = 3: 24 lanes per row, lanes 48..63 idle in the staging
     // EVERY global load of the kernel is issued here, before anything waits: weights (the long HBM latency), x fragments,
     // LayerNorm gain / shift fragments, and the epilogue's bias / residual values -- one round trip instead of four
     float4 b[NG][4], a[NG][4], gw[LN ? NG : 1][4], gb[LN ? NG : 1][4];
@@ -136,11 +143,13 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int u = 0; u < 4; ++u) b[g][u] = (SK_DBG & 2) ? make_float4(1.f, 2.f, 3.f, (float)tid) : wrow[8 * g + u];
+    float4 xv[NPASS];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)                                     // rows >= M repeat row M-1: computed, never stored
-            a[g][u] = (SK_DBG & 4) ? make_float4(1.f, 2.f, 3.f, (float)tid) : xrow[8 * g + u];
+    for (int j = 0; j < NPASS; ++j) {                  // rows >= M repeat row M-1: computed, never stored
+        const int r = min(min(j * RPP + pr, 31), M - 1);
+        xv[j] = (SK_DBG & 4) ? make_float4(1.f, 2.f, 3.f, (float)tid)
+                             : reinterpret_cast<const float4*>(x + (long long)r * K + k0)[pc];
+    }
     if (LN) {
         const float4* __restrict__ gwp = reinterpret_cast<const float4*>(ln_w + k0) + 4 * lh;
         const float4* __restrict__ gbp = reinterpret_cast<const float4*>(ln_b + k0) + 4 * lh;
@@ -155,6 +164,14 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     const float bias_n = (fused && bias) ? bias[nc] : 0.f;
     const float res0 = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)m0 * N + nc] : 0.f;
     const float res1 = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)m1 * N + nc] : 0.f;
+    if (pr < RPP)
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) *reinterpret_cast<float4*>(xs + (j * RPP + pr) * LDX + 4 * pc) = xv[j];
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[g][u] = *reinterpret_cast<const float4*>(xs + li * LDX + 32 * g + 16 * lh + 4 * u);
     if (LN) {
         // K == SL: the eight waves hold the eight k-pieces of the SAME 32 rows (row li per lane) -- row statistics from
         // the fragments themselves: piece sums meet in LDS, mean first, then the centred squares (two-pass like ln4_kernel)
