@@ -198,6 +198,10 @@ def main():
                 print(f"[bench] pipelined collectives unavailable ({type(e).__name__}: {e}); using the synchronous form",
                       file=sys.stderr)
             pipe = None
+        agree = torch.tensor([1 if pipe is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)                   # every rank takes the same form, or none does
+        if int(agree.item()) == 0:
+            pipe = None
 
     def step(i):
         group = [q_batches[(i * G + j) % nqb] for j in range(G)]
