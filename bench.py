@@ -184,7 +184,8 @@ def main():
     # others twice per step.  All K steps are still complete inside the timed region (flush before the closing sync).
     # R4D_BENCH_PIPELINE=0 selects the step-synchronous form; a failing self-test falls back to it as well.
     pipe = None
-    if world > 1 and backend == "nccl" and os.environ.get("R4D_BENCH_PIPELINE", "1") != "0":
+    pipe_env = os.environ.get("R4D_BENCH_PIPELINE", "1")              # "force": also under the gloo rehearsal backend
+    if world > 1 and pipe_env != "0" and (backend == "nccl" or pipe_env == "force"):
         try:
             pipe = PipelinedShardedTopK(index.pool_hat, index.index_offset, k, local_topk, ops.merge_topk)
             probe = ops.normalize_rows(torch.randn(QB * G, shape.n_embd, device=device))

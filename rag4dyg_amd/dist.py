@@ -131,6 +131,17 @@ class PipelinedShardedTopK:
 
     def _start_gather(self, t):
         t = t.contiguous()
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":       # 1-GPU rehearsal: staged through host memory
+            th = t.cpu()
+            oh = torch.empty((self.world * th.shape[0],) + tuple(th.shape[1:]), dtype=th.dtype)
+            work = dist.all_gather_into_tensor(oh, th, group=self.group, async_op=True)
+
+            class _Staged:                                             # wait(), then the result back on the device
+                def wait(_self):
+                    work.wait()
+                    out.copy_(oh)
+            out = torch.empty(oh.shape, dtype=t.dtype, device=t.device)
+            return _Staged(), out, (t, th, oh)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
         return work, out, t

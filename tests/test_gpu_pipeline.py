@@ -435,3 +435,32 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
     assert double.keys() == single.keys() and len(single) == n_q
     assert sum(double[k].get("predicted") == single[k].get("predicted") for k in single) >= len(single) - 1
     assert f"'R': [{r['R'][0]}]" in p.stdout or sum(double[k] == single[k] for k in single) < len(single)
+
+
+def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
+    """bench.py prints ONE JSON line with the contract's fields (roofline and cpu_baseline included) at N = 1, and its N > 1
+    control flow -- pool shard per rank, pipelined collectives drained inside the timed region, MAX over ranks -- runs with
+    two ranks on this one GPU (gloo rehearsal backend; the self-test inside compares pipelined with synchronous results)."""
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    small = ["--steps", "3", "--warmup", "1", "--pool-per-gpu", "2048", "--query-batches", "8"]
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + small, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"]["kind"] == "port"
+    env2 = dict(env, R4D_BENCH_BACKEND="gloo", R4D_BENCH_PIPELINE="force")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29536", os.path.join(REPO, "bench.py"), "--gpus", "2",
+                        "--no-cpu-baseline"] + small, env=env2, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0
+    assert "pipeline" in d2["config"]["collectives"] and "unavailable" not in p.stderr
