@@ -486,6 +486,7 @@ class GreedyDecoder:
                                        self.gen_len.data_ptr(), self.out.data_ptr(), self.params.data_ptr(), t_cap)
         self._graph = None
         self._graph_key = None
+        self.graph_builds = 0
         self.use_graph = os.environ.get("R4D_DECODE_GRAPH", "1") != "0"
 
     def close(self):
@@ -504,7 +505,7 @@ class GreedyDecoder:
         c, w, layers = self.tr._c_structs()
         stream = torch.cuda.current_stream().cuda_stream
         if self.use_graph:
-            key = bytes(w) + bytes(layers)                          # every weight pointer the graph has baked in
+            key = bytes(layers) + bytes((ctypes.c_void_p * 4)(w.wte, w.wpe, w.ln_f_w, w.ln_f_b))   # every weight pointer baked in
             if self._graph is None or key != self._graph_key:
                 self.close()
                 g = ctypes.c_void_p()
@@ -512,6 +513,7 @@ class GreedyDecoder:
                                                             self.cache.data_ptr(), self.B, self.t_cap, self.ws.data_ptr(),
                                                             self.ws.numel(), ctypes.byref(g)), "gpt2_greedy_graph_create")
                 self._graph, self._graph_key = g, key
+                self.graph_builds += 1
             _lib.check(lib.r4d_decode_graph_launch(self._graph, n, stream), "decode_graph_launch")
         else:
             for _ in range(n):

@@ -244,6 +244,7 @@ def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B)
             if trial == 0:                                            # same decoder (and graph), next batch
                 seqs2 = [s_[::-1] for s_ in seqs]
                 assert device_loop(seqs2, max_gen, limit, eos, cap) == host_loop(seqs2, max_gen, min(limit, cap), eos, cap)
+                assert tr.greedy_decoder(len(seqs), cap).graph_builds == (1 if graph == "1" else 0)     # captured ONCE
 
 
 def test_prefill_last_length_groups_equal_padded_prefill(dev):
