@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--shape", default="UCI_13", choices=sorted(synth.SHAPES))
     ap.add_argument("--pool-per-gpu", type=int, default=12500)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--batches-per-step", type=int, default=4,
+    ap.add_argument("--batches-per-step", type=int, default=8,
                     help="reference query batches (32 sequences each, padded independently) handed to the library per step "
                          "as one fused launch sequence")
     ap.add_argument("--query-batches", type=int, default=16, help="distinct synthetic query batches cycled over the steps")

@@ -102,7 +102,7 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "a") as f:
     for c, (n, tot) in sorted(_class_rows().items(), key=lambda kv: -kv[1][1]):
         if not c.startswith(("at::", "__amd")):
             f.write(f"\"{c}\",{n},{tot:.0f},{tot / max(n, 1):.0f}\n")
-traffic["_workload"] = {"shape": "UCI_13", "batches_per_step": 4, "n_gpus": 1,
+traffic["_workload"] = {"shape": "UCI_13", "batches_per_step": 8, "n_gpus": 1,
                         "command": "bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
