@@ -147,18 +147,28 @@ def argsort_desc(scores):
     return perm
 
 
-def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False):
-    """f64 [na,nb] Jaccard matrix of CSR sets (occurrence_matrix, retrieval_data_annotation.py:36-41)."""
+def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False, sort_rows=None):
+    """f64 [na,nb] Jaccard matrix of CSR sets (occurrence_matrix, retrieval_data_annotation.py:36-41).  ``sort_rows``: the
+    kernel visits the A rows longest set first (``r4d_jaccard_ordered_f64``) -- same values, fewer padded token steps.
+    Default: only when the sets average more than 4 tokens (measured on 20k x 20k: input sets of 14 tokens 206 -> 256 G
+    pairs/s; output sets of 1.8 tokens are bound by the division and the store, and the extra order lookup costs 15 %)."""
     na, nb = a_ptr.numel() - 1, b_ptr.numel() - 1
     out = torch.empty(na, nb, dtype=torch.float64, device=a_ptr.device)
     if a_idx.numel() == 0:                     # contract: idx buffers hold at least one element
         a_idx = torch.zeros(1, dtype=torch.int32, device=a_ptr.device)
     if b_idx.numel() == 0:
         b_idx = torch.zeros(1, dtype=torch.int32, device=b_ptr.device)
-    check(_lib.load().r4d_jaccard_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na,
-                                      a_idx.numel(), _dev(b_ptr, torch.int32, "b_ptr"),
-                                      _dev(b_idx, torch.int32, "b_idx"), nb, b_idx.numel(),
-                                      int(vocab), int(bool(zero_diag)), out.data_ptr(), _stream()), "jaccard")
+    order = None
+    if sort_rows is None:
+        sort_rows = a_idx.numel() > 4 * na and na * nb >= 50_000_000      # small problems: the argsort costs what it saves
+    if sort_rows and na > 1:
+        order = torch.argsort(a_ptr[1:] - a_ptr[:-1], descending=True, stable=True).to(torch.int32)
+    check(_lib.load().r4d_jaccard_ordered_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na,
+                                              a_idx.numel(), _dev(b_ptr, torch.int32, "b_ptr"),
+                                              _dev(b_idx, torch.int32, "b_idx"), nb, b_idx.numel(),
+                                              int(vocab), int(bool(zero_diag)),
+                                              order.data_ptr() if order is not None else None, out.data_ptr(), _stream()),
+          "jaccard")
     return out
 
 

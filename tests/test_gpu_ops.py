@@ -465,6 +465,11 @@ def test_jaccard_edge_cases_and_merge_fallback(dev):
         _, _, refd = jaccard_ref.jaccard_csr(ap, ai, ap, ai, zero_diag=True)
         outd = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(ap, dev), cu(ai, dev), vocab, zero_diag=True).cpu().numpy()
         assert np.array_equal(outd, refd)
+        # the row VISITING order (longest set first by default) changes the schedule, never a value
+        for zd in (False, True):
+            for sr in (False, True):
+                got = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(ap, dev), cu(ai, dev), vocab, zero_diag=zd, sort_rows=sr)
+                assert np.array_equal(got.cpu().numpy(), refd if zd else jaccard_ref.jaccard_csr(ap, ai, ap, ai)[2])
 
 
 def test_jaccard_every_small_quotient_is_correctly_rounded(dev):
