@@ -13,8 +13,8 @@
 // bandwidth-bound (7 MB in 15 us), but a LATENCY CHAIN: stage x, barrier, one round trip for the weights, then 128
 // dependent 32x32x2 MFMAs (64 cycles each = 3.4 us) in a single accumulator.  gemm_skinny8_kernel shortens the chain and
 // drops launches: EIGHT wavefronts share a 32-row tile of wT and split its k range (slices of 512 or 768: 16 or 24 MFMAs
-// per wave), x fragments come straight from L2 with the same 16-byte pattern as the weights (no staging, no barrier
-// before the MFMAs), the eight partial tiles meet in LDS, and when one slice covers K the bias / gelu_new / residual
+// per wave), every global load of the kernel is issued before anything waits (x pieces coalesced and re-read as
+// fragments from a per-wave LDS region), the eight partial tiles meet in LDS, and when one slice covers K the bias / gelu_new / residual
 // epilogue and -- for the two projections that read a LayerNorm -- the LayerNorm itself (row statistics recomputed
 // per workgroup from the L2-resident x, applied to the fragments) run in the same launch.  K = 4d (mlp c_proj) still
 // splits over gridDim.y and keeps the epilogue kernel.
