@@ -29,10 +29,14 @@ extern "C" {
 #define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
 #define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
 
-#define R4D_ABI_VERSION 1
+#define R4D_ABI_VERSION 2
 
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
+/* 0 for a product build.  Non-zero when the library was compiled with one of the kernel-ablation macros of
+ * tools/kc_ablate.sh (bit 0 KC_DBG, bit 1 ATT_DBG, bit 2 SK_DBG, bit 3 JAC_DBG, bit 4 SCAN_DBG): such a build
+ * computes WRONG results by construction and the Python binding refuses to load it outside tools/. */
+int r4d_build_flags(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* r4d_last_error(void);
 
@@ -67,11 +71,16 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
-    const float* wte;                /* device [vocab,d]  transformer.wte.weight (== lm_head.weight) */
+    const float* wte;                /* device [vocab,d]  transformer.wte.weight */
     const float* wpe;                /* device [n_positions,d] */
     const float* ln_f_w;             /* device [d] */
     const float* ln_f_b;
     const r4d_gpt2_layer* layers;    /* HOST array [n_layer] of device-pointer structs */
+    const float* lm_head;            /* device [vocab,d] lm_head.weight, or NULL when it is tied to wte
+                                      * (modeling_utils.py:155-181).  The reference UNTIES the two whenever it replaces
+                                      * transformer.wte or model.transformer without re-tying (hepth node-feature injection,
+                                      * utils/tokenizer.py:56-66; load_and_freeze_params, utils/model.py:71-78), so trained
+                                      * generator checkpoints carry two different tensors.  Read by the greedy step only. */
 } r4d_gpt2_weights;
 
 /* Scratch bytes r4d_gpt2_encode_f32 needs for a [B,T] batch. */
@@ -231,18 +240,26 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
                        int32_t k, int64_t index_offset, float* out_val_d, int64_t* out_idx_d,
                        float* out_scores_d, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Per-row top-k of an f32 matrix with the same canonical order (e.g. the ground-truth top-3 of the float32
- * Jaccard rows, train_retriever.py:461-462).  Workspace: r4d_score_topk_workspace_bytes(rows, n, k). */
+ * Jaccard rows, train_retriever.py:461-462).  rows <= 65535.  One launch for n <= 16384 * 1024 / k. */
+size_t r4d_topk_f32_workspace_bytes(int32_t rows, int32_t n, int32_t k);
 int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* out_val_d, int64_t* out_idx_d,
                  void* workspace_d, size_t workspace_bytes, void* stream);
 /* Merge G per-shard candidate lists (after the RCCL all-gather): vals_d [G,Q,k], idx_d [G,Q,k]
- * -> out [Q,k], same canonical order; result == single-GPU top-k by construction. */
+ * -> out [Q,k], same canonical order; result == single-GPU top-k by construction.  Shards in ascending order of
+ * their index ranges (rank order), every list sorted by (value desc, index asc) as r4d_score_topk_f32 emits them. */
 size_t r4d_merge_topk_workspace_bytes(int32_t G, int32_t Q, int32_t k);
 int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k,
                        float* out_val_d, int64_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream);
-/* Full-row ranking (file-compat mode): perm_d int32 [rows,n] = stable argsort of -scores (ties by
- * ascending index) == np.argsort(-S, axis=1, kind='stable').  n <= 65536. */
-int r4d_argsort_desc_f32(const float* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream);
-int r4d_argsort_desc_f64(const double* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream);
+/* Full-row ranking (file-compat mode: the reference writes the whole permutation of the pool per query,
+ * train_retriever.py:357-362; retrieval_data_annotation.py:88-93): perm_d int32 [rows,n] = stable argsort of -scores
+ * (ties by ascending index) == np.argsort(-S, axis=1, kind='stable'); NaN last, -0.0 == +0.0.  Any n < 2^31 / 16:
+ * chunks of 2048 (key, index) pairs are sorted in LDS, an element's rank is the sum of its binary-search ranks in the
+ * sorted chunks of its row (O(n * n/2048 * 11) instead of O(n^2) compares).  elem_bytes = 4 (f32) or 8 (f64). */
+size_t r4d_argsort_workspace_bytes(int32_t rows, int32_t n, int32_t elem_bytes);
+int r4d_argsort_desc_f32(const float* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* workspace_d,
+                         size_t workspace_bytes, void* stream);
+int r4d_argsort_desc_f64(const double* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* workspace_d,
+                         size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Jaccard pool annotation.  Replaces occurrence_matrix / co_occurrence_ratio,

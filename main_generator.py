@@ -69,8 +69,7 @@ def main(argv=None):
         for checkpoint in checkpoints:
             global_step = checkpoint.split("-")[-1] if len(checkpoints) > 1 else ""
             state_dict = torch.load(os.path.join(checkpoint, WEIGHTS_NAME), map_location="cpu", weights_only=True)
-            model.load_state_dict(state_dict)                                         # :118-119 (strict, like upstream)
-            model.tie_weights()
+            model.load_state_dict(state_dict)          # :118-119 (strict, like upstream); an untied checkpoint stays untied
             model.to(args.device)
             results[checkpoint] = get_eval_metrics_generator(args, 0, model, tokenizer, global_step, mode="test",
                                                              is_rag=True)

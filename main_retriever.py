@@ -91,8 +91,7 @@ def main(argv=None):
         print("Evaluate the following checkpoints: {}".format(checkpoints))
         for checkpoint in checkpoints:
             state_dict = torch.load(os.path.join(checkpoint, WEIGHTS_NAME), map_location="cpu", weights_only=True)
-            model.load_state_dict(state_dict)          # strict, like main_retriever.py:152-153
-            model.tie_weights()
+            model.load_state_dict(state_dict)          # strict, like main_retriever.py:152-153; no re-tie (as upstream)
             model.to(args.device)
             test_metrics = test(0, args, model, tokenizer, evaluate=False, prefix="best")
             print('test_metrics: ', test_metrics)

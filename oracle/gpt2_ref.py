@@ -98,8 +98,9 @@ def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logit
     """``GPT2Model.forward`` + ``GPT2LMHeadModel.forward`` --
     ``models/modeling_gpt2.py:400-509,583-603`` (== ``models/modeling_rag.py:455-564,664-687``).
 
-    position ids are always 0..T-1 (:420-423); no token types; lm_head is the
-    tied ``wte`` (``modeling_utils.py:165-181``).  Returns a dict with
+    position ids are always 0..T-1 (:420-423); no token types; logits = ``lm_head(hidden)``
+    (``modeling_gpt2.py:585``): ``lm_head.weight`` is the tied ``wte`` (``modeling_utils.py:165-181``) unless the
+    state dict carries its own (the reference unties it: ``utils/tokenizer.py:56-66``, ``utils/model.py:71-78``).  Returns a dict with
     ``hidden`` = ln_f output [B,T,d], optional ``logits`` [B,T,V] and the
     per-layer residual stream ``layers`` (embedding output first).
     """
@@ -116,7 +117,7 @@ def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logit
     h = layer_norm(x, sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"], eps)
     out = {"hidden": h}
     if want_logits:
-        out["logits"] = torch.matmul(h, wte.t())
+        out["logits"] = torch.matmul(h, sd.get("lm_head.weight", wte).t())
     if want_layers:
         out["layers"] = layers
     return out

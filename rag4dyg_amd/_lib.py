@@ -7,9 +7,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: A/B tuning only
+LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: tools/ A/B tuning only
 
-R4D_ABI_VERSION = 1
+R4D_ABI_VERSION = 2
 
 
 class R4DError(RuntimeError):
@@ -34,13 +34,14 @@ class GreedyStateC(Structure):
 
 class GPT2WeightsC(Structure):
     _fields_ = [("wte", c_void_p), ("wpe", c_void_p), ("ln_f_w", c_void_p), ("ln_f_b", c_void_p),
-                ("layers", POINTER(GPT2LayerC))]
+                ("layers", POINTER(GPT2LayerC)), ("lm_head", c_void_p)]
 
 
 _P = c_void_p
 # name -> (restype, argtypes); one entry per symbol declared in include/r4d.h
 PROTOTYPES = {
     "r4d_abi_version": (c_int32, []),
+    "r4d_build_flags": (c_int32, []),
     "r4d_last_error": (c_char_p, []),
     "r4d_gpt2_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, c_int32]),
     "r4d_gpt2_encode_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), _P, _P, c_int32, c_int32,
@@ -70,11 +71,13 @@ PROTOTYPES = {
     "r4d_score_topk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_score_topk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P,
                                      c_size_t, _P]),
+    "r4d_topk_f32_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_topk_f32": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_merge_topk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_merge_topk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
-    "r4d_argsort_desc_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),
-    "r4d_argsort_desc_f64": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "r4d_argsort_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "r4d_argsort_desc_f32": (c_int32, [_P, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "r4d_argsort_desc_f64": (c_int32, [_P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_jaccard_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_jaccard_ordered_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -105,6 +108,10 @@ def load():
     got = lib.r4d_abi_version()
     if got != R4D_ABI_VERSION:
         raise R4DError(f"ABI mismatch: library {got}, binding {R4D_ABI_VERSION}")
+    flags = lib.r4d_build_flags()
+    if flags and os.environ.get("R4D_ALLOW_ABLATED_LIB") != "1":      # tools/kc_ablate.sh builds: wrong results by construction
+        raise R4DError(f"{LIB_PATH} is a kernel-ablation build (r4d_build_flags() = {flags:#x}): timing aid for tools/ only; "
+                       "the product refuses it (set R4D_ALLOW_ABLATED_LIB=1 in a tuning script)")
     _LIB = lib
     return lib
 

@@ -591,3 +591,5 @@ int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* 
 }
 
 }  // namespace r4d
+
+namespace r4d { int dbgflag_att() { return ATT_DBG != 0; } }

@@ -9,6 +9,8 @@
 namespace r4d {
 
 void set_error(const char* fmt, ...);
+// 1 when the translation unit was built with its kernel-ablation macro set (tools/kc_ablate.sh): r4d_build_flags()
+int dbgflag_kc(); int dbgflag_att(); int dbgflag_sk(); int dbgflag_jac(); int dbgflag_scan();
 
 #define R4D_REQUIRE(cond, ...)                     \
     do {                                           \
@@ -82,6 +84,14 @@ bool gemm_skinny_fuses_ln(int M, int K, int N);       // y = epilogue(LayerNorm(
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
                        const float* ln_b = nullptr, float ln_eps = 0.f);
+
+// ------------------------------------------------------------------ topk.hip
+// rows x n values -> rows x k best (value, global index), canonical order; `counters_zeroed`: the caller already cleared
+// the ticket counters (first rows * 4 bytes of ws) on this stream
+template <typename T> size_t topk_ws_bytes(int rows, int n, int k);
+template <typename T>
+int topk_rows(const T* vals, const long long* idx_in, int rows, int n, long long ld, int k, long long index_offset, T* out_v,
+              long long* out_i, void* ws, size_t ws_bytes, bool counters_zeroed, hipStream_t s);
 
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,

@@ -124,6 +124,9 @@ using namespace r4d;
 extern "C" {
 
 int r4d_abi_version(void) { return R4D_ABI_VERSION; }
+int r4d_build_flags(void) {
+    return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4);
+}
 int r4d_set_attention_fused(int32_t mode) {
     // mode 2: fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning); 1: fused (column-split there)
     g_attention_variant = (mode == 2) ? 1 : 0;
@@ -180,7 +183,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         if (f > sc) sc = f;
         pl += lnf_meanpool_scratch_floats(G.B, G.T, d);
     }
-    R4D_REQUIRE(Mtot <= 0x7fffffff / (size_t)(4 * d), "gpt2: %zu rows in one call is too many", Mtot);
+    R4D_REQUIRE(Mtot <= 0x7fffffff / (size_t)(16 * d), "gpt2: %zu rows in one call is too many", Mtot);   // [M,4d] f32 byte offsets fit 31 bits
     const int M = (int)Mtot;
     Workspace ws = carve(workspace_d, Mtot, sc, pl, d);
     if (!workspace_d || workspace_bytes < ws.bytes) {
@@ -391,10 +394,11 @@ int r4d_gpt2_greedy_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         set_error("gpt2 greedy: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
         return R4D_ERR_WORKSPACE;
     }
+    const float* head = w->lm_head ? w->lm_head : w->wte;            // untied checkpoints carry their own lm_head.weight
     if (B <= 32 && gemm_skinny_supported(B, d, V))                   // lm_head on B rows: a weight stream like the projections
-        rc = launch_gemm_skinny(st->last_d, w->wte, nullptr, nullptr, B, d, V, EPI_NONE, st->logits_d, ws.pool, s);
+        rc = launch_gemm_skinny(st->last_d, head, nullptr, nullptr, B, d, V, EPI_NONE, st->logits_d, ws.pool, s);
     else
-        rc = r4d_lm_logits_f32(st->last_d, w->wte, B, V, d, st->logits_d, stream);
+        rc = r4d_lm_logits_f32(st->last_d, head, B, V, d, st->logits_d, stream);
     if (rc) return rc;
     GreedyState g;
     g.next = st->next_d; g.lens = st->lens_d; g.pos = st->pos_d; g.active = st->active_d; g.gen_len = st->gen_len_d;

@@ -356,7 +356,8 @@ int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {
         static int use_kc = -1;
         if (use_kc < 0) { const char* e = getenv("R4D_GEMM_KC"); use_kc = e ? atoi(e) : 1; }
         const bool vec4 = ((g.lda | g.ldb | g.sA0 | g.sA1 | g.sB0 | g.sB1) & 3) == 0 && g.K % 32 == 0;   // float4 staging, whole k-tiles
-        const bool fits = (long long)g.M * g.lda < (1ll << 29) && (long long)g.N * g.ldb < (1ll << 29);   // 32-bit byte offsets
+        const bool fits = (long long)g.M * g.lda < (1ll << 29) && (long long)g.N * g.ldb < (1ll << 29) &&   // 32-bit byte offsets
+                          128ll * g.ldc < (1ll << 29) && (!g.resid || 128ll * g.ldr < (1ll << 29));   // per-tile C / residual descriptors
         if (use_kc && g.b_trans && g.causal != CAUSAL_PV && g.a_cols == g.K && g.b_rows == g.N && vec4 && fits)
             return launch_gemm_f32_kc(g, stream);
     }

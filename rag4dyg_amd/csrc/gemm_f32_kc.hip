@@ -501,3 +501,5 @@ int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace r4d
+
+namespace r4d { int dbgflag_kc() { return KC_DBG != 0; } }

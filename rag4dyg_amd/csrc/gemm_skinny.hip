@@ -301,3 +301,5 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
 }
 
 }  // namespace r4d
+
+namespace r4d { int dbgflag_sk() { return SK_DBG != 0; } }

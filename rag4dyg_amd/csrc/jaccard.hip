@@ -274,3 +274,5 @@ extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, i
     return r4d_jaccard_ordered_f64(a_ptr_d, a_idx_d, na, a_nnz, b_ptr_d, b_idx_d, nb, b_nnz, vocab, zero_diag, nullptr, out_d,
                                    stream);
 }
+
+namespace r4d { int dbgflag_jac() { return JAC_DBG != 0; } }

@@ -1,12 +1,18 @@
-// Retrieval scoring on gfx950: row normalisation, query-vs-pool cosine scan (fp32 MFMA), device top-k
-// with the canonical (score desc, index asc) order, multi-shard merge and full-row stable ranking.
+// Retrieval scoring on gfx950: row normalisation and the query-vs-pool cosine scan (exact-f32 MFMA), handing the
+// score rows to the one-launch top-k of topk.hip.
 // Reference: train/train_retriever.py:433-438 (normalise, matmul, (x+1)/2) and :357-358,461-467 (argsort).
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef SCAN_DBG
+#define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs, bit 1 the score stores, bit 2 the cross-wave reduction
+#endif
+
 namespace r4d {
+
+int dbgflag_scan() { return SCAN_DBG != 0; }
 
 // ------------------------------------------------------------------------------------ normalise rows
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int n, int d,
@@ -25,339 +31,175 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------ pool scan (Q <= 64)
 // S[q, n] = (q_hat[q] . pool_hat[n] + 1) / 2 for one block of <= 32 queries against the whole pool shard:
-// train_retriever.py:437-438 at the reference's query batch (32).  At Q_b = 32 the scan is HBM-READ bound
-// (16 flop per pool byte), so the kernel is built around streaming pool_hat exactly once:
-//   * the 32 normalised queries sit in LDS k-major (Qs[k][q], d*132 B) for the whole kernel; an MFMA A operand
-//     is one conflict-free ds_read_b32 (row stride 33 floats; 12 % of the LDS read rate at full MFMA issue);
-//   * every wavefront owns whole 32-row pool tiles and the full d, so there is no cross-wave reduction and no
-//     barrier in the loop; lane (j, h) streams row j of its tile with 16-byte global loads, the lane pair of a row
-//     consuming each 128-byte line at once (k permuted identically on both operands), 16 KB per wave in flight;
-//   * exact-f32 MFMA 32x32x2 accumulates S[32 q x 32 rows]; the epilogue applies (x+1)/2 and writes 128-byte
-//     row segments of the score matrix, from which topk_seg_kernel selects.
+// train_retriever.py:437-438 at the reference's query batch (32).
+//
+// At 32 queries the scan sits ON the fp32 ridge of the chip: 16 flop per pool byte is 21 us of exact-f32 MFMA issue at
+// peak for a 100k x 512 pool against 25.6 us of HBM at peak, so the kernel has to keep BOTH pipes busy, which comes
+// down to balance and to what shares the issue port with the MFMAs:
+//   * one workgroup = KW wavefronts that SPLIT THE CONTRACTION of one 32-row pool tile (wave w owns the 128-byte lines
+//     w, w + KW, ... of every row): a tile is d / (2 KW) MFMAs per SIMD instead of d / 2 on one, so the 391 tiles of a
+//     12.5k-row shard become 1,564 wave-tiles and 3,125 tiles spread over 256 CUs to within one tile (the previous
+//     tile-per-wave form left SIMDs with 4 tiles next to SIMDs with 2);
+//   * the wave's slice of the 32 normalised queries lives in REGISTERS for the whole kernel (NG x 16 VGPRs): no LDS read
+//     in front of the MFMAs at all -- the loop body is 16 MFMAs + 4 global loads per 128-byte line group;
+//   * lane (j, h) streams row j of the tile with 16-byte loads, the lane pair of a row consuming each 128-byte line at
+//     once; a group's registers are refilled with the NEXT tile's data right after its MFMAs (program order, no copies);
+//   * the KW partial 32 x 32 tiles meet in LDS (double-buffered, ONE barrier per tile), wave w finishing 16 / KW of the
+//     accumulator registers in a fixed order (deterministic sums); the epilogue applies (x+1)/2 and writes 128-byte row
+//     segments of the score matrix, which topk_chunk_kernel then reduces from the Infinity Cache in one launch.
+// Measured (MI355X, 100k x 512, 32 queries; tools/bench_components.py, SCAN_DBG builds): 45-46 us = 4.7 TB/s = 0.59-0.61 of
+// the 8 TB/s spec; the same kernel WITHOUT its MFMAs streams the pool in 34.5 us (6.3 TB/s, the measured HBM ceiling of
+// this part), the MFMAs alone are 21 us: the two pipes overlap to ~80 %.  PMC: FETCH_SIZE == the algorithmic bytes (no
+// re-reads), MFMA pipe 46 % busy.  Tried without gain: two tiles in flight per wave (0.58), 16-byte pieces 64 bytes apart
+// per load instead of whole 32-byte sectors (0.56-0.59), 4-way split with three workgroups per CU (0.56; 0.60 with two).
+// Fusing the selection into this epilogue was priced and NOT done: a score costs 16 SIMD-cycles of MFMA here, an exact
+// per-workgroup top-k costs ~2.3 more on the same issue port (+14 %), which buys nothing over the separate launch while
+// the raw rows (6 % of the pool bytes) stay cache-resident.
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
-
-// Q tile layout in LDS: ROW-major [32 queries][d + 4] (k contiguous).  A lane's MFMA A operands for four consecutive
-// MFMAs are then ONE ds_read_b128 (16-lane groups hit 16 distinct 16-byte slots: stride 4 banks), matching the four k
-// of its 16-byte pool load; the k-major layout needed a ds_read2_b32 + lgkmcnt(0) wait in front of every MFMA pair.
-template <int NW>                                    // wavefronts per workgroup (they share the Q tile)
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void pool_scan_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
-                                                        int Q, int N, int d, float* __restrict__ scores) {
-    extern __shared__ float Qs[];                       // [32][d + 4]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <int KW, int NG>                               // d == 32 * KW * NG
+__global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_scan_ks_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
+                                                              int Q, int N, float* __restrict__ scores,
+                                                              unsigned* __restrict__ zero_d, int nzero) {
+    constexpr int D = 32 * KW * NG;
+    constexpr int R = 16 / KW;                          // accumulator registers a wave finishes
+    __shared__ float red[KW > 1 ? 2 * KW * KW * 64 * R : 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.y * 32;
-    const int ldq = d + 4;
-    for (int q = wid; q < 32; q += NW) {                // one query row per wave and trip, 16-byte pieces
-        const bool ok = q0 + q < Q;
-        const float4* src = reinterpret_cast<const float4*>(qhat + (long long)min(q0 + q, Q - 1) * d);
-        for (int k4 = lane; k4 < d / 4; k4 += 64) {
-            float4 v = src[k4];
-            if (!ok) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
-            *reinterpret_cast<float4*>(Qs + q * ldq + 4 * k4) = v;
-        }
-    }
-    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0)             // ticket counters of the top-k launch that follows on this stream
+        for (int i = tid; i < nzero; i += 64 * KW) zero_d[i] = 0u;
     const int ntiles = (N + 31) / 32;
-    // k order: lane half h of row j owns the 64-byte halves [32g + 16h, 32g + 16h + 16) of the row, i.e. the lane
-    // pair (j,0),(j,1) consumes each 128-byte line of the row at once (four 16-byte loads per lane per line);
-    // component c of load u of group g is k = 32g + 16h + 4u + c on BOTH operands.  d % 32 == 0 here
-    // (r4d_score_topk_f32 falls back to the GEMM otherwise).
-    const int ngroups = d / 32;
-    const float* qfrag = Qs + li * ldq + 16 * lh;       // + 32g + 4u
-    for (int t = blockIdx.x * NW + wid; t < ntiles; t += gridDim.x * NW) {
-        const int row = t * 32 + li;
-        const float4* __restrict__ prow =
-            reinterpret_cast<const float4*>(pool + (long long)min(row, N - 1) * d) + 4 * lh;   // clamped: always valid
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    // k order: load u of lane half h of row j is the 16-byte piece 2u + h of the wave's 128-byte line g, so ONE load
+    // instruction touches a whole 32-byte sector of each of its 32 rows; component c of that load is
+    // k = 32 (g KW + w) + 8 u + 4 h + c on BOTH operands.
+    float4 qf[NG][4];
+    {
+        const bool ok = q0 + li < Q;
+        const float4* src = reinterpret_cast<const float4*>(qhat + (long long)min(q0 + li, Q - 1) * D) + lh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 v = src[8 * (g * KW + w) + 2 * u];
+                if (!ok) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+                qf[g][u] = v;
+            }
+    }
+    auto tile_ptr = [&](int tt) {
+        return reinterpret_cast<const float4*>(pool + (long long)min(tt * 32 + li, N - 1) * D) + lh + 8 * w;   // clamped: always valid
+    };
+    int buf = 0;
+    // one tile: MFMAs over the staged rows `bb`, each group's registers refilled with tile `trefill` (< 0: none) right after
+    // its MFMAs (program order, no copies), cross-wave reduction, (x+1)/2, store
+    auto do_tile = [&](float4 (&bb)[NG][4], int tcur, int trefill) {
+        const float4* __restrict__ pn = tile_ptr(trefill >= 0 ? trefill : tcur);
         f32x16s acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // NB groups (NB x 64 B per lane) in flight; the slot of group g is refilled with group g + NB right after its
-        // MFMAs (program order: no register copies).  NB = 3 and no Q look-ahead keep the kernel under 128 registers:
-        // four waves per SIMD (two 8-wave workgroups per CU) hide more latency than a deeper per-wave queue.
-        constexpr int NB = NW == 8 ? 3 : 4;
-        float4 b[NB][4];
 #pragma unroll
-        for (int s_ = 0; s_ < NB; ++s_)
+        for (int g = 0; g < NG; ++g) {
+            if (!(SCAN_DBG & 1)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) b[s_][u] = prow[8 * min(s_, ngroups - 1) + u];
-        for (int g0 = 0; g0 < ngroups; g0 += NB) {
-#pragma unroll
-            for (int s_ = 0; s_ < NB; ++s_) {
-                const int g = g0 + s_;
-                if (g < ngroups) {                      // wave-uniform
-                    float4 qa[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4*>(qfrag + 32 * g + 4 * u);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].x, b[s_][u].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].y, b[s_][u].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].z, b[s_][u].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u].w, b[s_][u].w, acc, 0, 0, 0);
-                    }
-                    const int gl = min(g + NB, ngroups - 1);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) b[s_][u] = prow[8 * gl + u];
+                for (int u = 0; u < 4; ++u) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].x, bb[g][u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].y, bb[g][u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].z, bb[g][u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].w, bb[g][u].w, acc, 0, 0, 0);
                 }
-            }
-        }
-        if (row < N) {
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (q < Q) scores[(long long)q * N + row] = (acc[r] + 1.0f) / 2.0f;
+                for (int u = 0; u < 4; ++u) acc[u] += bb[g][u].x + bb[g][u].y + bb[g][u].z + bb[g][u].w;
+            }
+            if (trefill >= 0) {                                          // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bb[g][u] = pn[8 * KW * g + 2 * u];
             }
         }
-    }
+        float fin[R];
+        if (KW > 1 && !(SCAN_DBG & 4)) {
+            // red[buf][src wave][dst wave][lane][R]: lane-contiguous vectors, conflict-free on both sides
+            float* base = red + buf * (KW * KW * 64 * R);
+#pragma unroll
+            for (int wd = 0; wd < KW; ++wd)
+#pragma unroll
+                for (int i = 0; i < R; ++i) base[((w * KW + wd) * 64 + lane) * R + i] = acc[wd * R + i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < R; ++i) fin[i] = 0.f;
+#pragma unroll
+            for (int p = 0; p < KW; ++p)                                 // fixed order: deterministic sums
+#pragma unroll
+                for (int i = 0; i < R; ++i) fin[i] += base[((p * KW + w) * 64 + lane) * R + i];
+            buf ^= 1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) fin[i] = acc[w * R + i];
+        }
+        const int row = tcur * 32 + li;
+        if (row < N && !(SCAN_DBG & 2)) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = w * R + i;
+                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (q < Q) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+            }
+        }
+    };
+    auto load_tile = [&](float4 (&bb)[NG][4], int tt) {
+        const float4* __restrict__ p = tile_ptr(tt);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bb[g][u] = p[8 * KW * g + 2 * u];
+    };
+    const int G = (int)gridDim.x;
+    float4 b0[NG][4];
+    load_tile(b0, t);
+    for (; t < ntiles; t += G) do_tile(b0, t, t + G < ntiles ? t + G : -1);
 }
 
-static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, int d, float* scores, hipStream_t s) {
-    const size_t lds = (size_t)32 * (d + 4) * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute((const void*)pool_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    140 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)pool_scan_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    140 * 1024) != hipSuccess) {
-                set_error("pool_scan: cannot raise dynamic LDS limit");
-                return R4D_ERR_HIP;
-            }
-            raised = true;
-        }
+template <int KW, int NG>
+static int launch_scan_variant(const float* qhat, const float* pool, int Q, int N, float* scores, unsigned* zero_d, int nzero,
+                               hipStream_t s) {
+    static int wgs_per_cu = 0;
+    if (wgs_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ks_kernel<KW, NG>, 64 * KW, 0) != hipSuccess || nb < 1) nb = 1;
+        wgs_per_cu = nb;
     }
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("R4D_SCAN_WGS_PER_CU"); force = e ? atoi(e) : 0; }     // tuning aid
+    const int per_cu = force > 0 ? force : wgs_per_cu;
     const int ntiles = cdiv(N, 32);
-    const int blocks_per_cu = lds > 80 * 1024 ? 1 : 2;
-    // algorithmic bytes (SURVEY 8d B_score): pool read once + queries + score rows out
-    ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
-    static int nw = -1;
-    if (nw < 0) { const char* e = getenv("R4D_SCAN_WAVES"); nw = e ? atoi(e) : 8; }   // tuning aid: 4 or 8
-    if (nw == 8 && ntiles >= 8 * 256) {
-        const int gx = max(1, min(cdiv(ntiles, 8), 256 * blocks_per_cu));
-        hipLaunchKernelGGL(pool_scan_kernel<8>, dim3(gx, cdiv(Q, 32)), dim3(512), lds, s, qhat, pool, Q, N, d, scores);
-    } else {
-        const int gx = max(1, min(cdiv(ntiles, 4), 256 * blocks_per_cu));
-        hipLaunchKernelGGL(pool_scan_kernel<4>, dim3(gx, cdiv(Q, 32)), dim3(256), lds, s, qhat, pool, Q, N, d, scores);
-    }
+    const int gx = max(1, min(ntiles, 256 * per_cu));
+    hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat, pool, Q, N, scores,
+                       zero_d, nzero);
     R4D_CHECK_LAUNCH("pool_scan");
     return R4D_OK;
 }
 
-// ------------------------------------------------------------------------------------ top-k machinery
-// Candidate order == np.argsort(-x, kind='stable'): larger score first, ties by smaller index.  NaN
-// sorts last (as in numpy).
-template <typename T>
-struct Cand {
-    T v;
-    long long i;
-};
-template <typename T>
-__device__ __forceinline__ bool better(const Cand<T>& a, const Cand<T>& b) {
-    return (a.v > b.v) || (a.v == b.v && a.i < b.i);
-}
-template <typename T>
-__device__ __forceinline__ Cand<T> shfl_xor_cand(const Cand<T>& c, int o) {
-    Cand<T> r;
-    r.v = __shfl_xor(c.v, o, 64);
-    r.i = __shfl_xor(c.i, o, 64);
-    return r;
-}
-template <typename T>
-__device__ __forceinline__ T neg_inf() { return (T)(-INFINITY); }
-
-constexpr int TOPK_E = 16;                 // candidates per lane
-constexpr int TOPK_SEG = 64 * TOPK_E;      // candidates per WAVEFRONT segment
-
-// Candidate inside a segment: value + POSITION in the row / candidate list.  Positions order ties exactly like
-// global indices do (level 1: position == column; deeper levels: candidate lists are laid out by (segment, rank) and
-// every segment is already sorted by (value desc, index asc)), so the reduction carries 32-bit positions and the
-// 64-bit global index is looked up only for the k winners.
-template <typename T>
-struct WCand {
-    T v;
-    unsigned int p;
-};
-template <typename T>
-__device__ __forceinline__ bool wbetter(const WCand<T>& a, const WCand<T>& b) {
-    return (a.v > b.v) | ((a.v == b.v) & (a.p < b.p));          // branch-free: || / && compile to exec-mask branches
-}
-
-// One wavefront reduces one segment of 1024 candidates of one row to its k best: k rounds of a 6-step shuffle
-// arg-best over (value, position) pairs with removal -- no LDS, no barrier.  Every lane keeps its current local best;
-// only the round's winner rescans its 16 registers.
-//   vals [rows, ld]; idx_in (nullable) parallel global indices, else index = column + index_offset.
-//   out_v / out_i [rows, nseg*k]
-template <typename T>
-__global__ __launch_bounds__(256) void topk_seg_kernel(const T* __restrict__ vals, const long long* __restrict__ idx_in,
-                                                       int n, long long ld, int k, long long index_offset, int nseg,
-                                                       int rows, T* __restrict__ out_v, long long* __restrict__ out_i) {
-    const int lane = threadIdx.x & 63;
-    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);        // (row, segment) of this wave
-    if (unit >= (long long)rows * nseg) return;
-    const int row = (int)(unit / nseg), seg = (int)(unit % nseg);
-    const T* v = vals + (long long)row * ld;
-    const WCand<T> none = {neg_inf<T>(), 0xffffffffu};
-    WCand<T> c[TOPK_E];
-#pragma unroll
-    for (int e = 0; e < TOPK_E; ++e) {
-        const int col = seg * TOPK_SEG + e * 64 + lane;
-        const T x = v[min(col, n - 1)];                                 // clamped address, value masked below
-        c[e].v = (col < n && x == x) ? x : neg_inf<T>();                // NaN sorts last (as numpy)
-        c[e].p = (col < n) ? (unsigned)col : 0xffffffffu;
+// d -> (KW, NG) with d == 32 * KW * NG; +1 = no instantiation (the tiled GEMM takes the call)
+static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, int d, float* scores, unsigned* zero_d,
+                            int nzero, hipStream_t s) {
+    static int kw8 = -1;
+    if (kw8 < 0) { const char* e = getenv("R4D_SCAN_KW8"); kw8 = e ? atoi(e) : 1; }               // tuning aid: 0 = 4-way split at d 512
+    // algorithmic bytes (SURVEY 8d B_score): pool read once per 32 queries + queries + score rows out
+    ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
+    switch (d) {
+        case 32:   return launch_scan_variant<1, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 64:   return launch_scan_variant<2, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 128:  return launch_scan_variant<4, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 256:  return launch_scan_variant<4, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 384:  return launch_scan_variant<4, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 512:  return kw8 ? launch_scan_variant<8, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s)       // default
+                              : launch_scan_variant<4, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 768:  return launch_scan_variant<8, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 1024: return launch_scan_variant<8, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        default:   return 1;
     }
-    auto local_best = [&](int& slot) {
-        WCand<T> b = none;
-        slot = -1;
-#pragma unroll
-        for (int e = 0; e < TOPK_E; ++e) {
-            const bool bt = wbetter(c[e], b);
-            b.v = bt ? c[e].v : b.v; b.p = bt ? c[e].p : b.p; slot = bt ? e : slot;
-        }
-        return b;
-    };
-    int slot;
-    WCand<T> mine = local_best(slot);
-    T* ov = out_v + ((long long)row * nseg + seg) * k;
-    long long* oi = out_i + ((long long)row * nseg + seg) * k;
-    const long long* ii = idx_in ? idx_in + (long long)row * ld : nullptr;
-    WCand<T> won = none;                                                // lane r keeps the r-th winner (k <= 64)
-    for (int r = 0; r < k; ++r) {
-        WCand<T> w = mine;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            WCand<T> t;
-            t.v = __shfl_xor(w.v, o, 64);
-            t.p = __shfl_xor(w.p, o, 64);
-            const bool bt = wbetter(t, w);
-            w.v = bt ? t.v : w.v; w.p = bt ? t.p : w.p;
-        }
-        if (lane == r) won = w;
-        if (__any(slot >= 0 && mine.p == w.p)) {                        // positions are unique: exactly one owner
-            const bool own = slot >= 0 && mine.p == w.p;
-#pragma unroll
-            for (int e = 0; e < TOPK_E; ++e) {
-                const bool kill = own & (e == slot);
-                c[e].v = kill ? none.v : c[e].v; c[e].p = kill ? none.p : c[e].p;
-            }
-            int s2;
-            const WCand<T> nb = local_best(s2);
-            mine.v = own ? nb.v : mine.v; mine.p = own ? nb.p : mine.p; slot = own ? s2 : slot;
-        }
-    }
-    // the k index look-ups and stores go out in parallel, off the selection loop's critical path
-    if (lane < k) {
-        const bool pad = won.p == 0xffffffffu;
-        const long long gi = ii ? ii[pad ? 0 : won.p] : (long long)won.p + index_offset;
-        ov[lane] = won.v;
-        oi[lane] = pad ? 0x7fffffffffffffffLL : gi;
-    }
-}
-
-template <typename T>
-static size_t topk_ws_bytes(int rows, int n, int k) {
-    size_t total = 0;
-    long long cur = n;
-    while (cur > TOPK_SEG) {
-        const long long nseg = (cur + TOPK_SEG - 1) / TOPK_SEG;
-        total += align_up((size_t)rows * nseg * k * sizeof(T), 256) + align_up((size_t)rows * nseg * k * 8, 256);
-        cur = nseg * k;
-    }
-    return total + 256;
-}
-
-// rows x n values -> rows x k best (value, index).  Multi-level: wavefront segments of 1024 candidates.
-template <typename T>
-static int topk_rows(const T* vals, int rows, int n, long long ld, int k, long long index_offset, T* out_v,
-                     long long* out_i, void* ws, size_t ws_bytes, hipStream_t s) {
-    R4D_REQUIRE(k >= 1 && k <= 64 && k <= n, "topk: k=%d must be in [1, min(64, n=%d)]", k, n);
-    R4D_REQUIRE(rows >= 1, "topk: no rows");
-    if (ws_bytes < topk_ws_bytes<T>(rows, n, k)) {
-        set_error("topk: workspace too small");
-        return R4D_ERR_WORKSPACE;
-    }
-    const T* cv = vals;
-    const long long* ci = nullptr;
-    long long cur = n, cld = ld;
-    char* wp = (char*)ws;
-    while (true) {
-        const int nseg = (int)((cur + TOPK_SEG - 1) / TOPK_SEG);
-        T* ov;
-        long long* oi;
-        if (nseg == 1) { ov = out_v; oi = out_i; }
-        else {
-            ov = (T*)wp; wp += align_up((size_t)rows * nseg * k * sizeof(T), 256);
-            oi = (long long*)wp; wp += align_up((size_t)rows * nseg * k * 8, 256);
-        }
-        const long long units = (long long)rows * nseg;
-        ProfScope prof(PK_TOPK, (double)rows * cur * (sizeof(T) + (ci ? 8 : 0)), s);
-        hipLaunchKernelGGL((topk_seg_kernel<T>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, cv, ci, (int)cur, cld,
-                           k, index_offset, nseg, rows, ov, oi);
-        R4D_CHECK_LAUNCH("topk_seg");
-        if (nseg == 1) break;
-        cv = ov; ci = oi; cur = (long long)nseg * k; cld = cur;
-    }
-    return R4D_OK;
-}
-
-// int64 -> int32 index narrowing for the f64 (Jaccard) API
-__global__ void narrow_idx_kernel(const long long* __restrict__ in, int32_t* __restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int32_t)in[i];
-}
-
-// ------------------------------------------------------------------------------------ shard merge
-// vals/idx [G,Q,k] -> row-major candidate lists [Q, G*k] (shard-major, so positions order ties like global indices),
-// then the same wavefront top-k.
-__global__ __launch_bounds__(256) void gather_candidates_kernel(const float* __restrict__ vals,
-                                                                const long long* __restrict__ idx, int G, int Q, int k,
-                                                                float* __restrict__ ov, long long* __restrict__ oi) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)G * Q * k) return;
-    const int j = (int)(t % k), g = (int)((t / k) % G), q = (int)(t / ((long long)k * G));
-    const long long src = ((long long)g * Q + q) * k + j;
-    ov[t] = vals[src];
-    oi[t] = idx[src];
-}
-
-// ------------------------------------------------------------------------------------ full-row ranking
-// perm = stable argsort of -scores by rank counting: rank(i) = #{j : better(j, i)}.  O(n^2) compares per
-// row, embarrassingly parallel and exactly np.argsort(-x, kind='stable') (file-compat mode only: the
-// reference writes the full permutation of the pool for every query, train_retriever.py:357-362).
-template <typename T>
-__global__ __launch_bounds__(256) void rank_count_kernel(const T* __restrict__ scores, int n, int32_t* __restrict__ perm) {
-    __shared__ T tile[1024];
-    const int row = blockIdx.y;
-    const T* v = scores + (long long)row * n;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    T mine = (i < n) ? v[i] : (T)0;
-    if (mine != mine) mine = neg_inf<T>();
-    int rank = 0;
-    for (int j0 = 0; j0 < n; j0 += 1024) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < 1024; t += 256) {
-            T x = (j0 + t < n) ? v[j0 + t] : neg_inf<T>();
-            tile[t] = (x != x) ? neg_inf<T>() : x;
-        }
-        __syncthreads();
-        const int lim = min(1024, n - j0);
-        for (int t = 0; t < lim; ++t) {
-            const T x = tile[t];
-            rank += (x > mine) || (x == mine && (j0 + t) < i);
-        }
-    }
-    if (i < n) perm[(long long)row * n + rank] = i;
-}
-
-template <typename T>
-static int argsort_desc(const T* scores, int rows, int n, int32_t* perm, hipStream_t s) {
-    R4D_REQUIRE(scores && perm, "argsort: null pointer");
-    R4D_REQUIRE(rows >= 0 && rows <= 65535 && n >= 1 && n <= 65536, "argsort: rows=%d (<= 65535), n=%d (<= 65536) out of range", rows, n);
-    if (rows == 0) return R4D_OK;
-    ProfScope prof(PK_RANK_COUNT, (double)rows * n * (sizeof(T) + 4), s);
-    hipLaunchKernelGGL((rank_count_kernel<T>), dim3(cdiv(n, 256), rows), dim3(256), 0, s, scores, n, perm);
-    R4D_CHECK_LAUNCH("rank_count");
-    return R4D_OK;
 }
 
 }  // namespace r4d
@@ -392,12 +234,16 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
     }
     hipStream_t s = (hipStream_t)stream;
     float* scores = out_scores_d ? out_scores_d : (float*)workspace_d;
-    char* ws = (char*)workspace_d + align_up((size_t)Q * N * sizeof(float), 256);
-    int rc;
-    if (Q <= 64 && d % 32 == 0 && d <= 1024) {
-        rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, s);         // HBM-bound regime: stream the pool once
-    } else {
-        GemmArgs g;                                                             // MFMA-bound regime: tiled GEMM
+    const size_t skip = align_up((size_t)Q * N * sizeof(float), 256);
+    char* ws = (char*)workspace_d + skip;                                        // starts with the top-k ticket counters
+    int rc = 1;
+    bool zeroed = false;
+    if (Q <= 64) {                                                               // HBM-bound regime: stream the pool once
+        rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, (unsigned*)ws, Q, s);
+        zeroed = rc == R4D_OK;
+    }
+    if (rc > 0) {                                                                // MFMA-bound regime / other d: tiled GEMM
+        GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = q_hat_d; g.B = pool_hat_d; g.C = scores;
         g.M = Q; g.N = N; g.K = d; g.lda = d; g.ldb = d; g.ldc = N;
@@ -405,96 +251,8 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
         rc = launch_gemm_f32(g, s);
     }
     if (rc) return rc;
-    return topk_rows<float>(scores, Q, N, N, k, index_offset, out_val_d, (long long*)out_idx_d, ws,
-                            workspace_bytes - align_up((size_t)Q * N * sizeof(float), 256), s);
-}
-
-int r4d_topk_f32(const float* m_d, int32_t rows, int32_t n, int32_t k, float* out_val_d, int64_t* out_idx_d,
-                 void* workspace_d, size_t workspace_bytes, void* stream) {
-    R4D_REQUIRE(m_d && out_val_d && out_idx_d && workspace_d, "topk_f32: null pointer");
-    R4D_REQUIRE(rows >= 1 && n >= 1, "topk_f32: empty input");
-    return topk_rows<float>(m_d, rows, n, n, k, 0, out_val_d, (long long*)out_idx_d, workspace_d, workspace_bytes,
-                            (hipStream_t)stream);
-}
-
-size_t r4d_merge_topk_workspace_bytes(int32_t G, int32_t Q, int32_t k) {
-    if (G <= 0 || Q <= 0 || k <= 0) return 0;
-    return align_up((size_t)G * Q * k * 4, 256) + align_up((size_t)G * Q * k * 8, 256) + topk_ws_bytes<float>(Q, G * k, k);
-}
-
-int r4d_merge_topk_f32(const float* vals_d, const int64_t* idx_d, int32_t G, int32_t Q, int32_t k, float* out_val_d,
-                       int64_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream) {
-    R4D_REQUIRE(vals_d && idx_d && out_val_d && out_idx_d && workspace_d, "merge_topk: null pointer");
-    R4D_REQUIRE(G >= 1 && Q >= 1 && k >= 1 && k <= 64, "merge_topk: G=%d Q=%d k=%d out of range", G, Q, k);
-    if (workspace_bytes < r4d_merge_topk_workspace_bytes(G, Q, k)) {
-        set_error("merge_topk: workspace too small");
-        return R4D_ERR_WORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const long long tot = (long long)G * Q * k;
-    float* cv = (float*)workspace_d;
-    long long* ci = (long long*)((char*)workspace_d + align_up((size_t)tot * 4, 256));
-    char* ws = (char*)ci + align_up((size_t)tot * 8, 256);
-    {
-        ProfScope prof(PK_MERGE_TOPK, 24.0 * tot, s);
-        hipLaunchKernelGGL(gather_candidates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, vals_d,
-                           (const long long*)idx_d, G, Q, k, cv, ci);
-        R4D_CHECK_LAUNCH("gather_candidates");
-    }
-    // level 1 of topk_rows must read the gathered indices: run it by hand with idx_in = ci
-    const float* v = cv;
-    const long long* ii = ci;
-    long long cur = (long long)G * k, cld = cur;
-    while (true) {
-        const int nseg = (int)((cur + TOPK_SEG - 1) / TOPK_SEG);
-        float* ov;
-        long long* oi;
-        if (nseg == 1) { ov = out_val_d; oi = (long long*)out_idx_d; }
-        else {
-            ov = (float*)ws; ws += align_up((size_t)Q * nseg * k * 4, 256);
-            oi = (long long*)ws; ws += align_up((size_t)Q * nseg * k * 8, 256);
-        }
-        const long long units = (long long)Q * nseg;
-        ProfScope prof(PK_TOPK, (double)Q * cur * 12.0, s);
-        hipLaunchKernelGGL((topk_seg_kernel<float>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, v, ii, (int)cur,
-                           cld, k, 0LL, nseg, Q, ov, oi);
-        R4D_CHECK_LAUNCH("topk_seg(merge)");
-        if (nseg == 1) break;
-        v = ov; ii = oi; cur = (long long)nseg * k; cld = cur;
-    }
-    return R4D_OK;
-}
-
-int r4d_argsort_desc_f32(const float* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream) {
-    return argsort_desc<float>(scores_d, rows, n, perm_d, (hipStream_t)stream);
-}
-int r4d_argsort_desc_f64(const double* scores_d, int32_t rows, int32_t n, int32_t* perm_d, void* stream) {
-    return argsort_desc<double>(scores_d, rows, n, perm_d, (hipStream_t)stream);
-}
-
-size_t r4d_topk_f64_workspace_bytes(int32_t rows, int32_t n, int32_t k) {
-    if (rows <= 0 || n <= 0 || k <= 0) return 0;
-    return topk_ws_bytes<double>(rows, n, k) + align_up((size_t)rows * k * 8, 256);
-}
-
-int r4d_topk_f64(const double* m_d, int32_t rows, int32_t n, int32_t k, double* out_val_d, int32_t* out_idx_d,
-                 void* workspace_d, size_t workspace_bytes, void* stream) {
-    R4D_REQUIRE(m_d && out_val_d && out_idx_d && workspace_d, "topk_f64: null pointer");
-    R4D_REQUIRE(rows >= 1 && n >= 1, "topk_f64: empty input");
-    if (workspace_bytes < r4d_topk_f64_workspace_bytes(rows, n, k)) {
-        set_error("topk_f64: workspace too small");
-        return R4D_ERR_WORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    long long* idx64 = (long long*)workspace_d;
-    char* ws = (char*)workspace_d + align_up((size_t)rows * k * 8, 256);
-    int rc = topk_rows<double>(m_d, rows, n, n, k, 0, out_val_d, idx64, ws,
-                               workspace_bytes - align_up((size_t)rows * k * 8, 256), s);
-    if (rc) return rc;
-    const long long tot = (long long)rows * k;
-    hipLaunchKernelGGL(narrow_idx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, idx64, out_idx_d, tot);
-    R4D_CHECK_LAUNCH("narrow_idx");
-    return R4D_OK;
+    return topk_rows<float>(scores, nullptr, Q, N, N, k, index_offset, out_val_d, (long long*)out_idx_d, ws,
+                            workspace_bytes - skip, zeroed, s);
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ def greedy_next_token(model, indexed_tokens, device):
     """argmax of the last position's logits for one sequence (``outputs[0][0, -1, :]``, :127-129)."""
     ids = torch.tensor([indexed_tokens], dtype=torch.int64, device=device)
     hidden = model.transformer.encode(ids, want_hidden=True)["hidden"]
-    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), model.transformer.wte.weight)
+    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), model.lm_head.weight)      # == wte when tied
     return int(torch.argmax(logits[0]).item())
 
 

@@ -219,7 +219,7 @@ def fused_next_token(model, indexed_tokens, sim_rows):
     H = wte[torch.tensor(indexed_tokens, dtype=torch.long, device=wte.device)]
     H_aug = torch.cat([H[:2], sim_rows, H[2:]], dim=0).unsqueeze(0).contiguous()
     hidden = model.transformer.encode(None, H_aug, want_hidden=True)["hidden"]
-    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), wte)
+    logits = ops.lm_logits(hidden[:, -1, :].contiguous(), model.lm_head.weight)     # == wte when tied
     return int(torch.argmax(logits[0]).item())
 
 

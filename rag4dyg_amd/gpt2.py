@@ -142,10 +142,20 @@ class _PreTrained(nn.Module):
             sd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
         elif has_prefix_own and not has_prefix_ckpt:
             sd = {"transformer." + k: v for k, v in sd.items()}
-        sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        # modeling_utils.py:543-566: size mismatches and missing weights are errors, not silent re-initialisation.  Missing
+        # keys are tolerated only where the reference tolerates them: the causal `attn.bias` buffers, `lm_head.weight`
+        # (tied to wte right below) and the fusion modules a generator checkpoint may or may not carry.
+        bad = [f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}"
+               for k, v in sd.items() if k in own and own[k].shape != v.shape]
+        missing = [k for k in own if k not in sd and not k.endswith(".attn.bias") and k != "lm_head.weight"
+                   and not k.startswith(("mlp_fusion.", "gnn_fusion."))]
+        if bad or missing:
+            raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(
+                cls.__name__, "\n\t".join(bad + [f"missing key {k}" for k in missing])))
+        sd = {k: v for k, v in sd.items() if k in own}
         model.load_state_dict(sd, strict=False)
-        if hasattr(model, "tie_weights"):
-            model.tie_weights()
+        if hasattr(model, "tie_weights") and not getattr(model, "_untied_by_checkpoint", False):
+            model.tie_weights()                                   # modeling_utils.py:571
         model.eval()
         return model
 
@@ -213,7 +223,10 @@ class GPT2Model(_PreTrained):
                                         p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias),
                                         self._wt(blk.attn.c_attn.weight), self._wt(blk.attn.c_proj.weight),
                                         self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight))
-        w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers)
+        head = self.__dict__.get("_lm_head_weight")              # set by an LM-head model whose lm_head is NOT tied to wte
+        head = head() if head is not None else None
+        w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers,
+                              p(head) if head is not None and head.data_ptr() != self.wte.weight.data_ptr() else None)
         return c, w, layers
 
     @torch.no_grad()
@@ -505,7 +518,7 @@ class GreedyDecoder:
         c, w, layers = self.tr._c_structs()
         stream = torch.cuda.current_stream().cuda_stream
         if self.use_graph:
-            key = bytes(layers) + bytes((ctypes.c_void_p * 4)(w.wte, w.wpe, w.ln_f_w, w.ln_f_b))   # every weight pointer baked in
+            key = bytes(layers) + bytes((ctypes.c_void_p * 5)(w.wte, w.wpe, w.ln_f_w, w.ln_f_b, w.lm_head))   # every weight pointer baked in
             if self._graph is None or key != self._graph_key:
                 self.close()
                 g = ctypes.c_void_p()
@@ -556,9 +569,38 @@ class _LMHeadBase(_PreTrained):
     def tie_weights(self):
         """``modeling_utils.py:155-181``: lm_head.weight is the wte Parameter."""
         self.lm_head.weight = self.transformer.wte.weight
+        self._untied_by_checkpoint = False
 
     def get_output_embeddings(self):
         return self.lm_head
+
+    def lm_head_is_tied(self):
+        return self.lm_head.weight is self.transformer.wte.weight
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "transformer" and isinstance(value, GPT2Model):
+            # the decode kernels read lm_head through the transformer's weight struct; a weakref-free closure over `self`
+            # keeps following whatever Parameter lm_head.weight currently is (tied, untied, re-tied)
+            value.__dict__["_lm_head_weight"] = lambda: self.lm_head.weight if "lm_head" in self._modules else None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """``nn.Module.load_state_dict`` with the reference's UNTIED checkpoints handled.  The reference unties lm_head from
+        wte whenever it replaces ``transformer.wte`` or ``model.transformer`` without re-tying (hepth node features,
+        ``utils/tokenizer.py:56-66``; ``load_and_freeze_params``, ``utils/model.py:71-78``), trains the two separately and
+        saves both.  Loading such a checkpoint into a TIED model would copy ``transformer.wte.weight`` and then
+        ``lm_head.weight`` into the same Parameter (the input embedding silently becomes the lm_head).  Here the model is
+        untied first, so both tensors load as saved -- the state the reference's own training process evaluates with
+        (``--evaluate_during_training``).  ``R4D_REFERENCE_EVAL_TIE=1`` keeps the tie, reproducing what the reference's
+        eval-only run (``main_generator.py:108-121`` on a freshly built, tied model) computes."""
+        import os as _os
+        a, b = state_dict.get("transformer.wte.weight"), state_dict.get("lm_head.weight")
+        if a is not None and b is not None and self.lm_head_is_tied() and _os.environ.get("R4D_REFERENCE_EVAL_TIE") != "1" \
+                and (a.shape != b.shape or not torch.equal(a, b)):
+            w = self.transformer.wte.weight
+            self.lm_head.weight = nn.Parameter(w.detach().clone())
+            self._untied_by_checkpoint = True
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def resize_token_embeddings(self, new_num_tokens=None):
         emb = self.transformer.resize_token_embeddings(new_num_tokens)
@@ -570,7 +612,7 @@ class _LMHeadBase(_PreTrained):
     def _lm(self, input_ids, labels, inputs_embeds, **unsupported):
         tr = self.transformer(input_ids, inputs_embeds=inputs_embeds, **unsupported)
         hidden = tr[0]
-        lm_logits = ops.lm_logits(hidden, self.transformer.wte.weight)
+        lm_logits = ops.lm_logits(hidden, self.lm_head.weight)                 # == wte unless the checkpoint untied them
         outputs = (lm_logits,) + tr[1:]
         if labels is not None:                     # shifted CE, modeling_gpt2.py:604-615 (metric only; torch op on device)
             shift_logits = lm_logits[..., :-1, :].contiguous()

@@ -114,7 +114,7 @@ def topk_f32(m, k):
     """Canonical per-row top-k of an f32 matrix -> (vals [rows,k], idx int64 [rows,k])."""
     rows, n = m.shape
     lib = _lib.load()
-    ws = workspace(lib.r4d_score_topk_workspace_bytes(rows, n, k), m.device, "score")
+    ws = workspace(lib.r4d_topk_f32_workspace_bytes(rows, n, k), m.device, "topk32")
     vals = torch.empty(rows, k, dtype=torch.float32, device=m.device)
     idx = torch.empty(rows, k, dtype=torch.int64, device=m.device)
     check(lib.r4d_topk_f32(_dev(m, torch.float32, "m"), rows, n, k, vals.data_ptr(), idx.data_ptr(), ws.data_ptr(),
@@ -139,11 +139,15 @@ def argsort_desc(scores):
     rows, n = scores.shape
     perm = torch.empty(rows, n, dtype=torch.int32, device=scores.device)
     lib = _lib.load()
-    if scores.dtype == torch.float64:
-        rc = lib.r4d_argsort_desc_f64(_dev(scores, torch.float64, "scores"), rows, n, perm.data_ptr(), _stream())
-    else:
-        rc = lib.r4d_argsort_desc_f32(_dev(scores, torch.float32, "scores"), rows, n, perm.data_ptr(), _stream())
-    check(rc, "argsort_desc")
+    f64 = scores.dtype == torch.float64
+    fn = lib.r4d_argsort_desc_f64 if f64 else lib.r4d_argsort_desc_f32
+    ptr = _dev(scores, torch.float64 if f64 else torch.float32, "scores")
+    step = 65535                                            # grid.y limit of one launch
+    for r0 in range(0, rows, step):
+        nr = min(step, rows - r0)
+        ws = workspace(lib.r4d_argsort_workspace_bytes(nr, n, 8 if f64 else 4), scores.device, "argsort")
+        check(fn(ptr + r0 * n * scores.element_size(), nr, n, perm.data_ptr() + r0 * n * 4, ws.data_ptr(), ws.numel(),
+                 _stream()), "argsort_desc")
     return perm
 
 

@@ -209,5 +209,6 @@ def get_model_tokenizer(args, MODEL_CLASSES):
         sp_feat = wte.data[tok.vocab_size:]
         weights = torch.cat([torch.as_tensor(feats, dtype=torch.float32, device=wte.device), sp_feat])
         model.transformer.wte = torch.nn.Embedding.from_pretrained(embeddings=weights, freeze=False)
-        model.tie_weights()
+        # NOT re-tied, exactly like the reference (utils/tokenizer.py:65, utils/tokenizer_generator.py:116): lm_head.weight
+        # stays the resized random-init Parameter, trained separately from the injected node features.
     return model, tok, model_class, args

@@ -388,6 +388,96 @@ def test_normalize_and_score_topk_vs_oracle(dev):
         assert np.array_equal(perm, retrieval_ref.rank_full(S))
 
 
+def _rank_inputs(rows, n, seed, dtype):
+    """Score rows full of ties and special values: quantised normals, duplicated columns, +-inf, -0.0, NaN."""
+    rng = np.random.default_rng(seed)
+    x = np.round(rng.standard_normal((rows, n)) * 8) / 8
+    x = x.astype(dtype)
+    if n >= 8:
+        x[:, n // 2] = x[:, 1]
+        x[0, rng.integers(0, n, 3)] = -np.inf
+        x[0, rng.integers(0, n, 2)] = np.inf
+        x[-1, rng.integers(0, n, 3)] = np.nan
+        x[:, rng.integers(0, n, 4)] = -0.0
+        x[:, n - 1] = x.max(axis=1, initial=-np.inf, where=np.isfinite(x))       # a tie with the best at the very end
+    return x
+
+
+@pytest.mark.parametrize("rows,n,k", [(1, 1, 1), (3, 7, 7), (5, 1000, 10), (4, 1025, 64), (2, 3965, 10), (3, 16384, 5),
+                                      (3, 16385, 10), (2, 40001, 3), (32, 100003, 10), (2, 300000, 64), (70, 2049, 1)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_topk_one_launch_every_size_bit_exact(dev, rows, n, k, dtype):
+    """r4d_topk_f32 / r4d_topk_f64: one wavefront (n <= 1024), one workgroup (n <= 16384), several workgroups merged by
+    the last arriver, unaligned row strides, k up to 64 -- always == stable argsort (NaN ranks with -inf, -0.0 == 0.0)."""
+    from rag4dyg_amd import ops
+    from oracle import retrieval_ref
+    x = _rank_inputs(rows, n, 100 + n % 97, dtype)
+    ref_in = np.where(np.isnan(x), -np.inf, x)
+    ev, ei = retrieval_ref.topk_stable(ref_in, k)
+    fn = ops.topk_f32 if dtype == np.float32 else ops.topk_f64
+    for _ in range(2):                                  # twice: the ticket counters must come back clean
+        v, i = fn(cu(x, dev), k)
+        assert np.array_equal(i.cpu().numpy().astype(np.int64), ei)
+        assert np.array_equal(v.cpu().numpy(), ev)
+
+
+@pytest.mark.parametrize("rows,n", [(3, 1), (4, 2048), (3, 2049), (2, 3965), (5, 65537), (32, 100000), (1, 200001)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_argsort_desc_any_length_equals_numpy_stable(dev, rows, n, dtype):
+    """Full-row ranking (file-compat mode, train_retriever.py:357-362 writes the whole permutation) with no length cap:
+    == np.argsort(-x, kind='stable') including NaN (last), +-inf and -0.0."""
+    from rag4dyg_amd import ops
+    x = _rank_inputs(rows, n, 7 + n % 89, dtype)
+    perm = ops.argsort_desc(cu(x, dev)).cpu().numpy()
+    assert np.array_equal(perm, np.argsort(-x, axis=1, kind="stable"))
+
+
+def test_merge_topk_many_shards_general_path(dev):
+    """G * k > 1024 takes the gather + chunked top-k path; G * k <= 1024 the one-wave merge: both == a host merge."""
+    from rag4dyg_amd import ops
+    rng = np.random.default_rng(5)
+    for G, Q, k in ((20, 9, 64), (8, 33, 10), (3, 1, 1), (16, 5, 64)):
+        vals = np.round(rng.standard_normal((G, Q, k)) * 4).astype(np.float32) / 4
+        vals = -np.sort(-vals, axis=2)                                    # every shard list sorted by value
+        idx = np.sort(rng.integers(0, 1000, (G, Q, k)), axis=2) + 1000 * np.arange(G)[:, None, None]
+        # inside a shard equal values must carry ascending indices (they do: idx sorted, vals sorted)
+        flat_v = vals.transpose(1, 0, 2).reshape(Q, G * k)
+        flat_i = idx.transpose(1, 0, 2).reshape(Q, G * k)
+        order = np.lexsort((flat_i, -flat_v), axis=1)[:, :k]
+        vm, im = ops.merge_topk(cu(vals, dev), cu(idx.astype(np.int64), dev))
+        assert np.array_equal(im.cpu().numpy(), np.take_along_axis(flat_i, order, 1))
+        assert np.array_equal(vm.cpu().numpy(), np.take_along_axis(flat_v, order, 1))
+
+
+def test_untied_lm_head_logits_and_greedy(dev):
+    """A checkpoint whose lm_head.weight differs from transformer.wte.weight (the reference unties them): input
+    embeddings come from wte, logits and the device greedy loop from lm_head."""
+    from oracle import gpt2_ref
+    L, H, d, V, P = 2, 2, 64, 50, 64
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=12, random_affine=True)
+    sd["lm_head.weight"] = torch.randn(V, d, generator=torch.Generator().manual_seed(1)) * 0.05
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False)
+    assert not m.lm_head_is_tied()
+    m = m.to(dev).eval()
+    ids = torch.randint(0, V, (3, 9), generator=torch.Generator().manual_seed(2))
+    (logits, _), hidden = m(input_ids=ids.to(dev))
+    ref = gpt2_ref.gpt2_forward(sd, ids, H)
+    assert rel_err(hidden.cpu().numpy(), ref["hidden"].numpy()) < TOL
+    assert rel_err(logits.cpu().numpy(), ref["logits"].numpy()) < TOL
+    tied = gpt2_ref.gpt2_forward({k: v for k, v in sd.items() if k != "lm_head.weight"}, ids, H)["logits"]
+    assert rel_err(logits.cpu().numpy(), tied.numpy()) > 0.1              # it really is the other matrix
+    # device greedy loop (lm_head pointer of r4d_gpt2_weights) == oracle greedy decode with the untied head
+    prompt = ids[0].tolist()
+    want = gpt2_ref.greedy_decode(sd, H, prompt, eos_id=V - 1, mode="val")[len(prompt):]
+    tr = m.transformer
+    dec = tr.greedy_decoder(1, 64)
+    last = tr.prefill(dec.cache, input_ids=torch.tensor([prompt], device=dev))[:, -1, :].contiguous()
+    got = dec.run(last, torch.tensor([len(prompt)]), max_gen=11, len_limit=64, eos=(V - 1,))[0]
+    assert got == want, (got, want)
+
+
 def test_score_topk_golden_uci(dev):
     from rag4dyg_amd import ops
     from oracle import retrieval_ref

@@ -24,7 +24,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.r4d_abi_version() == 1
+    assert lib.r4d_abi_version() == 2
+    assert lib.r4d_build_flags() == 0                      # the in-tree library is a product build, not an ablation
     assert lib.r4d_last_error() == b""
     assert lib.r4d_profile_num_classes() > 0 and lib.r4d_profile_class_name(0).startswith(b"gemm")
     # size queries are pure host arithmetic
@@ -36,6 +37,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert need >= 4 * (M * 512 * 10 + 32 * 2 * 128 * 128)
     assert lib.r4d_attention_workspace_bytes(2, 2, 129) == 2 * 2 * 129 * 256 * 4
     assert lib.r4d_score_topk_workspace_bytes(32, 100000, 10) >= 32 * 100000 * 4
+    assert lib.r4d_topk_f32_workspace_bytes(32, 100000, 10) < 64 * 1024          # candidates + ticket counters only
+    assert lib.r4d_argsort_workspace_bytes(4, 2048, 4) <= 512                    # one chunk: sorted in LDS, no scratch
+    assert lib.r4d_argsort_workspace_bytes(4, 100000, 4) >= 4 * 49 * 2048 * 8
+    assert lib.r4d_argsort_workspace_bytes(4, 100000, 8) >= 4 * 49 * 2048 * 12
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -55,7 +60,100 @@ def test_product_path_has_no_cpu_fallback():
     assert "import oracle" not in src and "from oracle" not in src        # the product never touches the oracle
 
 
+def test_ablated_library_is_refused(tmp_path, monkeypatch):
+    """tools/kc_ablate.sh builds compute WRONG results by construction: r4d_build_flags() marks them and the binding
+    refuses to load one unless a tuning script opts in."""
+    from rag4dyg_amd import _lib, build
+    src = os.path.join(build.CSRC, "jaccard.hip")
+    obj = str(tmp_path / "jaccard_dbg.o")
+    subprocess.run([build.HIPCC, *build.FLAGS, "-DJAC_DBG=2", "-c", src, "-o", obj], check=True)
+    objs = [os.path.join(build.OBJ, f) for f in os.listdir(build.OBJ) if f.endswith(".o") and f != "jaccard.o"]
+    so = str(tmp_path / "librag4dyg_dbg.so")
+    subprocess.run([build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs, obj], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom rag4dyg_amd import _lib\n"
+            "try:\n    _lib.load(); print('LOADED', _lib.load().r4d_build_flags())\n"
+            "except _lib.R4DError as e:\n    print('REFUSED', 'ablation' in str(e))\n") % REPO
+    env = dict(os.environ, R4D_LIB_PATH=so)
+    env.pop("R4D_ALLOW_ABLATED_LIB", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert "REFUSED True" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, R4D_ALLOW_ABLATED_LIB="1"), capture_output=True,
+                         text=True, check=True).stdout
+    assert "LOADED 8" in out, out                          # bit 3 = JAC_DBG
+
+
 # ------------------------------------------------------------------------------------------- model layout
+def test_untied_checkpoint_loads_untied_and_reference_eval_tie_is_opt_in(monkeypatch):
+    """Generator / hepth checkpoints of the reference carry DIFFERENT transformer.wte.weight and lm_head.weight
+    (utils/tokenizer.py:56-66, utils/model.py:71-78 replace wte / the transformer without re-tying).  Loading one must
+    not pour lm_head into the input embedding."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    cfg = dict(vocab_size=23, n_positions=16, n_ctx=16, n_embd=64, n_layer=1, n_head=2)
+    sd = gpt2_ref.make_state_dict(1, 64, 23, n_positions=16, seed=4)
+    sd["lm_head.weight"] = torch.randn(23, 64) * 0.02
+    m = GPT2LMHeadModelRAG(GPT2Config(**cfg))
+    assert m.lm_head_is_tied()
+    m.load_state_dict(sd, strict=False)
+    assert not m.lm_head_is_tied()
+    assert torch.equal(m.transformer.wte.weight, sd["transformer.wte.weight"])
+    assert torch.equal(m.lm_head.weight, sd["lm_head.weight"])
+    saved = m.state_dict()                                  # round trip keeps both tensors
+    assert torch.equal(saved["lm_head.weight"], sd["lm_head.weight"])
+    assert torch.equal(saved["transformer.wte.weight"], sd["transformer.wte.weight"])
+    # a tied checkpoint leaves the model tied
+    m2 = GPT2LMHeadModelRAG(GPT2Config(**cfg))
+    m2.load_state_dict(gpt2_ref.make_state_dict(1, 64, 23, n_positions=16, seed=4), strict=False)
+    assert m2.lm_head_is_tied()
+    # the reference's eval-only quirk (tied model, strict load: lm_head wins) is available on request only
+    monkeypatch.setenv("R4D_REFERENCE_EVAL_TIE", "1")
+    m3 = GPT2LMHeadModelRAG(GPT2Config(**cfg))
+    m3.load_state_dict(sd, strict=False)
+    assert m3.lm_head_is_tied() and torch.equal(m3.transformer.wte.weight, sd["lm_head.weight"])
+
+
+def test_hepth_node_feature_injection_matches_reference_layout(tmp_path, monkeypatch):
+    """utils/tokenizer.py:56-66 on the shipped resources/hepth/node_features.npy: rows [0, V0) of wte are the node
+    features zero-padded to n_embd, the special-token rows keep their initialisation, and lm_head is NOT re-tied."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference resources only exist in the build container")
+    from types import SimpleNamespace
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    from rag4dyg_amd.tokenizer import WordLevelTokenizer, get_model_tokenizer
+    monkeypatch.chdir(tmp_path)
+    os.symlink(os.path.join(REF, "vocabs"), tmp_path / "vocabs")
+    feat_file = os.path.join(REF, "resources", "hepth", "node_features.npy")
+    args = SimpleNamespace(model_type="gpt2", dataset="hepth", timestamp="11", n_head=2, n_layer=1, n_embed=256,
+                           device=torch.device("cpu"), node_feat_file=feat_file, config_name=None, model_name_or_path=None)
+    torch.manual_seed(0)
+    model, tok, _, _ = get_model_tokenizer(args, {"gpt2": (GPT2Config, GPT2LMHeadModelRAG, WordLevelTokenizer)})
+    feats = np.load(feat_file)
+    V0 = tok.vocab_size
+    wte = model.transformer.wte.weight.detach().numpy()
+    assert wte.shape == (len(tok), 256) and feats.shape[1] == 172
+    assert np.array_equal(wte[:V0, :172], feats[:V0].astype(np.float32))
+    assert not wte[:V0, 172:].any()                                        # zero padding to n_embd
+    assert not model.lm_head_is_tied()                                     # as upstream: the old Parameter stays the head
+    head = model.lm_head.weight.detach().numpy()
+    assert head.shape == wte.shape and np.array_equal(head[V0:], wte[V0:])  # special rows: same initial values
+    assert not np.array_equal(head[:V0], wte[:V0])
+
+
+def test_from_pretrained_raises_on_shape_mismatch(tmp_path):
+    """modeling_utils.py:543-566: a checkpoint of another width / vocabulary is an error, not a silent re-init."""
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel, GPT2Model
+    small = GPT2LMHeadModel(GPT2Config(vocab_size=30, n_positions=16, n_ctx=16, n_embd=64, n_layer=1, n_head=2))
+    small.save_pretrained(str(tmp_path))
+    wide = GPT2Config(vocab_size=30, n_positions=16, n_ctx=16, n_embd=128, n_layer=1, n_head=2)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        GPT2Model.from_pretrained(str(tmp_path), config=wide)
+    deep = GPT2Config(vocab_size=30, n_positions=16, n_ctx=16, n_embd=64, n_layer=2, n_head=2)
+    with pytest.raises(RuntimeError, match="missing key"):
+        GPT2LMHeadModel.from_pretrained(str(tmp_path), config=deep)
+    ok = GPT2Model.from_pretrained(str(tmp_path))                           # LM-head checkpoint -> base model still loads
+    assert torch.equal(ok.wte.weight, small.transformer.wte.weight)
+
+
 def test_state_dict_layout_matches_reference_checkpoint_keys():
     from oracle import gpt2_ref
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel, GPT2LMHeadModelRAG, GPT2Model

@@ -52,20 +52,60 @@ def emit(**kw):
     print(json.dumps(kw), flush=True)
 
 
+def graph_wall(fn, iters=20, reps=5):
+    """GPU-side time of one `fn()` launch sequence: `iters` back-to-back copies captured into one HIP graph (no Python
+    or launch-API time between the kernels, only the GPU's own kernel-to-kernel gaps), replayed `reps` times."""
+    fn(); torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        fn()
+        st.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                fn()
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / (reps * iters)
+
+
 def scan():
-    for N in (12500, 100000):
-        d, Q, k = 512, 32, 10
+    cases = [(12500, 512), (100000, 512), (12500, 768), (100000, 768)]
+    if os.environ.get("R4D_SCAN_CASES"):
+        cases = [tuple(int(x) for x in c.split("x")) for c in os.environ["R4D_SCAN_CASES"].split(",")]
+    for N, d in cases:
+        Q, k = 32, 10
         g = torch.Generator().manual_seed(1)
         q = ops.normalize_rows(torch.randn(Q, d, generator=g).to(dev))
         p = ops.normalize_rows(torch.randn(N, d, generator=g).to(dev))
         wall, pr = profile(lambda: ops.score_topk(q, p, k), 50)
+        gw = float("nan") if os.environ.get("R4D_NO_GRAPH") else graph_wall(lambda: ops.score_topk(q, p, k))
         s = pr["pool_scan"]
-        emit(component="scan", N=N, d=d, Q=Q, k=k, wall_us=round(wall * 1e6, 1), kernel="pool_scan",
-             kernel_us=round(s["us"], 2), algorithmic_bytes=s["work"],
+        emit(component="scan", N=N, d=d, Q=Q, k=k, host_loop_wall_us=round(wall * 1e6, 1), gpu_wall_us=round(gw * 1e6, 2),
+             kernel="pool_scan", kernel_us=round(s["us"], 2), algorithmic_bytes=s["work"],
              roofline={"bound": "hbm", "achieved": round(s["gbs"], 1), "peak": PEAK, "unit": "GB/s",
                        "frac": round(s["gbs"] / PEAK, 4)},
-             topk_us=round(sum(v["us"] * v["launches"] for n, v in pr.items() if n == "topk_seg"), 2),
-             queries_per_s_scan_only=round(Q / wall, 1))
+             topk_us=round(sum(v["us"] * v["launches"] for n, v in pr.items() if n == "topk"), 2),
+             topk_launches=sum(v["launches"] for n, v in pr.items() if n == "topk"),
+             env={k_: v for k_, v in os.environ.items() if k_.startswith("R4D_SCAN")},
+             queries_per_s_scan_topk=round(Q / gw, 1))
+    # full-row ranking (file-compat mode) at the north-star pool size
+    S = torch.rand(32, 100000, generator=torch.Generator().manual_seed(2)).to(dev)
+    wall, pr = profile(lambda: ops.argsort_desc(S), 5)
+    emit(component="argsort", rows=32, n=100000, kernel_us=round(pr["argsort"]["us"], 1), wall_us=round(wall * 1e6, 1))
+
+
+def topk():
+    """Selection alone: per-round cost = slope over k."""
+    for n in (12500, 100000):
+        S = torch.rand(32, n, generator=torch.Generator().manual_seed(3)).to(dev)
+        for k in (1, 10, 64):
+            gw = graph_wall(lambda: ops.topk_f32(S, k))
+            emit(component="topk", rows=32, n=n, k=k, gpu_wall_us=round(gw * 1e6, 2))
 
 
 def jaccard():
@@ -180,5 +220,5 @@ def generator():
 
 
 if __name__ == "__main__":
-    for part in (sys.argv[1:] or ["scan", "jaccard", "pool", "generator"]):
-        {"scan": scan, "jaccard": jaccard, "pool": pool, "generator": generator}[part]()
+    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "pool", "generator"]):
+        {"scan": scan, "topk": topk, "jaccard": jaccard, "pool": pool, "generator": generator}[part]()
