@@ -190,12 +190,25 @@ def g3_config_shapes():
 
 # --------------------------------------------------------------------------- G4/G6
 def _ref_tokenizer(dataset, timestamp):
-    """Tokenizer built by the reference's own ``utils/tokenizer.get_model_tokenizer`` (tiny model)."""
+    """Tokenizer built by the reference's own ``utils/tokenizer.get_model_tokenizer`` (tiny model).  hepth: the reference
+    branches on the dataset NAME to inject node features with ``.cuda()`` (utils/tokenizer.py:56-66, cannot run on this
+    CPU-only box); the tokenizer itself depends only on ``vocabs/<name>/<t>/vocab.json``, so the harness points an alias
+    directory name at the same vocab file."""
     from models import GPT2Config
     import models.modeling_rag as mr
     from transformers import PreTrainedTokenizerFast
     from utils.tokenizer import get_model_tokenizer
-    assert dataset != "hepth"      # hepth branch needs .cuda() (utils/tokenizer.py:56-66); not used here
+    if dataset == "hepth":
+        alias = "hepth_vocab_alias"
+        os.makedirs("vocabs_alias/" + alias, exist_ok=True)
+        if os.path.islink("vocabs"):                      # scratch cwd: replace the symlink by a directory of symlinks
+            target = os.readlink("vocabs")
+            os.remove("vocabs"); os.makedirs("vocabs")
+            for name in os.listdir(target):
+                os.symlink(os.path.join(target, name), os.path.join("vocabs", name))
+        if not os.path.exists(os.path.join("vocabs", alias)):
+            os.symlink(os.path.join(REF, "vocabs", "hepth"), os.path.join("vocabs", alias))
+        dataset = alias
     args = types.SimpleNamespace(model_type="gpt2", config_name=None, model_name_or_path=None, cache_dir=None,
                                  n_head=2, n_layer=1, n_embed=16, eta=0.0, gamma=0.0, beta=0.0,
                                  timestamp=str(timestamp), dataset=dataset, device="cpu", node_feat_file=None)
@@ -298,8 +311,203 @@ def g5_jaccard():
               n=np.array([len(train), len(test), len(val)]), **csr)
 
 
+def g6_more_tokenizers():
+    """G6 for the other two shipped datasets: hepth/11 and dialog/15 ids of the first lines of every split."""
+    print("G6 hepth / dialog tokens")
+    import dataloader.retriever as dr
+    for ds, ts, block in (("hepth", 11, 1024), ("dialog", 15, 1024)):
+        tok = _ref_tokenizer(ds, ts)
+        base = f"resources/{ds}/{ts}/"
+        args = types.SimpleNamespace()
+        out = {}
+        for split, cls in (("train", dr.LineByLineTextDatasetHistory), ("test", dr.LineByLineTextDataset), ("val", dr.LineByLineTextDataset)):
+            with open(base + f"{split}.link_prediction") as f:
+                lines = [l for l in f.read().splitlines() if l.strip()][:40]
+            with open(f"g6_{ds}_{split}.txt", "w") as f:
+                f.write("\n".join(lines) + "\n")
+            d_ = cls(tok, args, f"g6_{ds}_{split}.txt", block_size=block)
+            out[split + "_flat"], out[split + "_off"] = _ragged(d_.examples)
+        names = ["<|endoftext|>", "<|history|>", "<|endofhistory|>", "<|pre|>", "<|endofpre|>", "<|time0|>", f"<|time{ts}|>", "[PAD]", "[MASK]"]
+        _save(f"g6_{ds}_tokens", special_names=np.array(names), special_ids=np.array([tok.convert_tokens_to_ids(t_) for t_ in names]),
+              len_tok=np.array(len(tok)), vocab_size=np.array(tok.vocab_size), pad_id=np.array(tok.pad_token_id), **out)
+
+
+# --------------------------------------------------------------------------- G7
+def _import_utils_model():
+    """``utils/model.py`` imports ``transformers.AdamW`` (gone in transformers 5.x): harness-side alias."""
+    import transformers
+    if not hasattr(transformers, "AdamW"):
+        transformers.AdamW = torch.optim.AdamW
+    import utils.model as um
+    return um
+
+
+def g7_generator():
+    """RAG generator side, from the reference's own code on CPU:
+    Evaluation metrics of both ``utils/Evaluation_*.py``, ``MLP_custom`` vectors, ``fusion_mlp`` logits and the greedy
+    loop of ``Evaluation_generator.py:153-175`` restated around the reference's ``fusion_mlp`` (tiny and reddit shape),
+    the SimpleDyG greedy loop of ``Evaluation_SimpleDyG.py:126-145`` around the reference model, ``TextIndexScoreDataset``.
+    NOT pinned: ``fusion_graphpooling`` -- ``GCNConv`` / ``from_networkx`` come from torch_geometric, absent here."""
+    print("G7 generator / evaluation")
+    import models.modeling_rag as mr
+    from oracle import generator_ref
+    from rag4dyg_amd import synth
+    um = _import_utils_model()
+    out = {}
+
+    # ---- (a) metrics: both Evaluation classes, random prediction / target token lists
+    import utils.Evaluation_generator as eg
+    import utils.Evaluation_SimpleDyG as es
+    rng = np.random.default_rng(77)
+    preds, tgts, rows = [], [], []
+    for _ in range(60):
+        tg = [str(x) for x in rng.choice(40, size=int(rng.integers(1, 9)), replace=False)]
+        pr = [str(x) for x in rng.choice(40, size=int(rng.integers(0, 12)), replace=True)]
+        if rng.random() < 0.5:
+            pr = tg[:int(rng.integers(0, len(tg) + 1))] + pr
+        preds.append(pr); tgts.append(tg)
+        row = []
+        for Ev in (eg.Evaluation(), es.Evaluation()):
+            row += [Ev.jaccard(pr, tg)] if (pr or tg) else [0.0]
+            for k in (1, 3, 5):
+                row += [Ev.ndcg_k(pr, tg, k), Ev.recall_k(pr, tg, k), Ev.precision_k(pr, tg, k), Ev.map_k(pr, tg, k)]
+        rows.append(row)
+    pf, po = _ragged([[int(x) for x in p_] for p_ in preds]); tf, to = _ragged([[int(x) for x in t_] for t_ in tgts])
+    out.update(met_pred_flat=pf, met_pred_off=po, met_tgt_flat=tf, met_tgt_off=to, met_values=np.asarray(rows, np.float64))
+
+    # ---- (b) MLP_custom forward
+    with torch.no_grad():
+        for n_layers, m in ((1, 1), (2, 3), (3, 2)):
+            ref = mr.MLP_custom(512, m, n_layers).eval()
+            sdm = generator_ref.make_mlp_state(900 + n_layers, 512, m, n_layers)
+            ref.load_state_dict(sdm)
+            x = torch.randn(24, 512, generator=torch.Generator().manual_seed(n_layers)) * 0.7
+            out[f"mlp{n_layers}_x"] = x.numpy(); out[f"mlp{n_layers}_y"] = ref(x).numpy()
+            out[f"mlp{n_layers}_cfg"] = np.array([512, m, n_layers, 900 + n_layers])
+
+    # ---- (c) fusion_mlp + greedy loop, tiny and reddit (BASELINE config 5) shapes
+    def run_fusion(tag, L, H, d, V, pad_id, eos_id, sources, queries, idxs, m, n_layers, topk, seed, n_gen=11):
+        sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+        model = _ref_model("rag", L, H, d, V, 1024, sd)
+        mlp = model.get_mlp(512, m, n_layers)
+        mlp.load_state_dict(generator_ref.make_mlp_state(seed + 1, 512, m, n_layers))
+        args = types.SimpleNamespace(device="cpu", n_embed=d, m=m)
+        tok = types.SimpleNamespace(pad_token_id=pad_id)
+        ds = types.SimpleNamespace(retrieval_sources=sources)
+        gen, first_logits, step_top = [], [], []
+        with torch.no_grad():
+            for q, ix in zip(queries, idxs):
+                toks = list(q)
+                ids_sim = torch.tensor(ix, dtype=torch.long)
+                g_, tops = [], []
+                while True:                       # Evaluation_generator.py:153-175, val mode, around the reference fusion_mlp
+                    logits = um.fusion_mlp(args, model, tok, ds, torch.tensor([toks]), ids_sim, m, top_k=topk)
+                    last = logits[0, -1, :]
+                    if not g_:
+                        first_logits.append(last.numpy().copy())
+                    nxt = int(torch.argmax(last).item())
+                    tv, ti = torch.topk(last, 2)
+                    tops.append([float(tv[0]), float(tv[1])])
+                    toks.append(nxt); g_.append(nxt)
+                    if len(g_) > n_gen - 1 or nxt == eos_id:
+                        break
+                gen.append(g_); step_top.append(tops)
+            # batched call (B > 1, equal lengths): the flat `view` reshapes mix the batch dimension exactly as upstream
+            same = [q for q in queries if len(q) == len(queries[0])][:2]
+            if len(same) == 2:
+                bl = um.fusion_mlp(args, model, tok, ds, torch.tensor(same), torch.tensor(idxs[:2], dtype=torch.long), m, top_k=topk)
+                out[tag + "_batch2_last"] = bl[:, -1, :64].numpy()
+        used = sorted({int(i) for ix in idxs for i in ix[:topk]})
+        sf, so = _ragged([sources[i] for i in used])
+        qf, qo = _ragged(queries); gf, go = _ragged(gen)
+        tt = np.full((len(gen), n_gen, 2), np.nan, np.float32)
+        for i, tps in enumerate(step_top):
+            tt[i, :len(tps)] = np.asarray(tps, np.float32)
+        out.update({tag + "_cfg": np.array([L, H, d, V, pad_id, eos_id, m, n_layers, topk, seed]),
+                    tag + "_src_ids": np.asarray(used, np.int64), tag + "_src_flat": sf, tag + "_src_off": so,
+                    tag + "_q_flat": qf, tag + "_q_off": qo, tag + "_idxs": np.asarray(idxs, np.int64),
+                    tag + "_gen_flat": gf, tag + "_gen_off": go, tag + "_first_logits": np.asarray(first_logits[:2]),
+                    tag + "_step_top2": tt})
+
+    rng = np.random.default_rng(5)
+    V, pad, eos = 79, 78, 60
+    srcs = [[eos, 61] + rng.integers(0, 60, int(rng.integers(3, 30))).tolist() + [62] for _ in range(40)]
+    qs = [[eos, 61] + rng.integers(0, 60, n).tolist() + [62] for n in (9, 9, 14, 5)]
+    run_fusion("fmlp_tiny", 2, 2, 64, V, pad, eos, srcs, qs, [rng.permutation(40)[:7].tolist() for _ in qs], 3, 2, 5, 310)
+    sh = synth.SHAPES["reddit"]
+    Vr = sh.vocab_generator
+    assert Vr == 11919
+    pool = [s_.tolist() for s_ in synth.sequences(sh, 10527, "pool", seed=2026)]
+    qr = [s_.tolist() for s_ in synth.sequences(sh, 6, "query", seed=31)]
+    rng = np.random.default_rng(6)
+    run_fusion("fmlp_reddit", 2, 8, 512, Vr, sh.pad_id, sh.v0, pool, qr, [rng.permutation(10527)[:7].tolist() for _ in qr],
+               1, 1, 7, 320)
+
+    # ---- (d) SimpleDyG greedy loop (Evaluation_SimpleDyG.py:126-145) around the reference model, val + test stop rules
+    def run_simpledyg(tag, L, H, d, V, eos_id, prompts, seed, max_len, n_spl):
+        sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+        model = _ref_model("gpt2", L, H, d, V, 1024, sd)
+        res = {}
+        with torch.no_grad():
+            for mode in ("val", "test"):
+                gens = []
+                for pr in prompts:
+                    toks, gen_len = list(pr), 0
+                    while True:
+                        nxt = int(torch.argmax(model(torch.tensor([toks]))[0][0, -1, :]).item())
+                        toks.append(nxt); gen_len += 1
+                        if mode == "val":
+                            if gen_len > 10:
+                                break
+                        elif len(toks) >= max_len - n_spl:
+                            break
+                        if nxt == eos_id:
+                            break
+                    gens.append(toks[len(pr):])
+                res[mode] = gens
+        pf_, po_ = _ragged(prompts)
+        out.update({tag + "_cfg": np.array([L, H, d, V, eos_id, seed, max_len, n_spl]), tag + "_p_flat": pf_, tag + "_p_off": po_})
+        for mode in ("val", "test"):
+            gf_, go_ = _ragged(res[mode])
+            out.update({f"{tag}_{mode}_flat": gf_, f"{tag}_{mode}_off": go_})
+
+    rng = np.random.default_rng(8)
+    run_simpledyg("sdg_tiny", 2, 2, 64, 79, 60, [[60, 61] + rng.integers(0, 60, n).tolist() + [62] for n in (4, 11, 7)],
+                  330, max_len=40, n_spl=6)
+    uci = synth.SHAPES["UCI_13"]
+    run_simpledyg("sdg_cfg1", 6, 8, 768, uci.vocab_generator, uci.v0,
+                  [s_.tolist() for s_ in synth.sequences(uci, 4, "query", seed=41)], 340, max_len=1024, n_spl=19)
+
+    # ---- (e) TextIndexScoreDataset (dataloader/generator.py:12-80) on the shipped UCI_13 files + a small index/score pair
+    import dataloader.generator as dg
+    tok = _ref_tokenizer("UCI_13", 12)
+    base = "resources/UCI_13/12/"
+    with open(base + "test.link_prediction") as f:
+        lines = [l for l in f.read().splitlines() if l.strip()][:12]
+    rng = np.random.default_rng(9)
+    idx_rows = [rng.permutation(1708)[:8].tolist() for _ in lines]
+    sc_rows = [np.round(np.sort(rng.random(8))[::-1], 4).tolist() for _ in lines]
+    with open("g7_text.txt", "w") as f:
+        f.write("\n".join(lines) + "\n\n")
+    with open("g7_index.txt", "w") as f:
+        f.write("\n".join(" ".join(map(str, r)) for r in idx_rows) + "\n")
+    with open("g7_score.txt", "w") as f:
+        f.write("\n".join(" ".join(f"{x:.4f}" for x in r) for r in sc_rows) + "\n")
+    ds = dg.TextIndexScoreDataset(tok, types.SimpleNamespace(train_data_file=base + "train.link_prediction"),
+                                  "g7_text.txt", "g7_index.txt", "g7_score.txt", block_size=512)
+    tf_, to_ = _ragged(ds.text); rf_, ro_ = _ragged(ds.retrieval_sources[:25])
+    item = ds[3]
+    out.update(tis_text_flat=tf_, tis_text_off=to_, tis_src_flat=rf_, tis_src_off=ro_, tis_n_sources=np.array(len(ds.retrieval_sources)),
+               tis_index=np.asarray(ds.index, np.int64), tis_score=np.asarray(ds.score, np.float64),
+               tis_egolist=np.asarray(ds.egolist, np.int64), tis_lines=np.array(lines),
+               tis_item3_text=item[0].numpy(), tis_item3_index=item[1].numpy(), tis_item3_score=item[2].numpy(),
+               tis_item3_ego=item[3].numpy(), tis_ego_lookup=ds.get_item_by_egoId(int(ds.egolist[5])).numpy())
+    _save("g7_generator", **out)
+
+
 def main():
-    groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard}
+    groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
+              "g6b": g6_more_tokenizers, "g7": g7_generator}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

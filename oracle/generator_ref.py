@@ -17,6 +17,27 @@ import torch
 from . import gpt2_ref
 
 
+def make_mlp_state(seed, input_dim, output_dim, n_layers, std=0.05):
+    """Deterministic ``MLP_custom`` state dict (keys ``layers.<i>.{weight,bias}``, ``modeling_rag.py:74-99``): the golden
+    generator loads exactly these tensors into the reference module, so they are not committed."""
+    g = torch.Generator().manual_seed(seed)
+    hidden = int(input_dim / 2)
+    dims = [(input_dim, output_dim)] if n_layers == 1 else \
+        [(input_dim, hidden)] + [(hidden, hidden)] * (n_layers - 2) + [(hidden, output_dim)]
+    sd = {}
+    for i, (a, b) in enumerate(dims):
+        j = i if n_layers == 1 else 2 * i                 # Sequential indices: Linear, ReLU, Linear, ...
+        sd[f"layers.{j}.weight"] = torch.randn(b, a, generator=g) * std
+        sd[f"layers.{j}.bias"] = torch.randn(b, generator=g) * std
+    return sd
+
+
+def mlp_layers_of(sd):
+    """[(weight, bias), ...] in layer order from a ``make_mlp_state`` / reference ``MLP_custom`` state dict."""
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("layers.")})
+    return [(sd[f"layers.{j}.weight"], sd[f"layers.{j}.bias"]) for j in idx]
+
+
 def star_union_graph(retrieval_sources, idxs):
     """The fused graph of ``fusion_graphpooling`` (``utils/model.py:181-189``): for every retrieved sequence, edges
     from its ego node (token at position 2) to EVERY token id of the sequence (special tokens and the ego itself

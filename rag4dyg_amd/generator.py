@@ -333,6 +333,15 @@ class TextIndexScoreDataset:
         return (torch.tensor(self.text[i], dtype=torch.long), torch.tensor(self.index[i], dtype=torch.long),
                 torch.tensor(self.score[i], dtype=torch.float), torch.tensor(self.egolist[i], dtype=torch.long))
 
+    def __gethistory__(self, i):
+        return torch.tensor(self.text[i], dtype=torch.long)
+
+    def get_item_by_egoId(self, egoId):
+        """``dataloader/generator.py:73-80``: the text of the LAST line whose ego id is ``egoId`` (None when absent)."""
+        if egoId not in self.egoId or self.egoId[egoId] >= len(self.text):
+            return None
+        return self.__gethistory__(self.egoId[egoId])
+
 
 def load_and_cache_examples(args, tokenizer, evaluate=False, test=False):
     """``dataloader/generator.py:83-101``."""

@@ -32,12 +32,19 @@ class Shape:
     def pad_id(self):
         return self.v0 + 6 + self.t
 
+    @property
+    def vocab_generator(self):   # len(tokenizer), SimpleDyG / generator flavour (no [MASK]; main_SimpleDyG.py:91-95)
+        return self.v0 + 7 + self.t
+
 
 # architecture: scripts/train_retriever/train_retriever_{UCI_13,wikiv2}.sh; lengths: SURVEY.md section 5 / 8d
 UCI_13 = Shape("UCI_13", 1781, 12, 4, 2, 512, (13, 158, 329), (59, 304, 339))
 WIKIV2 = Shape("wikiv2", 8794, 15, 2, 6, 768, (6, 86, 512), (43, 225, 512))
 HEPTH = Shape("hepth", 4737, 11, 12, 2, 256, (9, 39, 78), (9, 39, 78), 1024)
-SHAPES = {"UCI_13": UCI_13, "wikiv2": WIKIV2, "hepth": HEPTH}
+# generator shape of BASELINE config 5: scripts/train_generator/train_rag_graphpooling_reddit_seed.sh:6-10 (L2 H8 d512),
+# V0 = 11,901 (len(tokenizer) = 11,919 without [MASK]), pool 10,527, history length p50/p99 = 8/133
+REDDIT = Shape("reddit", 11901, 11, 2, 8, 512, (8, 133, 512), (8, 133, 512))
+SHAPES = {"UCI_13": UCI_13, "wikiv2": WIKIV2, "hepth": HEPTH, "reddit": REDDIT}
 
 
 def _lengths(rng, n, median, p99, cap, lo=6):

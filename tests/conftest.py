@@ -30,3 +30,43 @@ def rel_err(got, ref):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def elementwise_err(got, ref, rtol=1e-4, atol=1e-5):
+    """Element-wise tolerance check: max over elements of |got-ref| / (rtol * |ref| + atol * max|ref|); PASS iff < 1.
+    north_star's "1e-4 relative fp32" applied to every element, with an absolute floor of 1e-5 of the tensor's largest
+    magnitude for the elements near zero (a K-term fp32 dot product cannot be relatively accurate where it cancels) --
+    unlike ``rel_err`` (max-norm) it cannot hide a relative error on the small elements behind the large ones."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float((np.abs(got - ref) / (rtol * np.abs(ref) + atol * max(np.abs(ref).max(), 1e-30))).max())
+
+
+def rank_mismatch_report(ref_scores, ref_idx, got_idx):
+    """Ranked top-k lists of the device against the reference's stable top-k.  Returns (fraction of rows whose whole
+    list is identical, largest REFERENCE-score gap between the item the device ranked at a position and the item the
+    reference ranked there, over all mismatching positions).  A mismatch is legitimate only inside fp32 summation noise."""
+    ref_scores = np.asarray(ref_scores, dtype=np.float64)
+    ref_idx, got_idx = np.asarray(ref_idx), np.asarray(got_idx)
+    same = (ref_idx == got_idx)
+    gap = 0.0
+    for r, c in zip(*np.nonzero(~same)):
+        gap = max(gap, abs(ref_scores[r, ref_idx[r, c]] - ref_scores[r, got_idx[r, c]]))
+    return float(same.all(axis=1).mean()), float(gap)
+
+
+def assert_tokens_equal_or_tie(got, want, logits_at, what="", rel_gap=2e-6):
+    """Greedy-decoded id lists must be equal.  A first difference at step i is accepted ONLY when the oracle's logits for
+    that step (``logits_at(prefix ids) -> 1-D array``) separate the two candidates by less than ``rel_gap * max|logit|``
+    (fp32 summation order decides the argmax there); the gap is printed.  Returns 1 when equal, 0 for a justified tie."""
+    got, want = list(got), list(want)
+    if got == want:
+        return 1
+    i = next((j for j, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))
+    assert i < min(len(got), len(want)), f"{what}: one list is a strict prefix of the other: {got} vs {want}"
+    lg = np.asarray(logits_at(want[:i]), dtype=np.float64)
+    gap = abs(lg[want[i]] - lg[got[i]])
+    scale = np.abs(lg).max()
+    print(f"[tie] {what}: step {i} device {got[i]} vs oracle {want[i]}: logit gap {gap:.3e} (max|logit| {scale:.3e})")
+    assert gap <= rel_gap * scale, f"{what}: step {i} differs at a logit gap of {gap:.3e} (> {rel_gap} * {scale:.3e})"
+    return 0

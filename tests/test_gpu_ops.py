@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import elementwise_err, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -297,8 +297,9 @@ def test_encoder_g1_every_layer(dev):
     loss, logits, presents, hs = m(ids, labels=ids)
     for i in range(L):
         assert rel_err(hs[i].cpu().numpy(), g[f"layer{i}"]) < 1e-5
-    assert rel_err(hs[-1].cpu().numpy(), g["hidden"]) < 1e-5
-    assert rel_err(logits.cpu().numpy(), g["logits"]) < 1e-5
+        assert elementwise_err(hs[i].cpu().numpy(), g[f"layer{i}"]) < 1       # every element: 1e-4 |ref| + 1e-5 max|ref|
+    assert rel_err(hs[-1].cpu().numpy(), g["hidden"]) < 1e-5 and elementwise_err(hs[-1].cpu().numpy(), g["hidden"]) < 1
+    assert rel_err(logits.cpu().numpy(), g["logits"]) < 1e-5 and elementwise_err(logits.cpu().numpy(), g["logits"]) < 1
     assert abs(loss.item() - float(g["loss"])) < 1e-5
     assert rel_err(presents[0].cpu().numpy(), g["present0"]) < 1e-5
     # retriever flavour: (outputs, hidden); inputs_embeds path; fused mean-pool
@@ -322,6 +323,9 @@ def test_encoder_g3_config_shapes(dev, name):
     r = m.transformer.encode(ids, want_hidden=True, want_meanpool=True)
     h = r["hidden"].cpu()
     assert rel_err(h[:, g["rows"].tolist(), :].numpy(), g["hidden_rows"]) < TOL
+    ew = elementwise_err(h[:, g["rows"].tolist(), :].numpy(), g["hidden_rows"])     # hidden states BEFORE pooling, element-wise
+    print(f"{name}: hidden max-norm err {rel_err(h[:, g['rows'].tolist(), :].numpy(), g['hidden_rows']):.2e}, element-wise ratio {ew:.3f}")
+    assert ew < 1, ew
     assert rel_err(r["meanpool"].cpu().numpy(), g["meanpool"]) < TOL
     assert abs(h.double().abs().sum().item() / float(g["hidden_abs_sum"]) - 1) < 1e-5
     if name.startswith("cfg1"):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, load_golden, rel_err
+from conftest import REPO, assert_tokens_equal_or_tie, elementwise_err, load_golden, rank_mismatch_report, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -49,11 +49,18 @@ def test_uci13_real_ids_match_reference_embeddings_scores_ranks(dev):
     assert rel_err(pool.norm(dim=1).cpu().numpy(), g["pool_emb_norms"]) < TOL
     assert rel_err(pool.double().sum(0).cpu().numpy(), g["pool_emb_colsum"]) < TOL
     assert rel_err(q.cpu().numpy(), g["query_emb"]) < TOL
+    # element-wise too: |d| <= 1e-4 |ref| + 1e-5 max|ref| for EVERY element (conftest.elementwise_err)
+    assert elementwise_err(q.cpu().numpy(), g["query_emb"]) < 1
+    assert elementwise_err(pool[:64].cpu().numpy(), g["pool_emb_head"]) < 1
     vals, idx, S = PoolIndex(pool).search(q, 10, want_scores=True)
-    assert rel_err(S.cpu().numpy(), g["scores"]) < TOL
-    assert retrieval_ref.topk_matches_modulo_ties(g["scores"], idx.cpu().numpy(), 10, 2e-5)
-    exact = (idx.cpu().numpy() == g["top10_stable"]).all(axis=1).mean()
-    assert exact > 0.9, exact                     # identical ranked top-10 lists except at sub-1e-5 score gaps
+    assert rel_err(S.cpu().numpy(), g["scores"]) < TOL and elementwise_err(S.cpu().numpy(), g["scores"]) < 1
+    # ranked top-10 against the reference's stable top-10: identical lists, except where two REFERENCE scores are closer
+    # than fp32 summation noise (2e-6 on scores in [0, 1]) -- reported, and nothing beyond that is tolerated
+    exact, gap = rank_mismatch_report(g["scores"], g["top10_stable"], idx.cpu().numpy())
+    print(f"UCI_13 top-10: {exact:.4f} of the 110 ranked lists identical to the reference's; largest reference-score gap at a "
+          f"mismatching rank {gap:.2e}; max |score - reference| {np.abs(S.cpu().numpy() - g['scores']).max():.2e}")
+    assert gap <= 2e-6, gap
+    assert retrieval_ref.topk_matches_modulo_ties(g["scores"], idx.cpu().numpy(), 10, 2e-6)
 
 
 # ------------------------------------------------------------------------------------------- synthetic dataset
@@ -159,7 +166,15 @@ def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch
             f"--eval_data_file {base}/val.link_prediction --eval_data_gt_file {base}/val_score.retrieval "
             f"--test_data_file {base}/test.link_prediction --test_data_gt_file {base}/test_score.retrieval "
             f"--block_size 512 --n_layer {L} --n_head {H} --n_embed {d} --topK 5").split()
+    captured = {}
+    real_test = main_retriever.test
+
+    def spy(epoch, args, model, tokenizer, evaluate=False, prefix=""):      # also run the validation branch (A11: BCE metric)
+        captured["val"] = real_test(epoch, args, model, tokenizer, evaluate=True, prefix="probe")
+        return real_test(epoch, args, model, tokenizer, evaluate=evaluate, prefix=prefix)
+    monkeypatch.setattr(main_retriever, "test", spy)
     main_retriever.main(argv)
+    monkeypatch.setattr(main_retriever, "test", real_test)
     res = tmp_path / "resources" / "retrieval_result" / "toy"
     idx_rows = np.array(_read_matrix(res / "test_index.gen", int))
     score_rows = np.array(_read_matrix(res / "test_score.gen"))
@@ -178,17 +193,32 @@ def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch
     q = retrieval_ref.encode_batches(sd, H, retrieval_ref.right_pad_batches(q_ids, 32, tok.pad_token_id))
     S = retrieval_ref.score_batch(q, pool).numpy()
     assert score_rows.shape == S.shape == (37, 150)
+    # A11 (train_retriever.py:439-441,477): BCEWithLogits of the score rows against the float32 Jaccard rows, summed over
+    # the batches' means and divided by the number of queries -- against oracle/retrieval_ref.bce_with_logits_mean
+    qv_ids = tok(rd(os.path.join(base, "val.link_prediction")), max_length=512)["input_ids"]
+    qv = retrieval_ref.encode_batches(sd, H, retrieval_ref.right_pad_batches(qv_ids, 32, tok.pad_token_id))
+    Sv = retrieval_ref.score_batch(qv, pool).numpy()
+    ref_loss = sum(retrieval_ref.bce_with_logits_mean(Sv[i:i + 32], gt["val"][i:i + 32]) for i in range(0, len(Sv), 32)) / len(Sv)
+    val_metrics, val_loss = captured["val"]
+    assert abs(float(val_loss) - ref_loss) <= 1e-5 * ref_loss, (float(val_loss), ref_loss)
+    ref_val_hits = retrieval_ref.hit_metrics([Sv[i:i + 32] for i in range(0, len(Sv), 32)],
+                                             [gt["val"][i:i + 32] for i in range(0, len(Sv), 32)])
+    assert abs(val_metrics["hit@1"] - ref_val_hits[0]) <= 1e-4 and abs(val_metrics["hit@3"] - ref_val_hits[1]) <= 1e-4
     assert np.abs(score_rows - S).max() < 1e-4 + 5e-5                   # %.4f text
     assert all(sorted(r) == list(range(150)) for r in idx_rows.tolist())   # full permutations
-    assert retrieval_ref.topk_matches_modulo_ties(S, idx_rows, 5, 1e-5)
-    assert (idx_rows[:, :5] == retrieval_ref.rank_full(S)[:, :5]).all(axis=1).mean() > 0.9
+    exact5, gap5 = rank_mismatch_report(S, retrieval_ref.rank_full(S)[:, :5], idx_rows[:, :5])
+    print(f"CLI top-5: {exact5:.4f} of rows identical to the oracle's, largest oracle-score gap at a mismatch {gap5:.2e}")
+    assert gap5 <= 2e-6, gap5
     csv = open(res / "test_results.csv").read()
     assert "Hit@1, Hit@3" in csv
     hits = [float(x) for x in csv.strip().splitlines()[1].split(",")[-2:]]
     sb = [S[i:i + 32] for i in range(0, 37, 32)]
     gb = [gt["test"][i:i + 32] for i in range(0, 37, 32)]
     ref_hits = retrieval_ref.hit_metrics(sb, gb)
-    assert abs(hits[0] - ref_hits[0]) <= 0.03 and abs(hits[1] - ref_hits[1]) <= 0.03
+    # hit@k: equal to the oracle's unless a rank mismatch above (none beyond 2e-6 ties) flips a hit -- at most one query per
+    # flipped row, i.e. 1/37 per batch-mean term; with identical rankings the metrics are identical
+    tol_hit = 0.0 if exact5 == 1.0 else (1.0 - exact5) + 1e-4
+    assert abs(hits[0] - ref_hits[0]) <= tol_hit + 1e-4 and abs(hits[1] - ref_hits[1]) <= tol_hit + 1e-4, (hits, ref_hits, exact5)
     # tokenizer files written in the reference layout
     assert (tmp_path / "tokenizers" / "toy" / "4" / "tokenizer.json").exists()
     # one process per GPU (two ranks, gloo on this one-GPU box): the pool encode is sharded by whole batches, every rank
@@ -203,8 +233,8 @@ def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch
     done = [pr.communicate(timeout=600) for pr in procs]
     assert all(pr.returncode == 0 for pr in procs), [e[-1500:] for _, e in done]
     idx2 = np.array(_read_matrix(res / "test_index.gen", int))
-    assert idx2.shape == idx_rows.shape and (idx2[:, :5] == idx_rows[:, :5]).all(axis=1).mean() > 0.9
-    assert retrieval_ref.topk_matches_modulo_ties(S, idx2, 5, 1e-5)
+    assert idx2.shape == idx_rows.shape
+    assert rank_mismatch_report(S, retrieval_ref.rank_full(S)[:, :5], idx2[:, :5])[1] <= 2e-6
     assert np.abs(np.array(_read_matrix(res / "test_score.gen")) - score_rows).max() <= 1.01e-4
     assert open(res / "test_results.csv").read() == csv
 
@@ -274,21 +304,22 @@ def test_simpledyg_greedy_eval_matches_oracle_decode(dev, tmp_path, monkeypatch)
     m = m.to(dev).eval()
     lines = jaccard_ref.read_lines(os.path.join(base, "val.link_prediction"))
     eos = tok.eos_token_id
-    same = 0
+    def logits_for(ids):
+        return lambda prefix: gpt2_ref.gpt2_forward(sd, torch.tensor([ids + list(prefix)]), H)["logits"][0, -1].numpy()
     for mode in ("val", "test"):
         for ln in lines[:6]:
             ids = tok.encode(ln)
             got = greedy_decode(m, tok, ids, mode, P, 12, dev)
             ref = gpt2_ref.greedy_decode(sd, H, ids, eos, mode, P, 12)
-            same += got == ref
             assert got[:len(ids)] == ids and len(got) > len(ids)
-    assert same >= 11                                   # argmax can only differ at sub-1e-6 logit ties
+            assert_tokens_equal_or_tie(got[len(ids):], ref[len(ids):], logits_for(ids), f"SimpleDyG {mode}")   # equal, or a printed sub-2e-6 tie
     from rag4dyg_amd.evaluation import greedy_decode_batch
     prompts = [tok.encode(ln) for ln in lines[:9]]
-    for mode in ("val", "test"):                        # cached, batched decode == the reference's one-at-a-time loop
-        one = [greedy_decode(m, tok, p_, mode, P, 12, dev) for p_ in prompts]
+    for mode in ("val", "test"):                        # cached, batched decode == the oracle's one-at-a-time loop
         many = greedy_decode_batch(m, tok, prompts, mode, P, 12, dev)
-        assert sum(a == b for a, b in zip(one, many)) >= len(prompts) - 1
+        for p_, got in zip(prompts, many):
+            ref = gpt2_ref.greedy_decode(sd, H, p_, eos, mode, P, 12)
+            assert_tokens_equal_or_tie(got[len(p_):], ref[len(p_):], logits_for(p_), f"SimpleDyG {mode} cached batch")
     argv = (f"--dataset toy --timestamp 4 --output_dir {tmp_path}/out --model_type gpt2 --train_data_file "
             f"{base}/train.link_prediction --do_eval --eval_all_checkpoints --eval_data_file {base}/val.link_prediction "
             f"--eval_data_gt_file {base}/val_gt.link_prediction --block_size 128 --n_layer {L} --n_head {H} --n_embed {d}").split()
@@ -355,7 +386,6 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
     ds = types.SimpleNamespace(retrieval_sources=sources)
     lines = jaccard_ref.read_lines(os.path.join(base, "val.link_prediction"))
     rng = np.random.default_rng(1)
-    same = total = 0
     for fusion in ("graphpooling", "mlp"):
         args = types.SimpleNamespace(fusion=fusion, m=m_rows, topK=topk)
         for ln in lines[:4]:
@@ -374,9 +404,9 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
             assert rel_err(rows.numpy(), ref_aug[0, 2:2 + nrows].numpy()) < 1e-5
             got = generator.greedy_decode_rag(args, model, tok, ds, ids, idx, "val", P, 12)
             ref = generator_ref.greedy_decode_rag(sd, H, fn, ids, tok.eos_token_id, "val", P, 12)
-            same += got == ref; total += 1
             assert got[:len(ids)] == ids and len(got) > len(ids)
-    assert same >= total - 1                            # argmax can only differ at sub-1e-6 logit ties
+            la = lambda prefix, fn=fn, ids=ids: gpt2_ref.gpt2_forward(sd, None, H, inputs_embeds=fn(ids + list(prefix)))["logits"][0, -1].numpy()
+            assert_tokens_equal_or_tie(got[len(ids):], ref[len(ids):], la, f"RAG {fusion}")
     # data-parallel decode of many queries (right-padded batch) == one query at a time, val and test stop rules
     args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=topk)
     qs = [tok.encode(ln) for ln in lines[:9]]
@@ -385,9 +415,12 @@ def test_rag_generator_fusion_and_decode_match_oracle(dev, tmp_path, monkeypatch
     rows_all = generator.fusion_rows_batch(args, model, tok, ds, ixs, topk)
     assert rows_all.shape == rows_one.shape and rel_err(rows_all.cpu().numpy(), rows_one.cpu().numpy()) < 1e-5
     for mode in ("val", "test"):
-        one = [generator.greedy_decode_rag(args, model, tok, ds, q, ix, mode, P, 12) for q, ix in zip(qs, ixs)]
         many = generator.greedy_decode_rag_batch(args, model, tok, ds, qs, ixs, mode, P, 12)
-        assert sum(a == b for a, b in zip(one, many)) >= len(qs) - 1
+        for q, ix, got in zip(qs, ixs, many):
+            fn = lambda t, ix=ix: generator_ref.fusion_graphpooling_embeds(sd, sources, t, ix, topk, convs)
+            ref = generator_ref.greedy_decode_rag(sd, H, fn, q, tok.eos_token_id, mode, P, 12)
+            la = lambda prefix, fn=fn, q=q: gpt2_ref.gpt2_forward(sd, None, H, inputs_embeds=fn(q + list(prefix)))["logits"][0, -1].numpy()
+            assert_tokens_equal_or_tie(got[len(q):], ref[len(q):], la, f"RAG cached batch {mode}")
         if mode == "test":
             assert all(len(t) <= P - 12 for t in many) and any(len(t) == P - 12 or t[-1] == tok.eos_token_id for t in many)
     # CLI: index / score files as main_retriever writes them (one row of pool indices / scores per query)

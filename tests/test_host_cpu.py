@@ -255,6 +255,26 @@ def test_tokenizer_on_shipped_files_matches_reference_ids():
         assert np.array_equal(np.cumsum([0] + [len(x) for x in ids]), g[key + "_off"])
 
 
+@has_ref
+@pytest.mark.parametrize("ds,ts", [("hepth", 11), ("dialog", 15)])
+def test_tokenizer_on_shipped_hepth_and_dialog_files_matches_reference_ids(ds, ts):
+    """G6 for the other two shipped datasets (block_size 1024, utils/tokenizer.py:41-43): ids of the first 40 lines of
+    every split, special-token ids, len(tokenizer), as the reference's own tokenizer + dataset classes produced them."""
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    g = load_golden(f"g6_{ds}_tokens")
+    tok, _ = build_tokenizer(ds, ts, root=REF)
+    assert len(tok) == int(g["len_tok"]) and tok.vocab_size == int(g["vocab_size"]) and tok.pad_token_id == int(g["pad_id"])
+    for name, want in zip(g["special_names"], g["special_ids"]):
+        assert tok.convert_tokens_to_ids(str(name)) == int(want), name
+    for split, hist in (("train", True), ("test", False), ("val", False)):
+        lines = [l for l in open(f"{REF}/resources/{ds}/{ts}/{split}.link_prediction").read().splitlines() if l.strip()][:40]
+        if hist:
+            lines = [l.split('<|pre|>')[0].strip() for l in lines]
+        ids = tok(lines, max_length=1024)["input_ids"]
+        assert np.array_equal(np.concatenate([np.asarray(x) for x in ids]), g[split + "_flat"])
+        assert np.array_equal(np.cumsum([0] + [len(x) for x in ids]), g[split + "_off"])
+
+
 # ------------------------------------------------------------------------------------------- data / parsing / synth
 def test_dataset_classes_and_eval_batching(tmp_path):
     from types import SimpleNamespace
@@ -503,3 +523,30 @@ def test_length_buckets_partition_and_cost():
     groups = GPT2Model.length_buckets(lens, max_buckets=3, bucket_cost=100)
     assert sum(len(g) * max(lens[i] for i in g) + 100 for g in groups) == best
     assert GPT2Model.length_buckets([]) == []
+
+
+@has_ref
+def test_text_index_score_dataset_matches_reference_class(tmp_path):
+    """dataloader/generator.py:12-80 (the reference class, run by gen_golden.py on the shipped UCI_13 files) against the
+    product's TextIndexScoreDataset: text / retrieval-source ids, index and score rows, ego ids, item tuple, ego lookup."""
+    from types import SimpleNamespace
+    from rag4dyg_amd.generator import TextIndexScoreDataset
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    g = load_golden("g7_generator")
+    unrag = lambda f, o: [f[o[i]:o[i + 1]].tolist() for i in range(len(o) - 1)]
+    (tmp_path / "text.txt").write_text("\n".join(str(x) for x in g["tis_lines"]) + "\n\n")
+    (tmp_path / "index.txt").write_text("\n".join(" ".join(map(str, r)) for r in g["tis_index"].tolist()) + "\n")
+    (tmp_path / "score.txt").write_text("\n".join(" ".join(f"{x:.4f}" for x in r) for r in g["tis_score"].tolist()) + "\n")
+    tok, _ = build_tokenizer("UCI_13", 12, with_mask=False, root=REF)
+    ds = TextIndexScoreDataset(tok, SimpleNamespace(train_data_file=os.path.join(REF, "resources/UCI_13/12/train.link_prediction")),
+                               str(tmp_path / "text.txt"), str(tmp_path / "index.txt"), str(tmp_path / "score.txt"), block_size=512)
+    assert [list(x) for x in ds.text] == unrag(g["tis_text_flat"], g["tis_text_off"])
+    assert len(ds.retrieval_sources) == int(g["tis_n_sources"])
+    assert [list(x) for x in ds.retrieval_sources[:25]] == unrag(g["tis_src_flat"], g["tis_src_off"])
+    assert np.array_equal(np.asarray(ds.index), g["tis_index"]) and np.array_equal(np.asarray(ds.score), g["tis_score"])
+    assert ds.egolist == g["tis_egolist"].tolist() and len(ds) == len(g["tis_lines"])
+    it = ds[3]
+    assert it[0].tolist() == g["tis_item3_text"].tolist() and it[1].tolist() == g["tis_item3_index"].tolist()
+    assert np.array_equal(it[2].numpy(), g["tis_item3_score"]) and int(it[3]) == int(g["tis_item3_ego"])
+    assert ds.get_item_by_egoId(int(ds.egolist[5])).tolist() == g["tis_ego_lookup"].tolist()
+    assert ds.get_item_by_egoId(10 ** 9) is None
