@@ -11,10 +11,13 @@ A STEP is one pass of the hot path over one batch of synthetic input, per rank:
   over the concatenated rows of the G batches) + fused ln_f/mean-pool -> row normalise ->
   [N>1: RCCL all-gather of the query embeddings] -> (S+1)/2 cosine scan of the rank's resident pool shard ->
   canonical top-10 -> [N>1: RCCL all-gather of the per-shard top-k + merge].
-Inputs (token ids, the pre-encoded pool shard) are resident in HBM before the timed region.  Weak scaling:
-every rank owns a fixed 12,500-row pool shard and encodes its own query batch, so N=8 is the north-star
-100k-sequence pool.  Rank 0 prints ONE JSON line.
+Inputs (token ids, the pre-encoded pool shard) are resident in HBM before the timed region.  The pool is the
+north-star 100,000-sequence pool at EVERY N: one GPU holds all of it (205 MB of fp32 embeddings), N GPUs hold
+contiguous batch-aligned shards of it (12,500 rows each at N = 8).  Weak scaling in the unit of the metric: every
+rank encodes its own G x 32 queries per step and scans its shard for the queries of all ranks, so per-GPU work is
+fixed as N grows.  Rank 0 prints ONE JSON line.
 """
+import hashlib
 import argparse
 import json
 import os
@@ -76,20 +79,29 @@ def host_cores():
 
 
 def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
-    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
-    from oracle import retrieval_ref
+    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample.  Like the reference
+    (train_retriever.py:419: ``_, h = model(input_ids)`` computes lm_logits and throws them away) the forward INCLUDES
+    the lm_head GEMM; the rate without it is reported beside it."""
+    from oracle import gpt2_ref, retrieval_ref
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
     pool = pool_emb.cpu()
     torch.set_num_threads(host_cores())
     done, t0 = 0, time.perf_counter()
-    nb = 0
+    nb, t_head = 0, 0.0
     while True:
         chunk = query_seqs[nb * QB:(nb + 1) * QB]
         if not chunk:
             break
         b = retrieval_ref.right_pad_batches(chunk, QB, shape.pad_id)
-        q = retrieval_ref.encode_batches(sd, shape.n_head, b)
-        S = retrieval_ref.score_batch(q, pool).numpy()
+        embs = []
+        for ids in b:                                               # retrieval_ref.encode_batches + the discarded lm_head
+            with torch.no_grad():
+                out = gpt2_ref.gpt2_forward(sd, ids, shape.n_head, want_logits=False)
+                th = time.perf_counter()
+                torch.matmul(out["hidden"], sd["transformer.wte.weight"].t())      # modeling_rag.py:675, result unused
+                t_head += time.perf_counter() - th
+            embs.append(out["hidden"].mean(dim=1))
+        S = retrieval_ref.score_batch(torch.cat(embs), pool).numpy()
         retrieval_ref.topk_stable(S, k)
         done += len(chunk)
         nb += 1
@@ -97,8 +109,84 @@ def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
             break
     el = time.perf_counter() - t0
     return {"value": round(done / el, 2), "unit": "query-seqs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{nb} query batches of {QB} (same synthetic UCI_13-shape inputs, same pool shard of "
-                      f"{pool.shape[0]} rows), oracle torch-CPU fp32 encode + score + stable top-{k}, {el:.1f} s"}
+            "value_without_lm_head": round(done / (el - t_head), 2),
+            "sample": f"{nb} query batches of {QB} (same synthetic {shape.name}-shape inputs, same resident pool of "
+                      f"{pool.shape[0]} rows), oracle torch-CPU fp32 encode INCLUDING the lm_head GEMM the reference computes "
+                      f"and discards + score + stable top-{k}, {el:.1f} s"}
+
+
+def verify_sharded(world, rank, device, index, last_out, model, q_batches, args, G, k, gather, elapsed_local):
+    """N > 1, after the timed region: (1) the process group really has `--gpus` ranks on distinct devices, (2) the merged
+    top-k of the LAST timed step equals what ONE GPU computes over the whole pool (rank 0 gathers every shard and rescans:
+    bit-exact values and indices), (3) per-rank wall time of the timed region (load spread)."""
+    assert dist.get_world_size() == args.gpus == world
+    dev_ids = [None] * world
+    dist.all_gather_object(dev_ids, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(device).name))
+    times = [None] * world
+    dist.all_gather_object(times, elapsed_local)
+    # the last timed step's queries, recomputed (deterministic): step index = steps - 1
+    i = args.steps - 1
+    nqb = len(q_batches)
+    emb = model.encode_groups_meanpool([q_batches[(i * G + j) % nqb] for j in range(G)])
+    q_all = gather(ops.normalize_rows(emb))
+    all_rows = [None] * world
+    dist.all_gather_object(all_rows, int(index.pool_hat.shape[0]))
+    nmax = max(all_rows)
+    pad = torch.zeros(nmax, index.pool_hat.shape[1], dtype=torch.float32, device=device)
+    pad[:index.pool_hat.shape[0]] = index.pool_hat
+    stacked = gather(pad).view(world, nmax, -1)                      # every rank receives every shard (205 MB at 100k x 512)
+    full = torch.cat([stacked[r, :all_rows[r]] for r in range(world)])
+    v1, i1, _ = ops.score_topk(q_all, full, k, 0)
+    mine = bool(torch.equal(i1, last_out[1]) and torch.equal(v1, last_out[0]))
+    oks = [None] * world
+    dist.all_gather_object(oks, mine)
+    ok = all(oks)
+    if not ok and rank == 0:
+        print(f"[bench] VERIFY FAILED: sharded top-k differs from the one-GPU recomputation on ranks {[r for r, o in enumerate(oks) if not o]}",
+              file=sys.stderr)
+    ms = [1e3 * t_ / args.steps for t_ in times]
+    return {"world_size": world, "devices": sorted({d[1] for d in dev_ids}), "device_names": sorted({d[2] for d in dev_ids}),
+            "sharded_topk_equals_one_gpu": ok, "pool_rows_checked": int(sum(all_rows)),
+            "per_rank_ms_per_step": [round(x, 3) for x in ms],
+            "rank_spread": round((max(ms) - min(ms)) / max(ms), 4)}
+
+
+def source_sha():
+    """sha256 over the kernel sources, the C ABI header and this file: what a PMC traffic figure was profiled on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "rag4dyg_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(REPO, "include", "r4d.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def scan_q32(index, shape, k, device, reps=50):
+    """The north-star kernel on its own roofline: the (S+1)/2 cosine scan of the rank's RESIDENT pool shard at the
+    reference's query batch (32) + top-k, HIP-event timed per launch on the launch stream (r4d_profile hooks)."""
+    lib = _lib.load()
+    q = ops.normalize_rows(torch.randn(QB, shape.n_embd, generator=torch.Generator().manual_seed(5)).to(device))
+    for _ in range(5):
+        ops.score_topk(q, index.pool_hat, k, index.index_offset)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.score_topk(q, index.pool_hat, k, index.index_offset)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    lib.r4d_profile_enable(1)
+    for _ in range(reps):
+        ops.score_topk(q, index.pool_hat, k, index.index_offset)
+    torch.cuda.synchronize()
+    prof = read_profile()
+    lib.r4d_profile_enable(0)
+    sc, tk = prof["pool_scan"], prof.get("topk", {"ms": 0.0, "launches": 1})
+    gbs = sc["work"] / (sc["ms"] * 1e-3) / 1e9
+    return {"pool_rows": int(index.pool_hat.shape[0]), "d": shape.n_embd, "queries": QB, "topk": k,
+            "scan_kernel_us": round(1e3 * sc["ms"] / sc["launches"], 2), "topk_kernel_us": round(1e3 * tk["ms"] / sc["launches"], 2),
+            "host_loop_wall_us": round(wall * 1e6, 1), "algorithmic_bytes": sc["work"] / sc["launches"],
+            "roofline": {"kernel": "pool_scan", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4)}}
 
 
 def main():
@@ -107,17 +195,22 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="UCI_13", choices=sorted(synth.SHAPES))
-    ap.add_argument("--pool-per-gpu", type=int, default=12500)
+    ap.add_argument("--pool-total", type=int, default=100000,
+                    help="rows of the whole pool (north star: 100k); rank r holds the r-th batch-aligned shard")
+    ap.add_argument("--pool-per-gpu", type=int, default=0, help="override: fixed shard rows per rank (pool = N x this)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--batches-per-step", type=int, default=8,
                     help="reference query batches (32 sequences each, padded independently) handed to the library per step "
                          "as one fused launch sequence")
-    ap.add_argument("--query-batches", type=int, default=16, help="distinct synthetic query batches cycled over the steps")
+    ap.add_argument("--query-batches", type=int, default=256,
+                    help="distinct synthetic query batches cycled over the steps (256 x 32 = the 8192 queries of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-pool", action="store_true",
                     help="profiling aid: fill the resident pool shard with N(0,1) embeddings instead of encoding the "
                          "synthetic pool, so that a rocprofv3 trace holds the timed-step kernels only")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: skip the post-run check that the sharded top-k equals a one-GPU recomputation on rank 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,13 +235,24 @@ def main():
     model = build_model(shape, device)
     k = args.topk
 
-    # --- resident pool shard: rows [rank*P, (rank+1)*P) of the global pool, encoded with reference batching
-    P = args.pool_per_gpu
+    # --- resident pool shard: this rank's contiguous, batch-aligned run of the global pool, encoded with reference batching
+    if args.pool_per_gpu > 0:
+        P, p_off, pool_total = args.pool_per_gpu, rank * args.pool_per_gpu, args.pool_per_gpu * world
+    else:
+        from rag4dyg_amd.dist import shard_bounds
+        pool_total = args.pool_total
+        p_off, p_end = shard_bounds(pool_total, world)[rank]
+        P = p_end - p_off
     if args.random_pool:
         pool_emb = torch.randn(P, shape.n_embd, generator=torch.Generator().manual_seed(2026 + rank)).to(device)
         pool_encode_s = float("nan")
     else:
-        pool_seqs = synth.sequences(shape, P, "pool", seed=2026 + rank)
+        # every rank derives the SAME global pool (one seed) and keeps its own rows, so the sharded run scans exactly the
+        # pool the one-GPU run scans; with --pool-per-gpu each rank draws its own fixed-size shard instead
+        if args.pool_per_gpu > 0:
+            pool_seqs = synth.sequences(shape, P, "pool", seed=2026 + rank)
+        else:
+            pool_seqs = synth.sequences(shape, pool_total, "pool", seed=2026)[p_off:p_off + P]
         pool_batches = right_pad_batches(pool_seqs, QB, shape.pad_id, device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -156,7 +260,7 @@ def main():
         torch.cuda.synchronize()
         pool_encode_s = time.perf_counter() - t0
         del pool_batches
-    index = PoolIndex(pool_emb, index_offset=rank * P)
+    index = PoolIndex(pool_emb, index_offset=p_off)
 
     # --- query batches resident in HBM
     q_seqs = synth.sequences(shape, QB * args.query_batches, "query", seed=9000 + rank)
@@ -234,6 +338,7 @@ def main():
         out = tail[-1]
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,10 +367,11 @@ def main():
         v = prof[dom]
         traffic = None
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):              # PMC figure of a separate rocprofv3 pass: valid for the workload it profiled only
-            pmc = json.load(open(tf))
+        if os.path.exists(tf):              # PMC figure of a separate rocprofv3 pass: valid for the workload AND the sources
+            pmc = json.load(open(tf))       # it was profiled on only -- otherwise null
             meta = pmc.get("_workload", {})
-            if meta.get("shape") == args.shape and meta.get("batches_per_step") == G and meta.get("n_gpus", 1) == world:
+            if (meta.get("shape") == args.shape and meta.get("batches_per_step") == G and meta.get("n_gpus", 1) == world
+                    and meta.get("pool_rows_per_gpu") == P and meta.get("source_sha") == source_sha()):
                 traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
         if dom.startswith(("gemm", "attn")):
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12
@@ -280,6 +386,16 @@ def main():
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
                         "bytes_per_launch": v["work"] / v["launches"]}
 
+    # --- N > 1: correctness bit + load spread, outside the timed region (never allowed to lose the run)
+    verify = None
+    if world > 1 and not args.no_verify:
+        try:
+            verify = verify_sharded(world, rank, device, index, out, model, q_batches, args, G, k, gather, elapsed_local)
+        except Exception as e:                                       # noqa: BLE001
+            verify = {"error": f"{type(e).__name__}: {e}"}
+    scan = None
+    if rank == 0 and not args.no_roofline:
+        scan = scan_q32(index, shape, k, device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, shape, [s.tolist() for s in q_seqs], pool_emb, k)
@@ -300,15 +416,17 @@ def main():
                                    f"d{shape.n_embd} V{shape.vocab} random-init fp32; per rank and step {G} reference query batches of {QB} "
                                    f"(each padded to its own batch max, mean T={np.mean(Ts):.0f}; one fused launch sequence) "
                                    f"encode+mean-pool+normalise, cosine scan of a "
-                                   f"resident {P}-row pool shard, top-{k}; N>1: RCCL all-gather of embeddings and per-shard top-k",
+                                   f"resident {P}-row shard of the {pool_total}-row pool, top-{k}; N>1: RCCL all-gather of embeddings "
+                                   f"and per-shard top-k",
                        "query_batch": QB, "query_batches_per_step": G, "queries_per_step_per_gpu": QB * G,
-                       "pool_rows_per_gpu": P, "pool_rows_total": P * world, "topk": k,
+                       "distinct_query_batches": nqb, "pool_rows_per_gpu": P, "pool_rows_total": pool_total, "topk": k,
                        "parallelism": f"pool-shard x{world}",
                        "collectives": ("none" if world == 1 else
                                        "async, consumed one step later (3-stage pipeline)" if pipe is not None else "synchronous")},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "extras": {"encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
+            "extras": {"source_sha": source_sha(), "scan_q32": scan, "verify": verify,
+                       "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),
                        "kernels": kernels},
         }

@@ -487,6 +487,11 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert "lm_head" in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["value_without_lm_head"] >= d["cpu_baseline"]["value"]
+    sq = d["extras"]["scan_q32"]                                         # the north-star kernel on its own (HBM) roofline
+    assert sq["queries"] == 32 and sq["pool_rows"] == 2048 and sq["roofline"]["bound"] == "hbm" and 0 < sq["roofline"]["frac"] <= 1
+    assert d["roofline"]["traffic"] is None                              # PMC figure belongs to another workload / pool size
+    assert len(d["extras"]["source_sha"]) == 16 and d["config"]["pool_rows_total"] == 2048
     env2 = dict(env, R4D_BENCH_BACKEND="gloo", R4D_BENCH_PIPELINE="force")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", "29536", os.path.join(REPO, "bench.py"), "--gpus", "2",
@@ -495,5 +500,8 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                              # rank 0 only
     d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0 and d2["config"]["pool_rows_total"] == 4096
+    v = d2["extras"]["verify"]                                           # post-run check: sharded == one-GPU recomputation
+    assert v.get("error") is None and v["world_size"] == 2 and v["sharded_topk_equals_one_gpu"] is True, v
+    assert v["pool_rows_checked"] == 4096 and len(v["per_rank_ms_per_step"]) == 2
     assert "pipeline" in d2["config"]["collectives"] and "unavailable" not in p.stderr

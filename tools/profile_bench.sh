@@ -5,12 +5,15 @@
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
-ARGS="--steps 32 --warmup 16 --random-pool --no-cpu-baseline"
+export R4D_PROFILE_SHAPE=${R4D_PROFILE_SHAPE:-UCI_13}
+ARGS="--shape $R4D_PROFILE_SHAPE --steps 32 --warmup 16 --random-pool --no-cpu-baseline"
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT.bench.log 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- python3 $R/bench.py $ARGS --no-roofline > /dev/null 2>&1
+  echo "pmc pass $tag" >> $OUT/progress.log
+  timeout -k 5 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- python3 $R/bench.py $ARGS --no-roofline > /dev/null 2>&1 || echo "pmc pass $tag FAILED" >> $OUT/progress.log
 done
 python3 $R/tools/profile_summary.py $OUT $TAG

@@ -21,7 +21,8 @@ def short(name):
 stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --shape {os.environ.get('R4D_PROFILE_SHAPE', 'UCI_13')} "
+            "--steps 32 --warmup 16 --random-pool --no-cpu-baseline\n")
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in rows:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
@@ -72,10 +73,12 @@ def bench_class(k):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
         return "layernorm"
+    if k.startswith("pool_scan_ks_kernel"):
+        return "pool_scan"
     return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
             "lnf_partial_kernel<8>": "lnf_partial", "lnf_partial_kernel<16>": "lnf_partial", "lnf_partial_kernel<32>": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce", "gemm_skinny_kernel": "gemm_skinny",
             "gemm_skinny_epilogue_kernel": "gemm_skinny_epilogue", "decode_attn_kernel": "decode_attention",
-            "normalize_rows_kernel": "normalize_rows", "topk_seg_kernel<float>": "topk_seg",
+            "normalize_rows_kernel": "normalize_rows", "topk_chunk_kernel<float>": "topk",
             "merge_topk_kernel": "merge_topk", "jaccard_lds_kernel": "jaccard"}.get(k, k)
 
 
@@ -102,8 +105,12 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "a") as f:
     for c, (n, tot) in sorted(_class_rows().items(), key=lambda kv: -kv[1][1]):
         if not c.startswith(("at::", "__amd")):
             f.write(f"\"{c}\",{n},{tot:.0f},{tot / max(n, 1):.0f}\n")
-traffic["_workload"] = {"shape": "UCI_13", "batches_per_step": 8, "n_gpus": 1,
-                        "command": "bench.py --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
+sys.path.insert(0, repo)
+from bench import source_sha                                                   # noqa: E402
+shape = os.environ.get("R4D_PROFILE_SHAPE", "UCI_13")
+traffic["_workload"] = {"shape": shape, "batches_per_step": 8, "n_gpus": 1, "pool_rows_per_gpu": 100000,
+                        "source_sha": source_sha(),
+                        "command": f"bench.py --shape {shape} --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1)[:3000])
