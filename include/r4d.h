@@ -275,10 +275,16 @@ int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, 
 /* The same matrix with the A rows VISITED in the order a_order_d (int32 [na], a permutation of 0..na-1; NULL = file
  * order).  Results land in their own rows; only the schedule changes: a wavefront walks the tokens of four A rows
  * jointly, to the longest of the four, so visiting rows of similar length together (longest first) saves the padding
- * steps -- 1.7x fewer token steps on log-normal input-set lengths.  Values are identical for every order. */
+ * steps -- 1.7x fewer token steps on log-normal input-set lengths.  Values are identical for every order.
+ * DENSE TOKENS (a_dense_d / b_dense_d, both or neither; NULL = none): uint32 [na] / [nb], bit t of a set's word = "the
+ * set contains dense token t".  The caller picks up to 32 tokens (the frequent ones: the <|timeK|> tokens that
+ * get_input_seq keeps, retrieval_data_annotation.py:17-20) and REMOVES them from the CSR lists; the kernel adds
+ * popcount(a_dense & b_dense) to the intersection and the popcounts to the set sizes: the same integers as the plain
+ * CSR form, for two vector instructions per row and 64 pairs instead of 4.3 per token. */
 int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, int32_t a_nnz,
                             const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz,
-                            int32_t vocab, int32_t zero_diag, const int32_t* a_order_d, double* out_d, void* stream);
+                            int32_t vocab, int32_t zero_diag, const int32_t* a_order_d,
+                            const uint32_t* a_dense_d, const uint32_t* b_dense_d, double* out_d, void* stream);
 /* Per-row top-k (value descending, index ascending) of an f64 matrix: save_score_file_train,
  * retrieval_data_annotation.py:97-103 (topk=10).  ws from r4d_topk_f64_workspace_bytes. */
 size_t r4d_topk_f64_workspace_bytes(int32_t rows, int32_t n, int32_t k);

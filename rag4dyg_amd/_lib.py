@@ -79,7 +79,7 @@ PROTOTYPES = {
     "r4d_argsort_desc_f32": (c_int32, [_P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_argsort_desc_f64": (c_int32, [_P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_jaccard_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "r4d_jaccard_ordered_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "r4d_jaccard_ordered_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_profile_enable": (c_int32, [c_int32]),

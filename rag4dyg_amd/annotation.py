@@ -65,15 +65,25 @@ def occurrence_matrix(target_csr, source_csr, vocab, zero_diag=False):
     return ops.jaccard(target_csr[0], target_csr[1], source_csr[0], source_csr[1], vocab, zero_diag)
 
 
-def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CHUNK):
+def rank_row_range(n_rows, rank, world):
+    """Contiguous target rows [start, end) of ``rank``: rows of the target side are independent, so they
+    are dealt to the ranks in order -- the source-side CSR is replicated and there is no collective on the data path."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CHUNK, rows=None):
     """Yield (row0, f64 slab [rows, N]) so that an N x N matrix never has to exist at once.
 
     With ``zero_diag`` the slab is computed against the full source and the diagonal entries of the global
-    matrix (row0+i, row0+i) are zeroed on device.
+    matrix (row0+i, row0+i) are zeroed on device.  ``rows = (start, end)`` restricts the walk to that range of target rows
+    (one rank's share).
     """
     n = target_csr[0].numel() - 1
-    for r0 in range(0, n, chunk):
-        r1 = min(n, r0 + chunk)
+    lo, hi = (0, n) if rows is None else rows
+    for r0 in range(lo, hi, chunk):
+        r1 = min(hi, r0 + chunk)
         p, ix = _slice_csr(target_csr[0], target_csr[1], r0, r1)
         m = ops.jaccard(p, ix, source_csr[0], source_csr[1], vocab, False)
         if zero_diag:
@@ -82,10 +92,10 @@ def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CH
         yield r0, m
 
 
-def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_file):
+def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_file, rows=None):
     """``retrieval_data_annotation.py:88-93``: full ranking (canonical stable order) + every score, as text."""
     with open(save_index_file, 'w') as f, open(save_score_file, 'w') as g:
-        for _r0, m in iter_row_chunks(target_csr, source_csr, vocab):
+        for _r0, m in iter_row_chunks(target_csr, source_csr, vocab, rows=rows):
             indices = ops.argsort_desc(m).cpu().numpy()
             mh = m.cpu().numpy()
             for i in range(mh.shape[0]):
@@ -93,10 +103,10 @@ def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_
                 g.write(' '.join([str(x) for x in mh[i]]) + '\n')
 
 
-def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk=10):
+def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk=10, rows=None):
     """``retrieval_data_annotation.py:97-103``: top-10 GT demonstrations of train x train (diag zeroed)."""
     with open(save_file_index, 'w') as f_index, open(save_file_score, 'w') as f_score:
-        for _r0, m in iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True):
+        for _r0, m in iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True, rows=rows):
             vals, idx = ops.topk_f64(m, min(topk, m.shape[1]))
             vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
             for i in range(idx.shape[0]):
@@ -104,12 +114,12 @@ def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk
                 f_score.write(' '.join(map(str, vals[i])) + '\n')
 
 
-def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False):
+def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False, rows=None):
     """Per anchor row: (i, positives, negative candidates, out-score row) following
     ``retrieval_data_annotation.py:52-74``; candidate order = canonical stable ranking of the input-set
     similarities (the reference's order is tie-dependent)."""
-    gen_in = iter_row_chunks(in_csr, in_csr, vocab, zero_diag=True)
-    for (r0, m_out), (_r0b, m_in) in zip(iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True), gen_in):
+    gen_in = iter_row_chunks(in_csr, in_csr, vocab, zero_diag=True, rows=rows)
+    for (r0, m_out), (_r0b, m_in) in zip(iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True, rows=rows), gen_in):
         has_pos = (m_out > threshold).any(dim=1)
         rows = torch.nonzero(has_pos).flatten()
         if rows.numel() == 0:
@@ -137,19 +147,25 @@ def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dial
             yield r0 + i_local, pos, negs, row
 
 
-def save_train_annotation(out_csr, in_csr, vocab, save_file, save_file_score, threshold=0.8, neg_num=5, dataset=""):
-    """``retrieval_data_annotation.py:43-85``: ``i pos neg`` triples; the negative is ``np.random.choice`` of the
-    candidates exactly as upstream (unseeded there, so column 3 is not reproducible by design)."""
+def save_train_annotation(out_csr, in_csr, vocab, save_file, save_file_score, threshold=0.8, neg_num=5, dataset="",
+                          rows=None, choice_seed=None):
+    """``retrieval_data_annotation.py:43-85``: ``i pos neg`` triples; the negative is a uniform random pick among the
+    candidates as upstream (``np.random.choice``, :79 -- unseeded there, so column 3 is not reproducible by design).  The
+    picks of anchor row i come from a generator seeded with ``choice_seed + i`` (``choice_seed`` itself is drawn from
+    numpy's global state, so ``np.random.seed`` still governs a run): a row's picks do not depend on which rows were
+    processed before it, which is what lets the rows be dealt to several ranks and still give the one-rank file."""
+    if choice_seed is None:
+        choice_seed = int(np.random.randint(0, 2 ** 31 - 1))
     cnt, n = 0, out_csr[0].numel() - 1
     with open(save_file, 'w') as f, open(save_file_score, 'w') as g:
-        for i, pos, negs, row in train_annotation_rows(out_csr, in_csr, vocab, threshold, neg_num, 'dialog' in dataset):
+        for i, pos, negs, row in train_annotation_rows(out_csr, in_csr, vocab, threshold, neg_num, 'dialog' in dataset, rows):
+            pick = np.random.RandomState((choice_seed + i) % (2 ** 32))
             for pos_ind in pos:
-                neg_i = np.random.choice(negs)
+                neg_i = pick.choice(negs)
                 f.write(f"{i} {pos_ind} {neg_i}\n")
                 g.write(f"{i} {row[pos_ind]} {row[neg_i]}\n")
                 cnt += 1
-    print("Number of original instances:", n)
-    print('Number of positive samples:', cnt)
+    return n, cnt
 
 
 def read_lines(path):
@@ -157,13 +173,39 @@ def read_lines(path):
         return [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
 
 
+def _join_parts(path, world):
+    """Concatenate ``path.part<r>`` (r = 0..world-1, in rank order = row order) into ``path`` and remove the parts."""
+    with open(path, 'wb') as out:
+        for r in range(world):
+            with open(f"{path}.part{r}", 'rb') as f:
+                while True:
+                    buf = f.read(1 << 24)
+                    if not buf:
+                        break
+                    out.write(buf)
+            os.remove(f"{path}.part{r}")
+
+
 def main(argv):
-    """``python retrieval_data_annotation.py <dataset> <timestamp> <threshold>`` (``:109-200``), cwd-relative paths."""
+    """``python retrieval_data_annotation.py <dataset> <timestamp> <threshold>`` (``:109-200``), cwd-relative paths.
+
+    One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, e.g. by ``python -m torch.distributed.run``): the
+    TARGET rows of each of the four matrices (``:166-169``) are dealt to the ranks in contiguous ranges, every rank holds
+    the whole source-side CSR and writes its rows to ``<file>.part<rank>``; rank 0 concatenates the parts in rank order.
+    No collective on the data path -- the process group (gloo) only carries one seed broadcast and the barrier before
+    the concatenation; the files equal the one-process run byte for byte."""
     dataset, timestamp = argv[1], argv[2]
     threshold = float(argv[3])
     if not torch.cuda.is_available():
         raise SystemExit("retrieval_data_annotation: needs the MI355X (no CPU fallback in rag4dyg_amd)")
-    device = torch.device("cuda")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as tdist
+    if world > 1 and not tdist.is_initialized():
+        tdist.init_process_group(backend="gloo")
     save_path = os.path.join('./resources/', dataset, str(timestamp), 'train_retrieval')
     os.makedirs(save_path, exist_ok=True)
     save_path_gen = os.path.join('./resources/train_generator', dataset, str(timestamp), "train_gt_topk")
@@ -183,13 +225,30 @@ def main(argv):
     te_out = table.pack(test_out, device)
     va_out = table.pack(val_out, device)
     vocab = len(table.vocab)
-    save_train_annotation(tr_out, tr_in, vocab, os.path.join(save_path, 'train_index.retrieval'),
-                          os.path.join(save_path, 'train_score.retrieval'), threshold=threshold, neg_num=5,
-                          dataset=dataset)
-    save_index_score(te_out, tr_out, vocab, os.path.join(save_path, 'test_index.retrieval'),
-                     os.path.join(save_path, 'test_score.retrieval'))
-    save_index_score(va_out, tr_out, vocab, os.path.join(save_path, 'val_index.retrieval'),
-                     os.path.join(save_path, 'val_score.retrieval'))
-    save_score_file_train(tr_out, vocab, os.path.join(save_path_gen, 'train_index.gen'),
-                          os.path.join(save_path_gen, 'train_score.gen'), topk=10)
-    print("Done!")
+    seed = [int(np.random.randint(0, 2 ** 31 - 1))]
+    if world > 1:
+        tdist.broadcast_object_list(seed, src=0)                     # one seed for the random negative picks of every rank
+    part = (lambda p: f"{p}.part{rank}") if world > 1 else (lambda p: p)
+    rng_tr = rank_row_range(len(train_out), rank, world) if world > 1 else None
+    files = {k: os.path.join(save_path, k) for k in ('train_index.retrieval', 'train_score.retrieval', 'test_index.retrieval',
+                                                      'test_score.retrieval', 'val_index.retrieval', 'val_score.retrieval')}
+    files.update({k: os.path.join(save_path_gen, k) for k in ('train_index.gen', 'train_score.gen')})
+    n, cnt = save_train_annotation(tr_out, tr_in, vocab, part(files['train_index.retrieval']), part(files['train_score.retrieval']),
+                                   threshold=threshold, neg_num=5, dataset=dataset, rows=rng_tr, choice_seed=seed[0])
+    save_index_score(te_out, tr_out, vocab, part(files['test_index.retrieval']), part(files['test_score.retrieval']),
+                     rows=rank_row_range(len(test_out), rank, world) if world > 1 else None)
+    save_index_score(va_out, tr_out, vocab, part(files['val_index.retrieval']), part(files['val_score.retrieval']),
+                     rows=rank_row_range(len(val_out), rank, world) if world > 1 else None)
+    save_score_file_train(tr_out, vocab, part(files['train_index.gen']), part(files['train_score.gen']), topk=10, rows=rng_tr)
+    if world > 1:
+        counts = [None] * world
+        tdist.all_gather_object(counts, cnt)                         # also the barrier: every part file is closed
+        cnt = sum(counts)
+        if rank == 0:
+            for p in files.values():
+                _join_parts(p, world)
+        tdist.barrier()
+    if rank == 0:
+        print("Number of original instances:", n)
+        print('Number of positive samples:', cnt)
+        print("Done!")

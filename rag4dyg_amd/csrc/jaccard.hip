@@ -10,6 +10,11 @@
 // a time: its tokens are wave-uniform, every token is ONE broadcast LDS read of mask[token], and lane j
 // adds bit j -- the popcount of the intersection accumulates across the wave's 64 pairs at 2 VALU ops per
 // token.  |A|B| = |A| + |B| - |A&B|; the f64 division is correctly rounded == python's int/int.
+// DENSE TOKENS.  The input sets of the annotation pass (get_input_seq, retrieval_data_annotation.py:17-20) keep their
+// <|timeK|> tokens, so a dozen tokens occur in most sets and dominate the token walk (14 tokens per set on hepth, 5 of them
+// sparse).  The host may therefore move up to 32 tokens of its choice out of the CSR lists into one 32-bit membership word
+// per set (a_dense / b_dense): their share of |A & B| is popcount(a_dense & b_dense) -- two vector instructions per row
+// and 64 pairs instead of 4.3 per token -- and the walk only visits the sparse remainder.  Same integers, same quotient.
 // (Measured and dropped: tables in GLOBAL memory so that tokens and masks come through scalar loads and a token costs one
 // v_addc_co_u32 with the mask as carry-in -- correct, but 2x SLOWER: random 8-byte lookups in a 95 KB table miss the scalar
 // cache and the dependent s_load chains (token -> mask) are latency-bound.)
@@ -31,6 +36,11 @@ constexpr int JAC_RCP = 512;                       // reciprocal table entries (
 //   r correctly rounded, b's significand not all ones).  tests/test_host_cpu.py proves q1 == a/b for every
 //   1 <= a <= b < 512 with exact rational arithmetic, tests/test_gpu_ops.py checks the kernel on sets that produce
 //   every such (a, b).  Unions >= 512 take the IEEE division (wave-uniform branch).
+// Tried and dropped (MI355X, round 2): a 64 x 64 LDS table of the quotients a / b themselves (one address + one ds_read_b64
+// per pair instead of the reciprocal sequence): hepth input sets 71 -> 82 us, output sets 39 -> 48 us (the 4096 true
+// divisions per workgroup and the 32 KB of LDS cost more than the lookup saves), synthetic 20k x 20k unchanged.  NOTE on
+// ablations of this kernel: JAC_DBG bit 1 ("no division") also lets the compiler delete the token walk, whose only use is
+// the quotient -- bit 0 (walk skipped, division kept) is the meaningful one: hepth input sets 71 -> 38 us, store-only 26 us.
 __device__ __forceinline__ double small_int_div(int a, int b, const double* __restrict__ rcp) {
     const double af = (double)a, bf = (double)b, r = rcp[b];
     const double q0 = af * r;
@@ -43,7 +53,9 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
                                                           const int32_t* __restrict__ b_ptr,
                                                           const int32_t* __restrict__ b_idx, int nb, int vocab,
                                                           int zero_diag, int rows_per_block,
-                                                          const int32_t* __restrict__ a_order, double* __restrict__ out) {
+                                                          const int32_t* __restrict__ a_order,
+                                                          const uint32_t* __restrict__ a_dense,
+                                                          const uint32_t* __restrict__ b_dense, double* __restrict__ out) {
     extern __shared__ unsigned long long mask[];    // [vocab + 1]
     // the wavefront index is made PROVABLY wave-uniform: everything per A row (CSR pointers, loop control, the row's
     // output base address) then lives in scalar registers / scalar loads instead of vector instructions
@@ -66,7 +78,8 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
     }
     __syncthreads();
     const int col = col0 + lane;
-    const int lb = (col < nb) ? (b_ptr[col + 1] - b_ptr[col]) : 0;
+    const uint32_t bd = (b_dense && col < nb) ? b_dense[col] : 0u;         // this column's dense-token word
+    const int lb = (col < nb) ? (b_ptr[col + 1] - b_ptr[col]) + __builtin_popcount(bd) : 0;
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(na, row_begin + rows_per_block);
     // R = 4 independent A rows per wavefront iteration (rows i, i+nwaves, ..., i+3*nwaves).  With the big table only
@@ -112,13 +125,15 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
             const int t = a_idx[min(sB[r] + lane, nz1)];
             tokB[r] = (sB[r] + lane < eB[r]) ? t : -1;
         }
-        int la[R], cnt[R];
+        int la[R], lw[R], cnt[R];                       // |A| (dense tokens included), tokens to walk, |A & B|
         int mmax = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            la[r] = eA[r] - sA[r];
-            cnt[r] = 0;
-            mmax = max(mmax, min(la[r], 64));
+            const uint32_t ad = a_dense ? a_dense[rowA[r]] : 0u;         // wave-uniform (scalar load)
+            lw[r] = eA[r] - sA[r];
+            la[r] = lw[r] + __builtin_popcount(ad);
+            cnt[r] = __builtin_popcount(ad & bd);
+            mmax = max(mmax, min(lw[r], 64));
         }
         if (JAC_DBG & 1) mmax = 0;
         // joint walk over the first 64 tokens of the four rows: four independent broadcast LDS reads per step
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(1024) void jaccard_lds_kernel(const int32_t* __rest
         // rows longer than 64 tokens (rare): the remaining chunks, one row at a time
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if ((JAC_DBG & 1) || la[r] <= 64) continue;
+            if ((JAC_DBG & 1) || lw[r] <= 64) continue;
             for (int p0 = sA[r] + 64; p0 < eA[r]; p0 += 64) {
                 int mytok = a_idx[min(p0 + lane, nz1)];
                 mytok = (p0 + lane < eA[r]) ? mytok : -1;
@@ -202,13 +217,15 @@ __global__ __launch_bounds__(256) void jaccard_merge_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ a_idx, int na,
                                                             const int32_t* __restrict__ b_ptr,
                                                             const int32_t* __restrict__ b_idx, int nb, int zero_diag,
-                                                            double* __restrict__ out) {
+                                                            const uint32_t* __restrict__ a_dense,
+                                                            const uint32_t* __restrict__ b_dense, double* __restrict__ out) {
     const int col_blocks = (nb + 255) / 256;
     const int col = (blockIdx.x % col_blocks) * 256 + threadIdx.x, i = blockIdx.x / col_blocks;
     if (col >= nb) return;
     int p = a_ptr[i], pe = a_ptr[i + 1], q = b_ptr[col], qe = b_ptr[col + 1];
-    const int la = pe - p, lb = qe - q;
-    int cnt = 0;
+    const uint32_t ad = a_dense ? a_dense[i] : 0u, bd = b_dense ? b_dense[col] : 0u;
+    const int la = pe - p + __builtin_popcount(ad), lb = qe - q + __builtin_popcount(bd);
+    int cnt = __builtin_popcount(ad & bd);
     while (p < pe && q < qe) {
         const int x = a_idx[p], y = b_idx[q];
         cnt += (x == y);
@@ -227,12 +244,13 @@ using namespace r4d;
 
 extern "C" int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, int32_t a_nnz,
                                        const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz,
-                                       int32_t vocab, int32_t zero_diag, const int32_t* a_order_d, double* out_d,
-                                       void* stream) {
+                                       int32_t vocab, int32_t zero_diag, const int32_t* a_order_d,
+                                       const uint32_t* a_dense_d, const uint32_t* b_dense_d, double* out_d, void* stream) {
     R4D_REQUIRE(a_ptr_d && b_ptr_d && a_idx_d && b_idx_d && out_d, "jaccard: null pointer");
     R4D_REQUIRE(a_nnz >= 0 && b_nnz >= 0, "jaccard: negative nnz");
     if (a_nnz < 1) a_nnz = 1;                       // idx buffers hold >= 1 element by contract
     R4D_REQUIRE(na >= 0 && nb >= 0 && vocab >= 1, "jaccard: bad sizes na=%d nb=%d vocab=%d", na, nb, vocab);
+    R4D_REQUIRE((a_dense_d != nullptr) == (b_dense_d != nullptr), "jaccard: a_dense_d and b_dense_d go together");
     if (na == 0 || nb == 0) return R4D_OK;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic bytes (SURVEY 8d B_jac): the f64 matrix out + both CSR inputs read once
@@ -258,11 +276,11 @@ extern "C" int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_
         // a big table leaves room for one workgroup per CU only: give it 16 wavefronts instead of 4
         const int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
         hipLaunchKernelGGL(jaccard_lds_kernel, dim3(col_tiles, chunks), dim3(threads), lds, s, a_ptr_d, a_idx_d, na, a_nnz,
-                           b_ptr_d, b_idx_d, nb, vocab, zero_diag, rows_per_block, a_order_d, out_d);
+                           b_ptr_d, b_idx_d, nb, vocab, zero_diag, rows_per_block, a_order_d, a_dense_d, b_dense_d, out_d);
         R4D_CHECK_LAUNCH("jaccard_lds");
     } else {
         hipLaunchKernelGGL(jaccard_merge_kernel, dim3((unsigned)((long long)cdiv(nb, 256) * na)), dim3(256), 0, s, a_ptr_d, a_idx_d, na, b_ptr_d,
-                           b_idx_d, nb, zero_diag, out_d);
+                           b_idx_d, nb, zero_diag, a_dense_d, b_dense_d, out_d);
         R4D_CHECK_LAUNCH("jaccard_merge");
     }
     return R4D_OK;
@@ -271,8 +289,8 @@ extern "C" int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_
 extern "C" int r4d_jaccard_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, int32_t a_nnz,
                                const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz, int32_t vocab,
                                int32_t zero_diag, double* out_d, void* stream) {
-    return r4d_jaccard_ordered_f64(a_ptr_d, a_idx_d, na, a_nnz, b_ptr_d, b_idx_d, nb, b_nnz, vocab, zero_diag, nullptr, out_d,
-                                   stream);
+    return r4d_jaccard_ordered_f64(a_ptr_d, a_idx_d, na, a_nnz, b_ptr_d, b_idx_d, nb, b_nnz, vocab, zero_diag, nullptr, nullptr,
+                                   nullptr, out_d, stream);
 }
 
 namespace r4d { int dbgflag_jac() { return JAC_DBG != 0; } }

@@ -559,11 +559,30 @@ def test_jaccard_edge_cases_and_merge_fallback(dev):
         _, _, refd = jaccard_ref.jaccard_csr(ap, ai, ap, ai, zero_diag=True)
         outd = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(ap, dev), cu(ai, dev), vocab, zero_diag=True).cpu().numpy()
         assert np.array_equal(outd, refd)
-        # the row VISITING order (longest set first by default) changes the schedule, never a value
+        # the row VISITING order (longest set first by default) and the dense-token split (the 32 most frequent tokens as
+        # one membership word per set) change the schedule, never a value
         for zd in (False, True):
             for sr in (False, True):
-                got = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(ap, dev), cu(ai, dev), vocab, zero_diag=zd, sort_rows=sr)
-                assert np.array_equal(got.cpu().numpy(), refd if zd else jaccard_ref.jaccard_csr(ap, ai, ap, ai)[2])
+                for dn in (False, True):
+                    got = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(ap, dev), cu(ai, dev), vocab, zero_diag=zd, sort_rows=sr,
+                                      dense_split=dn)
+                    assert np.array_equal(got.cpu().numpy(), refd if zd else jaccard_ref.jaccard_csr(ap, ai, ap, ai)[2])
+        got = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(bp, dev), cu(bi, dev), vocab, dense_split=True).cpu().numpy()
+        assert np.array_equal(got, ref)
+    # input-set shaped: a dozen tokens shared by most sets (<|timeK|>), a few sparse ones, sets that are ALL dense / empty
+    vocab, n = 400, 300
+    sets = [sorted(set(rng.choice(12, rng.integers(0, 13), replace=False).tolist() + rng.integers(12, vocab, rng.integers(0, 7)).tolist()))
+            for _ in range(n)]
+    sets[3] = list(range(12)); sets[4] = []; sets[5] = list(range(40))
+    ptr = np.zeros(n + 1, np.int32); ptr[1:] = np.cumsum([len(s_) for s_ in sets])
+    idx = np.asarray([x for s_ in sets for x in s_], np.int32)
+    _, _, ref = jaccard_ref.jaccard_csr(ptr, idx, ptr, idx, zero_diag=True)
+    for dn in (False, True):
+        got = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), vocab, zero_diag=True, dense_split=dn, sort_rows=dn)
+        assert np.array_equal(got.cpu().numpy(), ref), dn
+    (ap2, ai2, ad), _ = ops.dense_token_split(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), vocab)
+    words = ad.cpu().numpy().view(np.uint32)
+    assert all(bin(int(w)).count("1") + int(ap2[i + 1] - ap2[i]) == len(sets[i]) for i, w in enumerate(words))   # nothing lost
 
 
 def test_jaccard_every_small_quotient_is_correctly_rounded(dev):
@@ -575,7 +594,9 @@ def test_jaccard_every_small_quotient_is_correctly_rounded(dev):
     lens = np.arange(0, n + 1, dtype=np.int32)                        # set i has i tokens (set 0 is empty)
     ptr = np.zeros(n + 2, np.int32); ptr[1:] = np.cumsum(lens)
     idx = np.concatenate([np.arange(l, dtype=np.int32) for l in lens])
-    out = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), n + 1).cpu().numpy()
+    out = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), n + 1, dense_split=False).cpu().numpy()
+    out_dense = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), n + 1, dense_split=True).cpu().numpy()
+    assert np.array_equal(out.view(np.uint64), out_dense.view(np.uint64))        # tokens 0..31 as membership words: same bits
     i, j = np.meshgrid(lens.astype(np.float64), lens.astype(np.float64), indexing="ij")
     with np.errstate(divide="ignore", invalid="ignore"):
         ref = np.where(np.maximum(i, j) > 0, np.minimum(i, j) / np.maximum(i, j), 0.0)

@@ -135,6 +135,41 @@ def test_annotation_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch):
     assert all(s[1] == m_out[int(t_[0]), t_[1]] and s[2] == m_out[int(t_[0]), t_[2]] for s, t_ in zip(sc, triples))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_annotation_cli_rows_sharded_over_ranks_equal_one_process_byte_for_byte(dev, tmp_path, world):
+    """the target rows of the four Jaccard matrices are dealt to the ranks (one process per GPU; all on
+    cuda:0 here), the source CSR is replicated, rank 0 concatenates the row-range files: every output file equals the
+    one-process run byte for byte (random negative picks included: they are seeded per anchor row)."""
+    import hashlib
+    import shutil
+    one, many = tmp_path / "one", tmp_path / "many"
+    _write_dataset(str(one), n_train=157, n_val=41, n_test=37, seed=11)
+    shutil.copytree(one, many)
+    cli = os.path.join(REPO, "retrieval_data_annotation.py")
+    code = f"import sys, numpy as np; sys.path.insert(0, {REPO!r}); np.random.seed(5); sys.argv = ['x', 'toy', '4', '0.5']; " \
+           f"from rag4dyg_amd.annotation import main; main(sys.argv)"
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-c", code], cwd=one, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=many, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(29560 + world))) for r in range(world)]
+    done = [pr.communicate(timeout=600) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [e[-1500:] for _, e in done]
+    assert "Number of positive samples" in done[0][0] and p.stdout.splitlines()[-3:] == done[0][0].splitlines()[-3:]
+    names = []
+    for root, _dirs, fs in os.walk(one / "resources"):
+        for f in fs:
+            if f.endswith((".retrieval", ".gen")):
+                names.append(os.path.relpath(os.path.join(root, f), one))
+    assert len(names) == 8, names
+    for rel in names:
+        a, b = (one / rel).read_bytes(), (many / rel).read_bytes()
+        assert len(a) > 0 and hashlib.sha256(a).digest() == hashlib.sha256(b).digest(), rel
+    assert not [f for _r, _d, fs in os.walk(many) for f in fs if ".part" in f]          # parts removed after the join
+    assert os.path.exists(cli)
+
+
 def test_main_retriever_cli_end_to_end_against_oracle(dev, tmp_path, monkeypatch):
     import main_retriever
     from oracle import gpt2_ref, jaccard_ref, retrieval_ref

@@ -550,3 +550,19 @@ def test_text_index_score_dataset_matches_reference_class(tmp_path):
     assert np.array_equal(it[2].numpy(), g["tis_item3_score"]) and int(it[3]) == int(g["tis_item3_ego"])
     assert ds.get_item_by_egoId(int(ds.egolist[5])).tolist() == g["tis_ego_lookup"].tolist()
     assert ds.get_item_by_egoId(10 ** 9) is None
+
+
+def test_annotation_rank_row_ranges_cover_in_order_and_parts_join(tmp_path):
+    """Host side of the sharded Jaccard annotation: contiguous, ordered, exhaustive row ranges; part files joined in rank order."""
+    from rag4dyg_amd.annotation import _join_parts, rank_row_range
+    for n, world in ((0, 2), (1, 3), (37, 2), (3965, 8), (100000, 8), (5, 8)):
+        spans = [rank_row_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    target = tmp_path / "x.retrieval"
+    for r in range(3):
+        (tmp_path / f"x.retrieval.part{r}").write_text("".join(f"{r} {i}\n" for i in range(r + 1)))
+    _join_parts(str(target), 3)
+    assert target.read_text() == "0 0\n1 0\n1 1\n2 0\n2 1\n2 2\n"
+    assert not list(tmp_path.glob("*.part*"))
