@@ -81,8 +81,10 @@ def main(argv=None):
     model = model.to(args.device)
 
     if args.do_train:
-        raise NotImplementedError("retriever training (backward pass) is outside the encode-and-retrieve hot path; "
-                                  "train with the reference, evaluate / retrieve here")
+        raise NotImplementedError("retriever training: the forward half of a step (data, augmentation, five encoder forwards, "
+                                  "time-decayed contrastive + InfoNCE loss: rag4dyg_amd.training.training_step_forward) is built "
+                                  "and pinned against the reference; the backward kernels and the optimizer are not yet "
+                                  "(SURVEY.md 8f-4) -- train with the reference, evaluate / retrieve here")
     if args.do_eval and args.local_rank in [-1, 0]:
         checkpoints = [args.output_dir]
         if args.eval_all_checkpoints:

@@ -505,9 +505,102 @@ def g7_generator():
     _save("g7_generator", **out)
 
 
+# --------------------------------------------------------------------------- G8
+def g8_training_step():
+    """Retriever training step, forward + loss + gradients, from the reference's own code on CPU:
+    ``CLtime_loss`` / ``info_nce`` / ``mask_correlated_samples`` (train/train_retriever.py:40-98), ``_aug``
+    (models/modeling_rag.py:774-840, python ``random`` seeded), ``PairSequenceDataset`` (dataloader/retriever.py:68-111), and
+    one whole step of ``train_epoch`` (:177-196) with autograd -- dropout probabilities set to 0 (the reference trains with
+    p = 0.1, whose masks are not reproducible across devices)."""
+    print("G8 retriever training step")
+    import random
+    from models import GPT2Config
+    import models.modeling_rag as mr
+    _import_utils_model()
+    import train.train_retriever as tr
+    import dataloader.retriever as dr
+    out = {}
+
+    # ---- (a) the two losses on seeded embeddings / times
+    g = torch.Generator().manual_seed(21)
+    for tag, B, d in (("l4", 4, 16), ("l32", 32, 64)):
+        a, p_, n_ = (torch.randn(B, d, generator=g) for _ in range(3))
+        ta, tp, tn = (torch.rand(B, 1, generator=g) * 30 for _ in range(3))
+        args = types.SimpleNamespace(temperature=0.07, lambda_decay=0.05, per_gpu_train_batch_size=B)
+        out[tag + "_emb"] = torch.stack([a, p_, n_]).numpy(); out[tag + "_time"] = torch.stack([ta, tp, tn]).numpy()
+        out[tag + "_cltime"] = np.array(tr.CLtime_loss(args, a, p_, n_, ta, tp, tn).item())
+        z1 = torch.nn.functional.normalize(a, dim=1); z2 = torch.nn.functional.normalize(p_, dim=1)
+        mask = tr.mask_correlated_samples(B)
+        out[tag + "_mask"] = mask.numpy()
+        out[tag + "_infonce"] = np.array(tr.info_nce(args, z1, z2, 0.07, B, mask).item())
+        out[tag + "_infonce_raw"] = np.array(tr.info_nce(args, a, p_, 0.07, B, mask).item())
+        args.per_gpu_train_batch_size = B + 1                      # last partial batch: the mask is rebuilt (:92-93)
+        out[tag + "_infonce_rebuilt"] = np.array(tr.info_nce(args, a, p_, 0.07, B, None).item())
+
+    # ---- (b) one training step at a tiny and at the cfg2 (UCI retriever) shape
+    def step(tag, L, H, d, V, pad, B, lens, seed, eta, gamma, alpha):
+        cfg = GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H,
+                         resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+        cfg.eta, cfg.gamma, cfg.beta = eta, gamma, 0.0
+        model = mr.GPT2LMHeadModel(cfg)
+        sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected
+        model.train()
+        rng = np.random.default_rng(seed)
+
+        def batch():
+            rows = [rng.integers(1, V - 2, int(n)).tolist() for n in rng.choice(lens, B)]
+            T = max(len(r) for r in rows)
+            return torch.tensor([r + [pad] * (T - len(r)) for r in rows], dtype=torch.long)
+        anchor, pos, neg = batch(), batch(), batch()
+        n_pool = 50
+        all_t = torch.tensor(rng.random(n_pool) * 40, dtype=torch.float)
+        ai, pi, ni = (torch.tensor(rng.integers(0, n_pool, (B, 1)), dtype=torch.long) for _ in range(3))
+        args = types.SimpleNamespace(temperature=0.07, lambda_decay=0.05, per_gpu_train_batch_size=B, alpha=alpha)
+        _, h_ego = model(input_ids=anchor); _, h_pos = model(input_ids=pos); _, h_neg = model(input_ids=neg)
+        h_egos, h_i, h_j = h_ego.mean(1), h_pos.mean(1), h_neg.mean(1)
+        cl = tr.CLtime_loss(args, h_egos, h_i, h_j, all_t[ai], all_t[pi], all_t[ni])
+        random.seed(seed)
+        aug1, aug2 = model._aug(anchor)
+        _, s1 = model(input_ids=aug1); _, s2 = model(input_ids=aug2)
+        aug = args.alpha * tr.info_nce(args, s1.mean(1), s2.mean(1), args.temperature, aug1.size(0), tr.mask_correlated_samples(B))
+        loss = cl + aug
+        loss.backward()
+        names = [n for n, p_ in model.named_parameters() if p_.grad is not None]
+        gn = np.array([model.get_parameter(n).grad.double().norm().item() for n in names])
+        out.update({tag + "_cfg": np.array([L, H, d, V, pad, B, seed]), tag + "_hyper": np.array([eta, gamma, alpha, 0.07, 0.05]),
+                    tag + "_anchor": anchor.numpy(), tag + "_pos": pos.numpy(), tag + "_neg": neg.numpy(),
+                    tag + "_times": all_t.numpy(), tag + "_idx": torch.cat([ai, pi, ni], 1).numpy(),
+                    tag + "_aug1": aug1.numpy(), tag + "_aug2": aug2.numpy(),
+                    tag + "_emb": torch.stack([h_egos, h_i, h_j, s1.mean(1), s2.mean(1)]).detach().numpy(),
+                    tag + "_losses": np.array([cl.item(), aug.item(), loss.item()]),
+                    tag + "_grad_names": np.array(names), tag + "_grad_norms": gn,
+                    tag + "_grad_lnf_w": model.transformer.ln_f.weight.grad.numpy().copy(),
+                    tag + "_grad_cattn_b0": model.transformer.h[0].attn.c_attn.bias.grad.numpy().copy(),
+                    tag + "_grad_wte_rows": model.transformer.wte.weight.grad[:8].numpy().copy()})
+
+    step("ts_tiny", 2, 2, 64, 80, 78, 4, [9, 12, 17, 23], 410, 0.2, 0.5, 0.1)
+    step("ts_cfg2", 4, 2, 512, 1801, 1799, 8, [12, 20, 37, 60], 420, 0.2, 0.5, 0.1)
+
+    # ---- (c) PairSequenceDataset on the shipped UCI_13 train file + a small triples file
+    tok = _ref_tokenizer("UCI_13", 12)
+    rng = np.random.default_rng(3)
+    triples = rng.integers(0, 1708, (10, 3))
+    with open("g8_pairs.txt", "w") as f:
+        f.write("\n".join(" ".join(map(str, r)) for r in triples.tolist()) + "\n")
+    ds = dr.PairSequenceDataset(tok, types.SimpleNamespace(train_data_file="resources/UCI_13/12/train.link_prediction"),
+                                "g8_pairs.txt", block_size=512)
+    af, ao = _ragged(ds.anchor); pf, po = _ragged(ds.positive); nf, no = _ragged(ds.negative)
+    item = ds[2]
+    out.update(pair_triples=triples, pair_anchor_flat=af, pair_anchor_off=ao, pair_pos_flat=pf, pair_pos_off=po,
+               pair_neg_flat=nf, pair_neg_off=no, pair_item2_anchor=item[0].numpy(), pair_item2_idx=np.array([int(item[3]), int(item[4]), int(item[5])]))
+    _save("g8_training_step", **out)
+
+
 def main():
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
-              "g6b": g6_more_tokenizers, "g7": g7_generator}
+              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

@@ -1,0 +1,107 @@
+"""torch-CPU restatement of ONE retriever training step (oracle; test infra only) -- SURVEY.md section 8f-4.
+
+Follows ``train/train_retriever.py:40-98`` (``CLtime_loss``, ``mask_correlated_samples``, ``info_nce``), ``:177-196`` (the five
+forwards and the loss of ``train_epoch``) and ``models/modeling_rag.py:774-840`` (``_aug``).  Pinned by
+``tests/golden/g8_training_step.npz`` (the reference's own functions and autograd, run by ``oracle/gen_golden.py g8``).
+Dropout is the identity here (the fixtures were generated with all dropout probabilities 0: the reference's p = 0.1 masks
+come from the device RNG and cannot be reproduced on another device).
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import gpt2_ref
+
+
+def cltime_loss(temperature, decay_rate, anchors, positives, hard_negatives, anchors_time, positives_time, negatives_time):
+    """``CLtime_loss`` -- ``train/train_retriever.py:40-72``: cosine similarities of [anchors; positives; hard negatives],
+    each block scaled by exp(-lambda |t_anchor - t_other|) (in-batch anchors: diagonal zeroed), one cross entropy with the
+    positive of the same row as the label."""
+    B = anchors.size(0)
+    allv = torch.cat([anchors, positives, hard_negatives], dim=0)
+    sim = F.cosine_similarity(allv.unsqueeze(1), allv.unsqueeze(0), dim=2)
+    d_pos = torch.exp(-decay_rate * torch.abs(anchors_time.unsqueeze(1) - positives_time).squeeze())
+    d_neg = torch.exp(-decay_rate * torch.abs(anchors_time.unsqueeze(1) - anchors_time).squeeze())
+    d_neg.fill_diagonal_(0)
+    d_hard = torch.exp(-decay_rate * torch.abs(anchors_time.unsqueeze(1) - negatives_time).squeeze())
+    logits = torch.cat([sim[:B, B:2 * B] * d_pos, sim[:B, :B] * d_neg, sim[:B, 2 * B:] * d_hard], dim=1) / temperature
+    return F.cross_entropy(logits, torch.arange(B))
+
+
+def mask_correlated_samples(batch_size):
+    """``train/train_retriever.py:74-82``."""
+    N = 2 * batch_size
+    mask = torch.ones((N, N), dtype=bool)
+    mask = mask.fill_diagonal_(0)
+    for i in range(batch_size):
+        mask[i, batch_size + i] = 0
+        mask[batch_size + i, i] = 0
+    return mask
+
+
+def info_nce(z_i, z_j, temp, batch_size):
+    """``info_nce`` -- ``train/train_retriever.py:84-98`` (plain dot products, NOT normalised)."""
+    N = 2 * batch_size
+    z = torch.cat((z_i, z_j), dim=0)
+    sim = torch.mm(z, z.T) / temp
+    pos = torch.cat((torch.diag(sim, batch_size), torch.diag(sim, -batch_size)), dim=0).reshape(N, 1)
+    neg = sim[mask_correlated_samples(batch_size)].reshape(N, -1)
+    return F.cross_entropy(torch.cat((pos, neg), dim=1), torch.zeros(N, dtype=torch.long))
+
+
+def aug(batch_seqs, eta, gamma, mask_token):
+    """``_aug`` -- ``models/modeling_rag.py:774-840``: first view = crop, second view = mask, driven by python's ``random``
+    (seed it to reproduce).  Quirks kept: the length of a row is its count of NON-ZERO ids (pads count, node id 0 does
+    not); the crop copies a window of ``floor(length * eta)`` ids to the END of an all-zero row; ``seq[:]`` of an ndarray
+    is a view, so the mask view is written into the row itself (after the crop view was taken)."""
+    seqs = batch_seqs.tolist()
+    lengths = batch_seqs.count_nonzero(dim=1).tolist()
+    out1, out2 = [], []
+    for seq, length in zip(seqs, lengths):
+        seq = np.asarray(list(seq), dtype=np.int64)
+
+        def crop():
+            num_left = math.floor(length * eta)
+            crop_begin = random.randint(4, length - num_left)
+            c = np.zeros_like(seq)
+            if crop_begin != 0:
+                c[-num_left:] = seq[-(crop_begin + num_left):-crop_begin]
+            else:
+                c[-num_left:] = seq[-(crop_begin + num_left):]
+            return c.tolist(), num_left
+
+        def mask():
+            num_mask = math.floor(length * gamma)
+            idx = random.sample(range(length), k=num_mask)
+            m = seq[:]
+            m[[-i - 1 for i in idx]] = mask_token
+            return m.tolist(), length
+
+        if length > 1:
+            a1, l1 = crop()
+            out1.append(a1 if l1 > 0 else seq.tolist())
+            a2, l2 = mask()
+            out2.append(a2 if l2 > 0 else seq.tolist())
+        else:
+            out1.append(seq.tolist()); out2.append(seq.tolist())
+    return torch.tensor(out1, dtype=torch.long), torch.tensor(out2, dtype=torch.long)
+
+
+def training_step(sd, n_head, anchor, pos, neg, all_times, idx, eta, gamma, alpha, temperature, decay_rate, mask_token,
+                  seed, with_grad=False):
+    """The loss of one ``train_epoch`` iteration (``train/train_retriever.py:177-196``): three forwards + time-decayed
+    contrastive loss, two augmented forwards + alpha * InfoNCE.  ``with_grad``: ``sd`` tensors must require grad; the
+    returned loss is then differentiable (gradient fixtures)."""
+    fwd = gpt2_ref.gpt2_forward.__wrapped__ if with_grad else gpt2_ref.gpt2_forward
+    emb = lambda ids: fwd(sd, ids, n_head, want_logits=False)["hidden"].mean(dim=1)
+    h_a, h_p, h_n = emb(anchor), emb(pos), emb(neg)
+    t = torch.as_tensor(all_times)
+    cl = cltime_loss(temperature, decay_rate, h_a, h_p, h_n, t[idx[:, 0:1]], t[idx[:, 1:2]], t[idx[:, 2:3]])
+    random.seed(seed)
+    a1, a2 = aug(anchor, eta, gamma, mask_token)
+    h1, h2 = emb(a1), emb(a2)
+    au = alpha * info_nce(h1, h2, temperature, a1.size(0))
+    return dict(cl=cl, aug=au, loss=cl + au, emb=torch.stack([h_a, h_p, h_n, h1, h2]), aug1=a1, aug2=a2)

@@ -43,27 +43,36 @@ class LineByLineTextDatasetHistory(LineByLineTextDataset):
 
 
 def load_and_cache_examples(args, tokenizer, evaluate=False, test=False, pair=True):
-    """``dataloader/retriever.py:113-125``; the (anchor, positive, negative) training triples are out of scope."""
+    """``dataloader/retriever.py:113-125``: the (anchor, positive, negative) triples of ``--train_pair_data_file`` for the
+    training step (``rag4dyg_amd.training``, forward half), line datasets otherwise."""
     if evaluate:
         file_path = args.eval_data_file
     elif test:
         file_path = args.test_data_file
+    elif pair:
+        from .training import PairSequenceDataset
+        return PairSequenceDataset(tokenizer, args, file_path=args.train_pair_data_file, block_size=args.block_size)
     else:
-        raise NotImplementedError("PairSequenceDataset feeds retriever TRAINING (backward pass), which is outside "
-                                  "the encode-and-retrieve path (SURVEY.md 8f-4)")
+        file_path = args.train_data_file
     return LineByLineTextDataset(tokenizer, args, file_path=file_path, block_size=args.block_size)
 
 
 def get_dataloader(dataset, tokenizer, args, split='eval'):
-    """Eval branch of ``dataloader/retriever.py:128-168``."""
-    if split == 'train':
-        raise NotImplementedError("training loader: outside the encode-and-retrieve path (SURVEY.md 8f-4)")
+    """``dataloader/retriever.py:128-168``: sequential right-padded eval batches; shuffled six-tensor training batches
+    (anchor / positive / negative sequences and their pool indices, all padded with the [PAD] id like upstream)."""
+    pad = {} if tokenizer.pad_token is None else {"padding_value": tokenizer.pad_token_id}
 
     def collate(examples):
-        if tokenizer.pad_token is None:
-            return pad_sequence(examples, batch_first=True)
-        return pad_sequence(examples, batch_first=True, padding_value=tokenizer.pad_token_id)
+        if split == 'train':
+            return tuple(pad_sequence([ex[j] for ex in examples], batch_first=True, **pad) for j in range(6))
+        return pad_sequence(examples, batch_first=True, **pad)
 
+    if split == 'train':
+        from torch.utils.data import RandomSampler
+        args.train_batch_size = args.per_gpu_train_batch_size * max(1, args.n_gpu)
+        loader = DataLoader(dataset, sampler=RandomSampler(dataset), batch_size=args.train_batch_size, collate_fn=collate,
+                            drop_last=False)
+        return loader, args
     args.eval_batch_size = args.per_gpu_eval_batch_size * max(1, args.n_gpu)
     loader = DataLoader(dataset, sampler=SequentialSampler(dataset), batch_size=args.eval_batch_size,
                         collate_fn=collate, drop_last=False)

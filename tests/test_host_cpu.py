@@ -295,8 +295,18 @@ def test_dataset_classes_and_eval_batching(tmp_path):
     b0 = batches[0]
     assert b0.shape[1] == max(len(hist[i]) for i in range(32))
     assert (b0[0, len(hist[0]):] == 1799).all()                        # right-padded with [PAD]
-    with pytest.raises(NotImplementedError):
-        get_dataloader(hist, tok, args, split="train")
+    # training loader (dataloader/retriever.py:130-151,157-160): six right-padded tensors per batch, shuffled
+    from rag4dyg_amd.training import PairSequenceDataset
+    (tmp_path / "pairs.txt").write_text("0 1 2\n3 4 5\n6 7 8\n9 10 11\n12 13 14\n")
+    args.train_data_file, args.per_gpu_train_batch_size = str(p), 4
+    pairs = PairSequenceDataset(tok, args, str(tmp_path / "pairs.txt"), block_size=512)
+    tl, args = get_dataloader(pairs, tok, args, split="train")
+    got = list(tl)
+    assert args.train_batch_size == 4 and [b[0].shape[0] for b in got] == [4, 1] and all(len(b) == 6 for b in got)
+    a0 = got[0]
+    assert a0[3].shape == (4, 1) and sorted(int(x) for b in got for x in b[3].flatten()) == [0, 3, 6, 9, 12]
+    row = int(a0[3][0, 0])
+    assert a0[0][0, :len(pairs.anchor[row // 3])].tolist() == pairs.anchor[row // 3] == hist[row].tolist()
 
 
 def test_annotation_parsing_matches_oracle():
@@ -566,3 +576,51 @@ def test_annotation_rank_row_ranges_cover_in_order_and_parts_join(tmp_path):
     _join_parts(str(target), 3)
     assert target.read_text() == "0 0\n1 0\n1 1\n2 0\n2 1\n2 2\n"
     assert not list(tmp_path.glob("*.part*"))
+
+
+# ------------------------------------------------------------------------------------------- training step, host side (8f-4)
+def test_training_losses_and_augmentation_match_reference_fixtures():
+    """rag4dyg_amd.training against the reference's own functions (G8): CLtime_loss, info_nce (+ rebuilt mask), the
+    crop / mask augmentation under a seeded python ``random``."""
+    import random
+    from types import SimpleNamespace
+    from rag4dyg_amd import training
+    g = load_golden("g8_training_step")
+    T = torch.from_numpy
+    for tag in ("l4", "l32"):
+        a, p, n = (T(x) for x in g[tag + "_emb"])
+        ta, tp, tn = (T(x) for x in g[tag + "_time"])
+        B = a.shape[0]
+        args = SimpleNamespace(temperature=0.07, lambda_decay=0.05, per_gpu_train_batch_size=B)
+        assert abs(training.CLtime_loss(args, a, p, n, ta, tp, tn).item() - float(g[tag + "_cltime"])) < 1e-5
+        mask = training.mask_correlated_samples(B)
+        assert np.array_equal(mask.numpy(), g[tag + "_mask"])
+        assert abs(training.info_nce(args, a, p, 0.07, B, mask).item() / float(g[tag + "_infonce_raw"]) - 1) < 1e-6
+        args.per_gpu_train_batch_size = B + 1
+        assert abs(training.info_nce(args, a, p, 0.07, B, None).item() / float(g[tag + "_infonce_rebuilt"]) - 1) < 1e-6
+    for tag in ("ts_tiny", "ts_cfg2"):
+        L, H, d, V, pad, B, seed = (int(x) for x in g[tag + "_cfg"])
+        eta, gamma = float(g[tag + "_hyper"][0]), float(g[tag + "_hyper"][1])
+        random.seed(seed)
+        a1, a2 = training.aug(T(g[tag + "_anchor"]), eta, gamma, V - 1)
+        assert np.array_equal(a1.numpy(), g[tag + "_aug1"]) and np.array_equal(a2.numpy(), g[tag + "_aug2"])
+
+
+@has_ref
+def test_pair_sequence_dataset_matches_reference_class(tmp_path):
+    """dataloader/retriever.py:68-111 on the shipped UCI_13 train file and a triples file (G8)."""
+    from types import SimpleNamespace
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    from rag4dyg_amd.training import PairSequenceDataset
+    g = load_golden("g8_training_step")
+    unrag = lambda f, o: [f[o[i]:o[i + 1]].tolist() for i in range(len(o) - 1)]
+    (tmp_path / "pairs.txt").write_text("\n".join(" ".join(map(str, r)) for r in g["pair_triples"].tolist()) + "\n")
+    tok, _ = build_tokenizer("UCI_13", 12, root=REF)
+    ds = PairSequenceDataset(tok, SimpleNamespace(train_data_file=os.path.join(REF, "resources/UCI_13/12/train.link_prediction")),
+                             str(tmp_path / "pairs.txt"), block_size=512)
+    assert len(ds) == 10
+    assert [list(x) for x in ds.anchor] == unrag(g["pair_anchor_flat"], g["pair_anchor_off"])
+    assert [list(x) for x in ds.positive] == unrag(g["pair_pos_flat"], g["pair_pos_off"])
+    assert [list(x) for x in ds.negative] == unrag(g["pair_neg_flat"], g["pair_neg_off"])
+    it = ds[2]
+    assert it[0].tolist() == g["pair_item2_anchor"].tolist() and [int(it[3]), int(it[4]), int(it[5])] == g["pair_item2_idx"].tolist()
