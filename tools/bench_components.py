@@ -158,7 +158,7 @@ def pool():
              seqs_per_s=round(12500 / el, 1))
 
 
-def generator():
+def generator(shape_name="UCI_13", L=6, H=8, d=768, topk=7, pool_n=512):
     """RAG generator inference (graph-pooling fusion of top-7 retrieved sequences + greedy decode, val
     mode = 11 tokens per query, batch 1 like the reference) on UCI_13-shaped synthetic data, model L6 H8 d768
     (scripts/train_generator/train_rag_graphpooling_UCI_seed.sh), next to the oracle on the host cores."""
@@ -166,19 +166,18 @@ def generator():
     from oracle import generator_ref, gpt2_ref
     from rag4dyg_amd import generator as gen
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
-    shape = synth.SHAPES["UCI_13"]
-    L, H, d, topk = 6, 8, 768, 7
-    V = shape.vocab
+    shape = synth.SHAPES[shape_name]
+    V = shape.vocab_generator if shape_name == "reddit" else shape.vocab
     sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=4, random_affine=True)
     model = GPT2LMHeadModelRAG(GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H))
     model.load_state_dict(sd, strict=False); model.tie_weights()
     gnn = model.get_gnn(d, d // 2, d, 1, 0.2)
     convs = [(gnn.convs[0].lin.weight.detach().clone(), gnn.convs[0].bias.detach().clone())]
     model = model.to(dev).eval()
-    pool_seqs = [s.tolist() for s in synth.sequences(shape, 512, "pool", seed=1)]
+    pool_seqs = [s.tolist() for s in synth.sequences(shape, pool_n, "pool", seed=1)]
     queries = [s.tolist() for s in synth.sequences(shape, 256, "query", seed=2)]
     rng = np.random.default_rng(0)
-    idxs = [rng.permutation(512)[:topk].tolist() for _ in queries]
+    idxs = [rng.permutation(pool_n)[:topk].tolist() for _ in queries]
     ds = types.SimpleNamespace(retrieval_sources=pool_seqs)
     args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=topk)
     tok = types.SimpleNamespace(encode=lambda s: [shape.v0], pad_token_id=shape.pad_id)     # <|endoftext|> = V0
@@ -211,7 +210,7 @@ def generator():
         out = generator_ref.greedy_decode_rag(sd, H, fn, q, eos, "val", 1024, 12)
         ncpu += len(out) - len(q)
     elc = time.perf_counter() - t0
-    emit(component="generator_decode", shape="UCI_13", model="L6 H8 d768", fusion="graphpooling", topK=topk,
+    emit(component="generator_decode", shape=shape_name, model=f"L{L} H{H} d{d} V{V}", pool=pool_n, fusion="graphpooling", topK=topk,
          queries=len(queries), mean_query_len=round(float(np.mean([len(q) for q in queries])), 1), tokens=ntok,
          tokens_per_s=round(ntok / el, 1), queries_per_s=round(len(queries) / el, 2), batch=32,
          tokens_per_s_batch1=round(ntok1 / el1, 1),
@@ -219,6 +218,44 @@ def generator():
                        "sample": "3 queries, oracle torch-CPU fp32 (fusion + full forward per token, as the reference)"})
 
 
+
+def generator_reddit():
+    """BASELINE config 5 shape: reddit t=11, L2 H8 d512, V = 11,919, pool 10,527, top-7 (the script) and top-5 (BASELINE.json)."""
+    generator("reddit", 2, 8, 512, 7, 10527)
+    generator("reddit", 2, 8, 512, 5, 10527)
+
+
+_JAC_CPU = r"""
+import json, os, sys, time, multiprocessing as mp
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import jaccard_ref
+cores = int(sys.argv[2])
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "g5_jaccard_hepth.npz"))
+lists = [g["tr_out_idx"][g["tr_out_ptr"][i]:g["tr_out_ptr"][i + 1]].tolist() for i in range(len(g["tr_out_ptr"]) - 1)]
+rows = 150 * cores
+blocks = [lists[i:i + 150] for i in range(0, rows, 150)]
+t0 = time.perf_counter()
+with mp.get_context("fork").Pool(cores) as pool:
+    pool.starmap(jaccard_ref.occurrence_matrix_naive, [(b_, lists) for b_ in blocks])
+el = time.perf_counter() - t0
+print(json.dumps({"rows": rows, "cols": len(lists), "seconds": el}))
+"""
+
+
+def jaccard_cpu_all_cores():
+    """the reference's python-set double loop (retrieval_data_annotation.py:36-41) on ALL host cores (row blocks in
+    a process pool, started from a fresh interpreter that never touches the GPU) next to the single-thread line of jaccard()."""
+    import subprocess
+    cores = host_cores()
+    out = subprocess.run([sys.executable, "-c", _JAC_CPU, REPO, str(cores)], capture_output=True, text=True, check=True).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    emit(component="jaccard_cpu_baseline", kind="port", cores=cores,
+         sample=f"{r['rows']} x {r['cols']} hepth out-set pairs, python sets per pair, {cores} processes",
+         pairs_per_s=round(r["rows"] * r["cols"] / r["seconds"]))
+
+
 if __name__ == "__main__":
-    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "pool", "generator"]):
-        {"scan": scan, "topk": topk, "jaccard": jaccard, "pool": pool, "generator": generator}[part]()
+    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "jaccard_cpu", "pool", "generator", "generator_reddit"]):
+        {"scan": scan, "topk": topk, "jaccard": jaccard, "jaccard_cpu": jaccard_cpu_all_cores, "pool": pool, "generator": generator,
+         "generator_reddit": generator_reddit}[part]()
