@@ -152,7 +152,7 @@ def verify_sharded(world, rank, device, index, last_out, model, q_batches, args,
 
 
 def source_sha():
-    """sha256 over the kernel sources, the C ABI header and this file: what a PMC traffic figure was profiled on."""
+    """sha256 over the kernel sources and the C ABI header: what a PMC traffic figure was profiled on."""
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "rag4dyg_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
@@ -366,7 +366,9 @@ def main():
         dom = max(prof, key=lambda n: prof[n]["ms"])
         v = prof[dom]
         traffic = None
-        tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        tf = os.path.join(REPO, "profiles", f"pmc_traffic_{args.shape}.json")
+        if not os.path.exists(tf):
+            tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):              # PMC figure of a separate rocprofv3 pass: valid for the workload AND the sources
             pmc = json.load(open(tf))       # it was profiled on only -- otherwise null
             meta = pmc.get("_workload", {})
