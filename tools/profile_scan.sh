@@ -9,21 +9,31 @@ OUT=$R/gpurun_out/prof_scan_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export R4D_SCAN_CASES=${R4D_SCAN_CASES:-12500x512,100000x512}
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/bench_components.py scan topk > $OUT/trace.log 2>&1
-for grp in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$grp -- python3 $R/tools/bench_components.py scan > $OUT/pmc_$grp.log 2>&1
+# one pool size per process, so that the per-kernel averages and the per-launch counter means are not a mix of sizes
+for size in ${R4D_SCAN_CASES//,/ }; do
+  echo "trace $size" >> $OUT/progress.log
+  R4D_SCAN_CASES=$size R4D_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$size -- python3 $R/tools/bench_components.py scan > $OUT/trace_$size.log 2>&1
+  find $OUT/trace_$size -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$size.csv
+  for grp in FETCH_SIZE WRITE_SIZE; do
+    echo "pass $size $grp" >> $OUT/progress.log
+    R4D_SCAN_CASES=$size R4D_NO_GRAPH=1 timeout -k 5 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_${size}_$grp -- python3 $R/tools/bench_components.py scan > $OUT/pmc_${size}_$grp.log 2>&1 || echo "pass $size $grp FAILED" >> $OUT/progress.log
+  done
 done
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
-python3 - <<PY
+python3 - > $OUT/pmc.txt <<PY
 import csv, glob, collections
-for grp in ("FETCH_SIZE", "WRITE_SIZE"):
+import os
+print("# per-launch means, KiB as reported; hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction)")
+for d in sorted(glob.glob("$OUT/pmc_*_*")):
+    if not os.path.isdir(d):
+        continue
+    size, grp = os.path.basename(d)[4:].split("_", 1)
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % grp, recursive=True):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][:60]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     for k, (v, n) in sorted(agg.items()):
         if "scan" in k or "topk" in k:
-            print(grp, k, "launches", n, "avg per launch", v / n)
+            print(size, grp, k, "launches", n, "mean", round(v / n, 1))
 PY
-head -30 $OUT/kernel_stats.csv
+cat $OUT/pmc.txt; for f in $OUT/kernel_stats_*.csv; do echo "== $f"; grep -i "scan\|topk\|Name" $f; done

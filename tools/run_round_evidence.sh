@@ -17,4 +17,6 @@ echo "== profile bench wikiv2" >> $LOG
 R4D_PROFILE_SHAPE=wikiv2 bash tools/profile_bench.sh ${TAG}w >> $LOG 2>&1
 echo "== profile scan" >> $LOG
 bash tools/profile_scan.sh $TAG >> $LOG 2>&1
+echo "== profile jaccard" >> $LOG
+bash tools/profile_jaccard.sh $TAG >> $LOG 2>&1
 echo "== done" >> $LOG
