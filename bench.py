@@ -182,11 +182,17 @@ def scan_q32(index, shape, k, device, reps=50):
     lib.r4d_profile_enable(0)
     sc, tk = prof["pool_scan"], prof.get("topk", {"ms": 0.0, "launches": 1})
     gbs = sc["work"] / (sc["ms"] * 1e-3) / 1e9
+    traffic = None                                    # PMC bytes of a separate rocprofv3 pass on the same sources and size, else null
+    tf = os.path.join(REPO, "profiles", "pmc_scan.json")
+    if os.path.exists(tf):
+        pmc = json.load(open(tf))
+        if pmc.get("_workload", {}).get("source_sha") == source_sha():
+            traffic = pmc.get(f"{int(index.pool_hat.shape[0])}x{shape.n_embd}", {}).get("hbm_bytes_per_launch")
     return {"pool_rows": int(index.pool_hat.shape[0]), "d": shape.n_embd, "queries": QB, "topk": k,
             "scan_kernel_us": round(1e3 * sc["ms"] / sc["launches"], 2), "topk_kernel_us": round(1e3 * tk["ms"] / sc["launches"], 2),
             "host_loop_wall_us": round(wall * 1e6, 1), "algorithmic_bytes": sc["work"] / sc["launches"],
             "roofline": {"kernel": "pool_scan", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4)}}
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic}}
 
 
 def main():
