@@ -527,6 +527,8 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     assert sq["queries"] == 32 and sq["pool_rows"] == 2048 and sq["roofline"]["bound"] == "hbm" and 0 < sq["roofline"]["frac"] <= 1
     assert d["roofline"]["traffic"] is None                              # PMC figure belongs to another workload / pool size
     assert len(d["extras"]["source_sha"]) == 16 and d["config"]["pool_rows_total"] == 2048
+    lb = d["extras"]["length_bucketed"]                                  # SURVEY 8d's second run, never the headline
+    assert lb["value"] > 0 and lb["mean_padded_T"] > 0 and "not parity-comparable" in lb["note"]
     env2 = dict(env, R4D_BENCH_BACKEND="gloo", R4D_BENCH_PIPELINE="force")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", "29536", os.path.join(REPO, "bench.py"), "--gpus", "2",
