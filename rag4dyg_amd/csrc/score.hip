@@ -186,6 +186,7 @@ static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, 
                             int nzero, hipStream_t s) {
     static int kw8 = -1;
     if (kw8 < 0) { const char* e = getenv("R4D_SCAN_KW8"); kw8 = e ? atoi(e) : 1; }               // tuning aid: 0 = 4-way split at d 512
+    if (d != 32 && d != 64 && d != 128 && d != 256 && d != 384 && d != 512 && d != 768 && d != 1024) return 1;   // no variant
     // algorithmic bytes (SURVEY 8d B_score): pool read once per 32 queries + queries + score rows out
     ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
     switch (d) {

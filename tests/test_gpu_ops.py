@@ -425,6 +425,33 @@ def test_topk_one_launch_every_size_bit_exact(dev, rows, n, k, dtype):
         assert np.array_equal(v.cpu().numpy(), ev)
 
 
+def test_topk_fuzz_random_shapes_heavy_ties(dev):
+    """Selection fuzz: 120 random (rows, n, k) with values drawn from a handful of levels (mass ties: the filter form's
+    survivor list overflows and falls back to the iterative form), all-equal rows, rows of -inf, k = n, k > valid columns
+    of the last segment, segment and chunk boundaries -- always == stable argsort, f32 and f64."""
+    from rag4dyg_amd import ops
+    from oracle import retrieval_ref
+    rng = np.random.default_rng(2026)
+    edges = [1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 16383, 16384, 16385, 32768, 50001]
+    for trial in range(120):
+        n = int(rng.choice(edges)) if trial % 2 == 0 else int(rng.integers(1, 70000))
+        rows = int(rng.integers(1, 9))
+        k = int(min(n, rng.choice([1, 2, 3, 5, 7, 10, 16, 17, 33, 64])))
+        levels = int(rng.choice([1, 2, 5, 50, 100000]))
+        x = rng.integers(0, levels, (rows, n)).astype(np.float64) / max(levels, 1)
+        if trial % 7 == 0:
+            x[0, :] = -np.inf
+        if trial % 5 == 0 and n > 3:
+            x[-1, rng.integers(0, n, 3)] = np.nan
+        dtype = np.float32 if trial % 3 else np.float64
+        x = x.astype(dtype)
+        ref_in = np.where(np.isnan(x), -np.inf, x)
+        ev, ei = retrieval_ref.topk_stable(ref_in, k)
+        v, i = (ops.topk_f32 if dtype == np.float32 else ops.topk_f64)(cu(x, dev), k)
+        assert np.array_equal(i.cpu().numpy().astype(np.int64), ei), (trial, rows, n, k, levels, dtype)
+        assert np.array_equal(v.cpu().numpy(), ev), (trial, rows, n, k, levels)
+
+
 @pytest.mark.parametrize("rows,n", [(3, 1), (4, 2048), (3, 2049), (2, 3965), (5, 65537), (32, 100000), (1, 200001)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_argsort_desc_any_length_equals_numpy_stable(dev, rows, n, dtype):
