@@ -374,6 +374,7 @@ int topk_rows(const T* vals, const long long* idx_in, int rows, int n, long long
               T* out_v, long long* out_i, void* ws, size_t ws_bytes, bool counters_zeroed, hipStream_t s) {
     R4D_REQUIRE(k >= 1 && k <= MAXK && k <= n, "topk: k=%d must be in [1, min(64, n=%d)]", k, n);
     R4D_REQUIRE(rows >= 1 && rows <= 65535, "topk: rows=%d outside [1, 65535]", rows);
+    R4D_REQUIRE(n <= (1 << 30), "topk: n=%d exceeds 2^30 columns", n);          // 32-bit column arithmetic incl. the padded tail
     if (!ws || ws_bytes < topk_ws_bytes<T>(rows, n, k)) {
         set_error("topk: workspace too small");
         return R4D_ERR_WORKSPACE;
@@ -542,28 +543,41 @@ __global__ __launch_bounds__(1024) void sort_chunks_kernel(const T* __restrict__
     for (int j = t; j < SORT_CHUNK; j += 1024) { ws_k[base + j] = sk[j]; ws_i[base + j] = si[j]; }
 }
 
-// grid (cdiv(n,256), rows), block 256
+// grid (cdiv(n, 2048), rows), block 1024: a workgroup ranks 2048 elements of a row.  Every sorted chunk of the row passes
+// through LDS once per workgroup (coalesced 16-24 KB), and each thread binary-searches its two elements there: 12 LDS
+// steps per chunk instead of 12 dependent L2 round trips (first version: 4.2 ms for 32 x 100k rows).
 template <typename T>
-__global__ __launch_bounds__(256) void rank_scatter_kernel(const T* __restrict__ scores, int n, int nchunks,
-                                                           const typename DescKey<T>::K* __restrict__ ws_k,
-                                                           const uint32_t* __restrict__ ws_i, int32_t* __restrict__ perm) {
+__global__ __launch_bounds__(1024) void rank_scatter_kernel(const T* __restrict__ scores, int n, int nchunks,
+                                                            const typename DescKey<T>::K* __restrict__ ws_k,
+                                                            const uint32_t* __restrict__ ws_i, int32_t* __restrict__ perm) {
     typedef typename DescKey<T>::K K;
-    const int row = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const K mk = DescKey<T>::make(scores[(long long)row * n + i]);
-    const K* ck = ws_k + (long long)row * nchunks * SORT_CHUNK;
-    const uint32_t* ci = ws_i + (long long)row * nchunks * SORT_CHUNK;
-    long long rank = 0;
-    for (int c = 0; c < nchunks; ++c, ck += SORT_CHUNK, ci += SORT_CHUNK) {
-        int base = 0;
+    __shared__ K ck[SORT_CHUNK];
+    __shared__ uint32_t ci[SORT_CHUNK];
+    const int row = blockIdx.y, t = threadIdx.x;
+    const long long e0 = (long long)blockIdx.x * SORT_CHUNK + t, e1 = e0 + 1024;
+    const bool ok0 = e0 < n, ok1 = e1 < n;
+    const K k0 = DescKey<T>::make(scores[(long long)row * n + (ok0 ? e0 : n - 1)]);
+    const K k1 = DescKey<T>::make(scores[(long long)row * n + (ok1 ? e1 : n - 1)]);
+    const K* gk = ws_k + (long long)row * nchunks * SORT_CHUNK;
+    const uint32_t* gi = ws_i + (long long)row * nchunks * SORT_CHUNK;
+    long long r0 = 0, r1 = 0;
+    for (int c = 0; c < nchunks; ++c, gk += SORT_CHUNK, gi += SORT_CHUNK) {
+        __syncthreads();
+        ck[t] = gk[t]; ck[t + 1024] = gk[t + 1024];
+        ci[t] = gi[t]; ci[t + 1024] = gi[t + 1024];
+        __syncthreads();
+        int b0 = 0, b1 = 0;
 #pragma unroll
-        for (int s_ = SORT_CHUNK / 2; s_ >= 1; s_ >>= 1)
-            base += pair_less<K>(ck[base + s_ - 1], ci[base + s_ - 1], mk, (uint32_t)i) ? s_ : 0;
-        base += pair_less<K>(ck[base], ci[base], mk, (uint32_t)i) ? 1 : 0;
-        rank += base;
+        for (int s_ = SORT_CHUNK / 2; s_ >= 1; s_ >>= 1) {
+            b0 += pair_less<K>(ck[b0 + s_ - 1], ci[b0 + s_ - 1], k0, (uint32_t)e0) ? s_ : 0;
+            b1 += pair_less<K>(ck[b1 + s_ - 1], ci[b1 + s_ - 1], k1, (uint32_t)e1) ? s_ : 0;
+        }
+        b0 += pair_less<K>(ck[b0], ci[b0], k0, (uint32_t)e0) ? 1 : 0;
+        b1 += pair_less<K>(ck[b1], ci[b1], k1, (uint32_t)e1) ? 1 : 0;
+        r0 += b0; r1 += b1;
     }
-    perm[(long long)row * n + rank] = i;
+    if (ok0) perm[(long long)row * n + r0] = (int32_t)e0;
+    if (ok1) perm[(long long)row * n + r1] = (int32_t)e1;
 }
 
 template <typename T>
@@ -596,7 +610,7 @@ static int argsort_desc(const T* scores, int rows, int n, int32_t* perm, void* w
     hipLaunchKernelGGL((sort_chunks_kernel<T>), dim3(nchunks, rows), dim3(1024), 0, s, scores, n, nchunks, ws_k, ws_i, perm);
     R4D_CHECK_LAUNCH("sort_chunks");
     if (nchunks > 1) {
-        hipLaunchKernelGGL((rank_scatter_kernel<T>), dim3(cdiv(n, 256), rows), dim3(256), 0, s, scores, n, nchunks, ws_k, ws_i, perm);
+        hipLaunchKernelGGL((rank_scatter_kernel<T>), dim3(nchunks, rows), dim3(1024), 0, s, scores, n, nchunks, ws_k, ws_i, perm);
         R4D_CHECK_LAUNCH("rank_scatter");
     }
     return R4D_OK;
