@@ -292,6 +292,64 @@ int r4d_topk_f64(const double* m_d, int32_t rows, int32_t n, int32_t k, double* 
                  int32_t* out_idx_d, void* workspace_d, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Retriever TRAINING step.  Replaces, for the encoder, what torch autograd does for the reference in
+ * train/train_retriever.py:177-214: five forwards (anchor, positive, hard negative, two augmented views), loss.backward(),
+ * clip_grad_norm_, AdamW.  The contrastive losses themselves ([B,3B] / [2B,2B] similarity tables, :40-98) stay with the
+ * caller: it receives the mean-pooled embeddings and hands back their gradient.  Dropout is the identity.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct r4d_gpt2_layer_grads {   /* device pointers, same shapes as r4d_gpt2_layer's reference-layout tensors */
+    float* ln_1_w;      float* ln_1_b;
+    float* c_attn_w;    float* c_attn_b;      /* [d,3d], [3d] */
+    float* attn_proj_w; float* attn_proj_b;   /* [d,d],  [d]  */
+    float* ln_2_w;      float* ln_2_b;
+    float* c_fc_w;      float* c_fc_b;        /* [d,4d], [4d] */
+    float* mlp_proj_w;  float* mlp_proj_b;    /* [4d,d], [d]  */
+} r4d_gpt2_layer_grads;
+typedef struct r4d_gpt2_grads {
+    float* wte;                           /* [vocab,d]        (zeroed, then scatter-added) */
+    float* wpe;                           /* [n_positions,d]  (zeroed, then scatter-added) */
+    float* ln_f_w;
+    float* ln_f_b;
+    const r4d_gpt2_layer_grads* layers;   /* HOST array [n_layer] */
+} r4d_gpt2_grads;
+
+/* Scratch of one step: the activations the backward pass needs (16 * rows * d floats per layer + the attention
+ * probabilities) and the backward temporaries.  The SAME buffer goes to the forward and to the backward call. */
+size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs, const int32_t* Ts);
+/* Forward over up to 16 right-padded id batches (one launch sequence over their concatenated rows) that keeps every
+ * activation the backward pass reads.  Weights in the reference layout only (the optional wT copies are ignored: the
+ * weights change every step).  out_meanpool_d f32 [sum(Bs), d] = torch.mean(h, dim=1) per sequence. */
+int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
+                               const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts, float* out_meanpool_d,
+                               void* workspace_d, size_t workspace_bytes, void* stream);
+/* Backward of the call above (same arguments, same workspace contents): d_meanpool_d f32 [sum(Bs), d] = dLoss / d(embeddings)
+ * -> every gradient of `grads` is OVERWRITTEN with dLoss / d(parameter) (lm_head is not on this path: the retriever discards
+ * the logits, train_retriever.py:177-179). */
+int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_gpt2_grads* grads,
+                                int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
+                                const float* d_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
+/* Single backward ops, exported for per-op parity tests (the kernels the step launches). */
+size_t r4d_layernorm_bwd_workspace_bytes(int32_t rows, int32_t d);
+/* dx = dLayerNorm/dx (+ add_d when given; add_d may be dx_d), dw / db = gains' and shifts' gradients (overwritten). */
+int r4d_layernorm_bwd_f32(const float* x_d, const float* w_d, const float* dy_d, const float* add_d, int32_t rows, int32_t d,
+                          float eps, float* dx_d, float* dw_d, float* db_d, void* workspace_d, size_t workspace_bytes,
+                          void* stream);
+int r4d_gelu_new_f32(const float* pre_d, int64_t n, float* y_d, void* stream);                     /* modeling_gpt2.py:25 */
+int r4d_gelu_new_bwd_f32(const float* pre_d, const float* dy_d, int64_t n, float* dx_d, void* stream);   /* dx may be dy */
+/* p_d [nbh,T,ld] causal probabilities (zero right of the diagonal), dp_d [nbh,T,ld] = dLoss/dP on entry and
+ * dLoss/d(raw Q.K^T logits) on return (the logits were divided by scale_div before the softmax, modeling_gpt2.py:143);
+ * columns right of the diagonal are written as zero. */
+int r4d_causal_softmax_bwd_f32(const float* p_d, float* dp_d, int32_t nbh, int32_t T, int32_t ld, float scale_div, void* stream);
+/* accum_d[0] += sum x^2 (total gradient norm of clip_grad_norm_, train_retriever.py:210; zero accum_d first). */
+int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* stream);
+/* One transformers.AdamW update of a flat tensor (utils/model.py:80-93; decoupled weight decay applied after the step,
+ * bias correction on): step >= 1 is the update count; grad_sumsq_d (nullable) with max_grad_norm > 0 clips the gradient
+ * by min(1, max_grad_norm / (sqrt(sum) + 1e-6)) on the fly (torch.nn.utils.clip_grad_norm_). */
+int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, every kernel launch is bracketed by HIP events on the
  * launch stream and accumulated per kernel class together with its ALGORITHMIC work (flop for the
  * MFMA-bound classes, bytes for the HBM-bound ones; definitions in DESIGN.md).  Off by default;

@@ -32,6 +32,16 @@ class GreedyStateC(Structure):
                                          "out_tokens_d", "params_d")] + [("out_cap", c_int32)]
 
 
+class GPT2LayerGradsC(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_1_w", "ln_1_b", "c_attn_w", "c_attn_b", "attn_proj_w", "attn_proj_b",
+                                         "ln_2_w", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b")]
+
+
+class GPT2GradsC(Structure):
+    _fields_ = [("wte", c_void_p), ("wpe", c_void_p), ("ln_f_w", c_void_p), ("ln_f_b", c_void_p),
+                ("layers", POINTER(GPT2LayerGradsC))]
+
+
 class GPT2WeightsC(Structure):
     _fields_ = [("wte", c_void_p), ("wpe", c_void_p), ("ln_f_w", c_void_p), ("ln_f_b", c_void_p),
                 ("layers", POINTER(GPT2LayerC)), ("lm_head", c_void_p)]
@@ -82,6 +92,18 @@ PROTOTYPES = {
     "r4d_jaccard_ordered_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "r4d_gpt2_train_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "r4d_gpt2_train_forward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), c_int32, POINTER(_P), POINTER(c_int32),
+                                             POINTER(c_int32), _P, _P, c_size_t, _P]),
+    "r4d_gpt2_train_backward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GPT2GradsC), c_int32, POINTER(_P),
+                                              POINTER(c_int32), POINTER(c_int32), _P, _P, c_size_t, _P]),
+    "r4d_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "r4d_layernorm_bwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "r4d_gelu_new_f32": (c_int32, [_P, c_int64, _P, _P]),
+    "r4d_gelu_new_bwd_f32": (c_int32, [_P, _P, c_int64, _P, _P]),
+    "r4d_causal_softmax_bwd_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_float, _P]),
+    "r4d_sumsq_accumulate_f32": (c_int32, [_P, c_int64, _P, _P]),
+    "r4d_adamw_step_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, _P, c_float, _P]),
     "r4d_profile_enable": (c_int32, [c_int32]),
     "r4d_profile_num_classes": (c_int32, []),
     "r4d_profile_class_name": (c_char_p, [c_int32]),

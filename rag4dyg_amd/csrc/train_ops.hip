@@ -1,0 +1,368 @@
+// Row / element kernels of the retriever TRAINING step's backward pass on gfx950: LayerNorm backward,
+// gelu_new forward / backward, causal softmax backward, column sums (bias gradients), batched transpose (the A^T operand
+// of the weight-gradient GEMMs), embedding scatter-add, mean-pool broadcast, squared-norm accumulation and the AdamW update.
+// The reference gets all of these from torch autograd (loss.backward(), train/train_retriever.py:196-214) and
+// transformers.AdamW (utils/model.py:80-102); what is computed here is the same calculus on the tensors of
+// models/modeling_gpt2.py:140-235 -- checked against the reference's own autograd gradients (tests/golden/g8_training_step.npz).
+#include <math.h>
+#include "common.h"
+
+namespace r4d {
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm backward
+// y = (x - mean) * rstd * w + b per row.  Given dy:  g = dy * w,  xh = (x - mean) * rstd,
+//   dx = rstd * (g - mean_c(g) - xh * mean_c(g * xh))   [+ add[m,:] when `add` is given: the residual branch's gradient]
+//   dw = sum_rows dy * xh,  db = sum_rows dy      (two deterministic stages: per-workgroup partial rows, then a column pass)
+// One wavefront per row (d <= 2048), statistics recomputed from x (two-pass like the forward kernel).
+constexpr int LNB_ROWS = 32;                                     // rows per workgroup (8 per wave)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ dy, const float* add, int rows,
+                                                     int d, float eps, float* dx, float* __restrict__ part_w,
+                                                     float* __restrict__ part_b) {          // `add` may alias `dx` (in-place residual)
+    extern __shared__ float red[];                               // [2][4][d]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nv = d >> 6;                                       // d % 64 == 0
+    float aw[32], ab[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+    for (int r = 0; r < LNB_ROWS / 4; ++r) {
+        const long long row = (long long)blockIdx.x * LNB_ROWS + wid + 4 * r;
+        if (row >= rows) break;                                  // wave-uniform
+        float xv[32], gv[32];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) if (i < nv) { xv[i] = x[row * d + lane + 64 * i]; s += xv[i]; }
+        const float mean = wave_sum_t(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) if (i < nv) { xv[i] -= mean; q += xv[i] * xv[i]; }
+        const float rstd = rsqrtf(wave_sum_t(q) / (float)d + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < nv) {
+                const float dyv = dy[row * d + lane + 64 * i];
+                xv[i] *= rstd;                                   // xh
+                gv[i] = dyv * w[lane + 64 * i];
+                sg += gv[i]; sgx += gv[i] * xv[i];
+                aw[i] += dyv * xv[i]; ab[i] += dyv;
+            }
+        const float mg = wave_sum_t(sg) / (float)d, mgx = wave_sum_t(sgx) / (float)d;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < nv) {
+                float v = rstd * (gv[i] - mg - xv[i] * mgx);
+                if (add) v += add[row * d + lane + 64 * i];
+                dx[row * d + lane + 64 * i] = v;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) if (i < nv) { red[wid * d + lane + 64 * i] = aw[i]; red[(4 + wid) * d + lane + 64 * i] = ab[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {                 // waves combined in a fixed order
+        part_w[(long long)blockIdx.x * d + c] = (red[c] + red[d + c]) + (red[2 * d + c] + red[3 * d + c]);
+        part_b[(long long)blockIdx.x * d + c] = (red[4 * d + c] + red[5 * d + c]) + (red[6 * d + c] + red[7 * d + c]);
+    }
+}
+
+// out[c] (+)= sum over rows of x[r, c]: one thread per column walks the rows in order (deterministic); rows is small here
+// (partials of ln_bwd_kernel / colsum_partial_kernel)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ x, int rows, int n, float* __restrict__ out,
+                                                           int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(long long)r * n + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// partial[b, c] = sum of x[r, c] over the 256 rows of block b (4 waves x 64 rows, coalesced across c)
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int n, int ld,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long long r0 = (long long)blockIdx.y * CS_ROWS + wid * 64;
+    float s = 0.f;
+    if (c < n)
+        for (int r = 0; r < 64; ++r) {
+            const long long row = r0 + r;
+            if (row < rows) s += x[row * ld + c];
+        }
+    red[wid][lane] = s;
+    __syncthreads();
+    if (wid == 0 && c < n) partial[(long long)blockIdx.y * n + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ------------------------------------------------------------------------------------ gelu_new
+__device__ __forceinline__ float gelu_new_t(float x) {           // modeling_gpt2.py:25,206 (tanh form)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_new_grad(float x) {
+    const float c = 0.7978845608028654f;
+    const float u = c * (x + 0.044715f * x * x * x), t = tanhf(u);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, long long n, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = gelu_new_t(pre[i]);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, const float* dy, long long n,
+                                                       float* dx) {                              // dx may alias dy
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * gelu_new_grad(pre[i]);
+}
+
+// ------------------------------------------------------------------------------------ causal softmax backward
+// P = softmax of the causal row (zeros right of the diagonal), logits were divided by sqrt(hd) BEFORE the softmax
+// (modeling_gpt2.py:143), so dLogit_raw = dS / scale_div with dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik).  In place on dP;
+// every column right of the diagonal up to ld is WRITTEN as zero (the dP buffer holds unwritten memory there).
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long long nrows_total,
+                                                          int T, int ld, float scale_div) {
+    const int lane = threadIdx.x & 63;
+    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= nrows_total) return;
+    const int i = (int)(gr % T);
+    const long long base = (gr / T) * (long long)T * ld + (long long)i * ld;
+    const int n = i + 1;
+    float p[16], g[16];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = lane + 64 * c;
+        const bool ok = j < n;
+        p[c] = ok ? P[base + min(j, ld - 1)] : 0.f;
+        g[c] = ok ? dP[base + min(j, ld - 1)] : 0.f;
+        s += p[c] * g[c];
+    }
+    s = wave_sum_t(s);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = lane + 64 * c;
+        if (j < ld) dP[base + j] = (j < n) ? p[c] * (g[c] - s) / scale_div : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------ batched transpose
+// out[z][c][r] = in[z][r][c] for r < rows, c < cols; columns r in [rows, ld_out) of every out row are written as zero
+// (they are the padded contraction range of the GEMM that reads `out` as its A operand).  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols, long long ld_in,
+                                                        long long stride_in, float* __restrict__ out, long long ld_out,
+                                                        long long stride_out) {
+    __shared__ float tile[32][33];
+    const float* src = in + (long long)blockIdx.z * stride_in;
+    float* dst = out + (long long)blockIdx.z * stride_out;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        tile[ty + k][tx] = (r < rows && c < cols) ? src[(long long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;                  // out row = c, out column = r
+        if (c < cols && r < ld_out) dst[(long long)c * ld_out + r] = tile[tx][ty + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------ embedding backward
+// x[m,:] = wte[ids[m]] + wpe[t(m)]  (modeling_gpt2.py:463-469)  =>  dwte[ids[m]] += dx[m], dwpe[t(m)] += dx[m].
+// Unordered float atomics, like torch's embedding backward on a GPU.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
+                                                            long long rows, int T, int d, int vocab, float* __restrict__ dwte,
+                                                            float* __restrict__ dwpe) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long long id = ids[row];
+    const int t = (int)(row % T);
+    if (id < 0 || id >= vocab) return;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dx[row * d + c];
+        atomicAdd(dwte + id * d + c, g);
+        atomicAdd(dwpe + (long long)t * d + c, g);
+    }
+}
+
+// dh[row, :] = d_pool[seq(row), :] / T   (torch.mean(h, dim=1) backward, train_retriever.py:181-183)
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ d_pool, long long rows, int T, int d,
+                                                           float* __restrict__ dh) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * d) return;
+    const long long row = i / d;
+    dh[i] = d_pool[(row / T) * d + i % d] / (float)T;
+}
+
+// ------------------------------------------------------------------------------------ optimizer
+// accum[0] += sum x^2 (one atomic per workgroup; the total feeds clip_grad_norm_, train_retriever.py:210)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ accum) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum_t(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(accum, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// transformers.AdamW.step (the optimizer utils/model.py:80-93 builds; third-party, restated from its published update):
+//   g <- g * min(1, max_norm / (sqrt(sumsq) + 1e-6))                      (torch.nn.utils.clip_grad_norm_)
+//   m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2
+//   p <- p - lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps);   p <- p - lr * wd * p        (decoupled decay, after)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float step_scale, const float* __restrict__ sumsq, float max_norm) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (sumsq && max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float pi = p[i] - lr * step_scale * mi / (sqrtf(vi) + eps);
+    if (wd > 0.f) pi -= lr * wd * pi;
+    p[i] = pi;
+}
+
+// ------------------------------------------------------------------------------------ launchers (used by train.hip)
+size_t ln_bwd_scratch_floats(int rows, int d) { return (size_t)2 * cdiv(rows, LNB_ROWS) * d; }
+
+int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* add, int rows, int d, float eps, float* dx,
+                  float* dw, float* db, float* scratch, int accumulate, hipStream_t s) {
+    R4D_REQUIRE(d % 64 == 0 && d <= 2048, "layernorm_bwd: d=%d must be a multiple of 64 and <= 2048", d);
+    if (rows <= 0) return R4D_OK;
+    const int nb = cdiv(rows, LNB_ROWS);
+    float* pw = scratch;
+    float* pb = scratch + (size_t)nb * d;
+    const size_t lds = (size_t)8 * d * sizeof(float);
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            R4D_HIP(hipFuncSetAttribute((const void*)ln_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), lds, s, x, w, dy, add, rows, d, eps, dx, pw, pb);
+    R4D_CHECK_LAUNCH("ln_bwd");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, pw, nb, d, dw, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, pb, nb, d, db, accumulate);
+    R4D_CHECK_LAUNCH("ln_bwd colsum");
+    return R4D_OK;
+}
+
+size_t colsum_scratch_floats(long long rows, int n) { return (size_t)cdiv((int)rows, CS_ROWS) * n; }
+
+int launch_colsum(const float* x, long long rows, int n, int ld, float* out, float* scratch, int accumulate, hipStream_t s) {
+    if (rows <= 0 || n <= 0) return R4D_OK;
+    const int nb = cdiv((int)rows, CS_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, 64), nb), dim3(256), 0, s, x, (int)rows, n, ld, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scratch, nb, n, out, accumulate);
+    R4D_CHECK_LAUNCH("colsum");
+    return R4D_OK;
+}
+
+int launch_gelu_fwd(const float* pre, long long n, float* y, hipStream_t s) {
+    if (n <= 0) return R4D_OK;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, y);
+    R4D_CHECK_LAUNCH("gelu_fwd");
+    return R4D_OK;
+}
+int launch_gelu_bwd(const float* pre, const float* dy, long long n, float* dx, hipStream_t s) {
+    if (n <= 0) return R4D_OK;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dy, n, dx);
+    R4D_CHECK_LAUNCH("gelu_bwd");
+    return R4D_OK;
+}
+int launch_softmax_bwd(const float* P, float* dP, int nbh, int T, int ld, float scale_div, hipStream_t s) {
+    R4D_REQUIRE(T >= 1 && T <= 1024 && ld >= T && ld <= 1024, "softmax_bwd: T=%d ld=%d out of range", T, ld);
+    const long long rows = (long long)nbh * T;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, P, dP, rows, T, ld, scale_div);
+    R4D_CHECK_LAUNCH("softmax_bwd");
+    return R4D_OK;
+}
+int launch_transpose(const float* in, int rows, int cols, long long ld_in, long long stride_in, float* out, long long ld_out,
+                     long long stride_out, int nbatch, hipStream_t s) {
+    R4D_REQUIRE(rows >= 1 && cols >= 1 && ld_in >= cols && ld_out >= rows && nbatch >= 1 && nbatch <= 65535,
+                "transpose: bad shape rows=%d cols=%d", rows, cols);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv((int)ld_out, 32), nbatch), dim3(256), 0, s, in, rows, cols,
+                       ld_in, stride_in, out, ld_out, stride_out);
+    R4D_CHECK_LAUNCH("transpose");
+    return R4D_OK;
+}
+int launch_embedding_bwd(const float* dx, const int64_t* ids, long long rows, int T, int d, int vocab, float* dwte, float* dwpe,
+                         hipStream_t s) {
+    if (rows <= 0) return R4D_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, T, d, vocab, dwte,
+                       dwpe);
+    R4D_CHECK_LAUNCH("embedding_bwd");
+    return R4D_OK;
+}
+int launch_meanpool_bwd(const float* d_pool, long long rows, int T, int d, float* dh, hipStream_t s) {
+    if (rows <= 0) return R4D_OK;
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, s, d_pool, rows, T, d, dh);
+    R4D_CHECK_LAUNCH("meanpool_bwd");
+    return R4D_OK;
+}
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" {
+
+size_t r4d_layernorm_bwd_workspace_bytes(int32_t rows, int32_t d) {
+    if (rows <= 0 || d <= 0) return 0;
+    return ln_bwd_scratch_floats(rows, d) * sizeof(float) + 256;
+}
+int r4d_layernorm_bwd_f32(const float* x_d, const float* w_d, const float* dy_d, const float* add_d, int32_t rows, int32_t d,
+                          float eps, float* dx_d, float* dw_d, float* db_d, void* workspace_d, size_t workspace_bytes,
+                          void* stream) {
+    R4D_REQUIRE(x_d && w_d && dy_d && dx_d && dw_d && db_d && workspace_d, "layernorm_bwd: null pointer");
+    R4D_REQUIRE(workspace_bytes >= r4d_layernorm_bwd_workspace_bytes(rows, d), "layernorm_bwd: workspace too small");
+    return launch_ln_bwd(x_d, w_d, dy_d, add_d, rows, d, eps, dx_d, dw_d, db_d, (float*)workspace_d, 0, (hipStream_t)stream);
+}
+int r4d_gelu_new_f32(const float* pre_d, int64_t n, float* y_d, void* stream) {
+    R4D_REQUIRE(pre_d && y_d && n >= 0, "gelu_new: bad arguments");
+    return launch_gelu_fwd(pre_d, n, y_d, (hipStream_t)stream);
+}
+int r4d_gelu_new_bwd_f32(const float* pre_d, const float* dy_d, int64_t n, float* dx_d, void* stream) {
+    R4D_REQUIRE(pre_d && dy_d && dx_d && n >= 0, "gelu_new_bwd: bad arguments");
+    return launch_gelu_bwd(pre_d, dy_d, n, dx_d, (hipStream_t)stream);
+}
+int r4d_causal_softmax_bwd_f32(const float* p_d, float* dp_d, int32_t nbh, int32_t T, int32_t ld, float scale_div, void* stream) {
+    R4D_REQUIRE(p_d && dp_d && nbh >= 1, "causal_softmax_bwd: bad arguments");
+    return launch_softmax_bwd(p_d, dp_d, nbh, T, ld, scale_div, (hipStream_t)stream);
+}
+int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* stream) {
+    R4D_REQUIRE(x_d && accum_d && n >= 0, "sumsq: bad arguments");
+    if (n == 0) return R4D_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_d, n, accum_d);
+    R4D_CHECK_LAUNCH("sumsq");
+    return R4D_OK;
+}
+int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
+                       void* stream) {
+    R4D_REQUIRE(p_d && g_d && m_d && v_d && n >= 0 && step >= 1, "adamw: bad arguments");
+    if (n == 0) return R4D_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_scale = (float)(sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_d, g_d, m_d, v_d, n, lr,
+                       beta1, beta2, eps, weight_decay, step_scale, grad_sumsq_d, max_grad_norm);
+    R4D_CHECK_LAUNCH("adamw");
+    return R4D_OK;
+}
+
+}  // extern "C"

@@ -127,3 +127,152 @@ def training_step_forward(args, model, batch, all_query_time, mask_nce=None):
     cl = CLtime_loss(args, emb[0], emb[1], emb[2], t[anchor_idx], t[pos_idx], t[neg_idx])
     au = args.alpha * info_nce(args, emb[3], emb[4], args.temperature, B, mask_nce)
     return dict(cl_loss=cl, aug_loss=au, loss=cl + au, embeddings=emb, aug1=aug1, aug2=aug2)
+
+
+# ------------------------------------------------------------------------------------------------ backward + optimizer
+import ctypes                                                                   # noqa: E402
+
+from . import _lib, ops                                                         # noqa: E402
+
+_LAYER_PARAMS = (("ln_1_w", "ln_1.weight"), ("ln_1_b", "ln_1.bias"), ("c_attn_w", "attn.c_attn.weight"),
+                 ("c_attn_b", "attn.c_attn.bias"), ("attn_proj_w", "attn.c_proj.weight"), ("attn_proj_b", "attn.c_proj.bias"),
+                 ("ln_2_w", "ln_2.weight"), ("ln_2_b", "ln_2.bias"), ("c_fc_w", "mlp.c_fc.weight"), ("c_fc_b", "mlp.c_fc.bias"),
+                 ("mlp_proj_w", "mlp.c_proj.weight"), ("mlp_proj_b", "mlp.c_proj.bias"))
+
+
+class EncoderTrainer:
+    """Forward-with-saved-activations and backward of the SimpleDyG encoder on the HIP kernels
+    (``r4d_gpt2_train_forward_f32`` / ``r4d_gpt2_train_backward_f32``), for a ``GPT2LMHeadModelRAG`` whose parameters live
+    on the GPU.  ``grads`` maps the reference's parameter names (``transformer.h.0.attn.c_attn.weight`` ...) to gradient
+    tensors; ``lm_head.weight`` has none (the retriever discards the logits) unless it is the tied ``wte`` Parameter."""
+
+    def __init__(self, model):
+        self.model = model
+        tr = model.transformer
+        self.params = {"transformer.wte.weight": tr.wte.weight, "transformer.wpe.weight": tr.wpe.weight,
+                       "transformer.ln_f.weight": tr.ln_f.weight, "transformer.ln_f.bias": tr.ln_f.bias}
+        for i, blk in enumerate(tr.h):
+            sd = dict(blk.named_parameters())
+            for _f, name in _LAYER_PARAMS:
+                self.params[f"transformer.h.{i}.{name}"] = sd[name]
+        for n, p in self.params.items():
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.R4DError(f"{n}: training needs contiguous fp32 parameters on the GPU (no CPU fallback)")
+        self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        self._ws = None
+        self._saved = None
+
+    def _structs(self):
+        tr = self.model.transformer
+        cfg = tr.config
+        c = _lib.GPT2ConfigC(cfg.n_layer, cfg.n_head, cfg.n_embd, tr.wte.num_embeddings, tr.wpe.num_embeddings,
+                             cfg.layer_norm_epsilon)
+        layers = (_lib.GPT2LayerC * cfg.n_layer)()
+        glayers = (_lib.GPT2LayerGradsC * cfg.n_layer)()
+        for i in range(cfg.n_layer):
+            vals = [self.params[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS]
+            layers[i] = _lib.GPT2LayerC(*vals, None, None, None, None)                       # no wT copies: weights change
+            glayers[i] = _lib.GPT2LayerGradsC(*[self.grads[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS])
+        w = _lib.GPT2WeightsC(tr.wte.weight.data_ptr(), tr.wpe.weight.data_ptr(), tr.ln_f.weight.data_ptr(),
+                              tr.ln_f.bias.data_ptr(), layers, None)
+        g = _lib.GPT2GradsC(self.grads["transformer.wte.weight"].data_ptr(), self.grads["transformer.wpe.weight"].data_ptr(),
+                            self.grads["transformer.ln_f.weight"].data_ptr(), self.grads["transformer.ln_f.bias"].data_ptr(), glayers)
+        return c, w, g, (layers, glayers)
+
+    @torch.no_grad()
+    def forward(self, batches):
+        """Mean-pooled embeddings [sum B, d] of the right-padded id batches; keeps the activations for ``backward``."""
+        ids = [b.view(-1, b.shape[-1]).to(torch.int64).contiguous() for b in batches]
+        n, dev = len(ids), ids[0].device
+        lib = _lib.load()
+        c, w, g, keep = self._structs()
+        Bs = (ctypes.c_int32 * n)(*[int(t.shape[0]) for t in ids])
+        Ts = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in ids])
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ids])
+        nbytes = lib.r4d_gpt2_train_workspace_bytes(ctypes.byref(c), n, Bs, Ts)
+        if nbytes == 0:
+            raise _lib.R4DError("gpt2 train: bad batch shapes")
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        out = torch.empty(sum(int(t.shape[0]) for t in ids), self.model.config.n_embd, dtype=torch.float32, device=dev)
+        _lib.check(lib.r4d_gpt2_train_forward_f32(ctypes.byref(c), ctypes.byref(w), n, ptrs, Bs, Ts, out.data_ptr(),
+                                                  self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "gpt2_train_forward")
+        self._saved = (ids, n, Bs, Ts, ptrs)
+        return out
+
+    @torch.no_grad()
+    def backward(self, d_embeddings):
+        """dLoss/d(embeddings) [sum B, d] -> ``self.grads`` (overwritten)."""
+        if self._saved is None:
+            raise RuntimeError("backward() before forward()")
+        ids, n, Bs, Ts, ptrs = self._saved
+        lib = _lib.load()
+        c, w, g, keep = self._structs()
+        de = d_embeddings.to(torch.float32).contiguous()
+        _lib.check(lib.r4d_gpt2_train_backward_f32(ctypes.byref(c), ctypes.byref(w), ctypes.byref(g), n, ptrs, Bs, Ts, de.data_ptr(),
+                                                   self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "gpt2_train_backward")
+        self._saved = None
+        return self.grads
+
+
+class AdamW:
+    """``transformers.AdamW`` as ``utils/model.py:80-93`` configures it -- bias correction on, decoupled weight decay applied
+    after the update, no decay for names containing ``bias`` / ``LayerNorm.weight`` (the GPT-2 LayerNorms are called ln_1 /
+    ln_2 / ln_f, so their gains DO decay: upstream quirk kept) -- with ``clip_grad_norm_`` folded in: the squared norm of
+    all gradients is accumulated on the device and every update kernel scales its gradient by the clip coefficient."""
+
+    def __init__(self, params, grads, lr, eps=1e-8, weight_decay=0.0, betas=(0.9, 0.999)):
+        self.params, self.grads = params, grads
+        self.lr, self.eps, self.betas = lr, eps, betas
+        no_decay = ("bias", "LayerNorm.weight")
+        self.wd = {n: (0.0 if any(nd in n for nd in no_decay) else weight_decay) for n in params}
+        self.m = {n: torch.zeros_like(p) for n, p in params.items()}
+        self.v = {n: torch.zeros_like(p) for n, p in params.items()}
+        self.t = 0
+        dev = next(iter(params.values())).device
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def step(self, max_grad_norm=0.0):
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        self.t += 1
+        self.sumsq.zero_()
+        if max_grad_norm and max_grad_norm > 0:
+            for n, g in self.grads.items():
+                _lib.check(lib.r4d_sumsq_accumulate_f32(g.data_ptr(), g.numel(), self.sumsq.data_ptr(), stream), "sumsq")
+        for n, p in self.params.items():
+            _lib.check(lib.r4d_adamw_step_f32(p.data_ptr(), self.grads[n].data_ptr(), self.m[n].data_ptr(), self.v[n].data_ptr(),
+                                              p.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              float(self.wd[n]), self.t, self.sumsq.data_ptr() if max_grad_norm else None,
+                                              float(max_grad_norm or 0.0), stream), "adamw")
+
+    def grad_norm(self):
+        return float(self.sumsq.sqrt().item())
+
+
+def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None):
+    """One iteration of ``train_epoch`` (``train/train_retriever.py:164-214``) on the device: five forwards (one launch
+    sequence), the two contrastive losses (torch autograd over the [5, B, d] embeddings only), the encoder's backward pass,
+    gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss)."""
+    anchor_seq, pos_seq, neg_seq, anchor_idx, pos_idx, neg_idx = batch
+    dev = args.device
+    anchor_seq, pos_seq, neg_seq = anchor_seq.to(dev), pos_seq.to(dev), neg_seq.to(dev)
+    aug1, aug2 = aug(anchor_seq, model.config.eta, model.config.gamma, model.config.vocab_size - 1)
+    B = anchor_seq.size(0)
+    emb = trainer.forward([anchor_seq, pos_seq, neg_seq, aug1, aug2])
+    leaf = emb.view(5, B, -1).detach().requires_grad_(True)
+    with torch.enable_grad():
+        t = all_query_time
+        cl = CLtime_loss(args, leaf[0], leaf[1], leaf[2], t[anchor_idx], t[pos_idx], t[neg_idx])
+        au = args.alpha * info_nce(args, leaf[3], leaf[4], args.temperature, B, mask_nce)
+        loss = cl + au
+        if getattr(args, "gradient_accumulation_steps", 1) > 1:
+            loss = loss / args.gradient_accumulation_steps
+        loss.backward()
+    trainer.backward(leaf.grad.view(5 * B, -1))
+    optimizer.step(getattr(args, "max_grad_norm", 0.0))
+    model.transformer.__dict__.pop("_wt_cache", None)            # transposed weight copies of the inference path are stale now
+    return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()))
