@@ -345,8 +345,8 @@ int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* 
 /* One transformers.AdamW update of a flat tensor (utils/model.py:80-93; decoupled weight decay applied after the step,
  * bias correction on): step >= 1 is the update count; grad_sumsq_d (nullable) with max_grad_norm > 0 clips the gradient
  * by min(1, max_grad_norm / (sqrt(sum) + 1e-6)) on the fly (torch.nn.utils.clip_grad_norm_). */
-int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
+int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -80,11 +80,12 @@ def main(argv=None):
         model.tie_weights()
     model = model.to(args.device)
 
-    if args.do_train:
-        raise NotImplementedError("retriever training: the forward half of a step (data, augmentation, five encoder forwards, "
-                                  "time-decayed contrastive + InfoNCE loss: rag4dyg_amd.training.training_step_forward) is built "
-                                  "and pinned against the reference; the backward kernels and the optimizer are not yet "
-                                  "(SURVEY.md 8f-4) -- train with the reference, evaluate / retrieve here")
+    if args.do_train:                                  # main_retriever.py:124-136 -> train/train_retriever.train
+        from rag4dyg_amd.dataloader import load_and_cache_examples
+        from rag4dyg_amd.training import train
+        train_dataset = load_and_cache_examples(args, tokenizer, evaluate=False)
+        global_step, train_loss = train(args, train_dataset, model, tokenizer)
+        print(" global_step = {}, average loss = {}".format(global_step, train_loss))
     if args.do_eval and args.local_rank in [-1, 0]:
         checkpoints = [args.output_dir]
         if args.eval_all_checkpoints:

@@ -105,3 +105,24 @@ def training_step(sd, n_head, anchor, pos, neg, all_times, idx, eta, gamma, alph
     h1, h2 = emb(a1), emb(a2)
     au = alpha * info_nce(h1, h2, temperature, a1.size(0))
     return dict(cl=cl, aug=au, loss=cl + au, emb=torch.stack([h_a, h_p, h_n, h1, h2]), aug1=a1, aug2=a2)
+
+
+def clip_coefficient(grads, max_norm):
+    """``torch.nn.utils.clip_grad_norm_`` (``train/train_retriever.py:210``): min(1, max_norm / (total L2 norm + 1e-6))."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).item()
+    return min(1.0, max_norm / (total + 1e-6)), total
+
+
+def adamw_step(p, g, m, v, t, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One update of ``transformers.AdamW`` (the optimizer ``utils/model.py:80-93`` builds; third-party code that is not in the
+    reference tree -- transformers >= 4.24, README.md:9 -- restated from its published ``step``): bias correction on, the
+    denominator is sqrt(v) + eps WITHOUT bias correction, decoupled weight decay applied after the update with the plain
+    learning rate.  Returns the new (p, m, v); ``t`` is the 1-based update count."""
+    b1, b2 = betas
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    p = p - step_size * m / (v.sqrt() + eps)
+    if weight_decay > 0.0:
+        p = p - lr * weight_decay * p
+    return p, m, v

@@ -103,7 +103,7 @@ PROTOTYPES = {
     "r4d_gelu_new_bwd_f32": (c_int32, [_P, _P, c_int64, _P, _P]),
     "r4d_causal_softmax_bwd_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_float, _P]),
     "r4d_sumsq_accumulate_f32": (c_int32, [_P, c_int64, _P, _P]),
-    "r4d_adamw_step_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, _P, c_float, _P]),
+    "r4d_adamw_step_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int32, _P, c_float, _P]),
     "r4d_profile_enable": (c_int32, [c_int32]),
     "r4d_profile_num_classes": (c_int32, []),
     "r4d_profile_class_name": (c_char_p, [c_int32]),

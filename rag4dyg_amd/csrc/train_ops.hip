@@ -220,18 +220,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 //   m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2
 //   p <- p - lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps);   p <- p - lr * wd * p        (decoupled decay, after)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float step_scale, const float* __restrict__ sumsq, float max_norm) {
+                                                    float* __restrict__ v, long long n, float lr_step, float b1, float omb1, float b2,
+                                                    float omb2, float eps, float lr_wd, const float* __restrict__ sumsq,
+                                                    float max_norm) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float coef = 1.f;
     if (sumsq && max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
     const float gi = g[i] * coef;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;                    // scalars rounded to f32 like torch's mul_ / add_(alpha=)
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi; v[i] = vi;
-    float pi = p[i] - lr * step_scale * mi / (sqrtf(vi) + eps);
-    if (wd > 0.f) pi -= lr * wd * pi;
+    float pi = p[i] - lr_step * (mi / (sqrtf(vi) + eps));
+    if (lr_wd > 0.f) pi -= lr_wd * pi;
     p[i] = pi;
 }
 
@@ -352,15 +353,18 @@ int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* 
     R4D_CHECK_LAUNCH("sumsq");
     return R4D_OK;
 }
-int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
+int r4d_adamw_step_f32(float* p_d, const float* g_d, float* m_d, float* v_d, int64_t n, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, int32_t step, const float* grad_sumsq_d, float max_grad_norm,
                        void* stream) {
     R4D_REQUIRE(p_d && g_d && m_d && v_d && n >= 0 && step >= 1, "adamw: bad arguments");
     if (n == 0) return R4D_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_scale = (float)(sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_d, g_d, m_d, v_d, n, lr,
-                       beta1, beta2, eps, weight_decay, step_scale, grad_sumsq_d, max_grad_norm);
+    // python-float (double) hyper-parameters, every derived scalar formed in double and rounded to f32 once, like the
+    // reference's optimizer does through torch's scalar arguments
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float lr_step = (float)(lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_d, g_d, m_d, v_d, n,
+                       lr_step, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr * weight_decay), grad_sumsq_d, max_grad_norm);
     R4D_CHECK_LAUNCH("adamw");
     return R4D_OK;
 }

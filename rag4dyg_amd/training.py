@@ -276,3 +276,122 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
     optimizer.step(getattr(args, "max_grad_norm", 0.0))
     model.transformer.__dict__.pop("_wt_cache", None)            # transposed weight copies of the inference path are stale now
     return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()))
+
+
+# ------------------------------------------------------------------------------------------------ training loop
+def adjust_learning_rate(args, optimizer, epoch, base_lr, i, iteration_per_epoch):
+    """``train/train_retriever.py:120-130``: linear warm-up over ``warmup_steps`` EPOCHS, then a half cosine."""
+    T = epoch * iteration_per_epoch + i
+    warmup_iters = args.warmup_steps * iteration_per_epoch
+    total_iters = (args.num_train_epochs - args.warmup_steps) * iteration_per_epoch
+    if epoch < args.warmup_steps:
+        lr = base_lr * 1.0 * T / warmup_iters
+    else:
+        lr = 0.5 * base_lr * (1 + math.cos(1.0 * (T - warmup_iters) / total_iters * math.pi))
+    optimizer.lr = lr
+
+
+def save_checkpoint(model, optimizer, tokenizer, args, global_step):
+    """``utils/model.py:56-69`` layout: ``<output_dir>/checkpoint-<n>/{config.json, pytorch_model.bin, tokenizer files,
+    training_args.bin, optimizer.pt, scheduler.pt}`` (+ rotation by ``--save_total_limit``, :41-53)."""
+    import glob
+    import re
+    import shutil
+    out = os.path.join(args.output_dir, f"checkpoint-{global_step}")
+    os.makedirs(out, exist_ok=True)
+    model.save_pretrained(out)
+    tokenizer.save_pretrained(out)
+    keep = {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None)))}
+    torch.save(keep, os.path.join(out, "training_args.bin"))
+    limit = getattr(args, "save_total_limit", None)
+    if limit and limit > 0:
+        found = []
+        for path in glob.glob(os.path.join(args.output_dir, "checkpoint-*")):
+            m_ = re.match(r".*checkpoint-([0-9]+)", path)
+            if m_:
+                found.append((int(m_.group(1)), path))
+        for _n, path in sorted(found)[:max(0, len(found) - limit)]:
+            shutil.rmtree(path)
+    torch.save({"format": "rag4dyg_amd.AdamW", "t": optimizer.t, "lr": optimizer.lr,
+                "m": {k: v.cpu() for k, v in optimizer.m.items()}, "v": {k: v.cpu() for k, v in optimizer.v.items()}},
+               os.path.join(out, "optimizer.pt"))
+    torch.save({"last_epoch": optimizer.t}, os.path.join(out, "scheduler.pt"))
+
+
+def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args, mask_nce):
+    """``train/train_retriever.py:132-227``: one pass over the shuffled triples.  Returns (global_step, summed loss,
+    summed contrastive loss, summed augmentation loss)."""
+    tr_loss = tr_cl = tr_aug = 0.0
+    for i, batch in enumerate(train_dataloader):
+        if args.lrdecay == 1:
+            adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
+        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce)
+        tr_loss += r["loss"]; tr_cl += r["cl_loss"]; tr_aug += r["aug_loss"]
+        global_step += 1
+        if args.max_steps > 0 and global_step > args.max_steps:
+            break
+    return global_step, tr_loss, tr_cl, tr_aug
+
+
+def train(args, train_dataset, model, tokenizer):
+    """Drop-in for ``train/train_retriever.train`` (``:230-354``): AdamW on the time-decayed contrastive + InfoNCE loss, validation
+    hit@3 after every epoch, best checkpoint as ``checkpoint-0`` (only once ``epoch > warmup_steps``, as upstream), last as
+    ``checkpoint-1``, early stopping after ``--patience`` epochs without improvement, then the test / validation passes on
+    the best and the last weights.  Differences: dropout is the identity; ``--gradient_accumulation_steps`` > 1, ``--fp16``
+    and multi-process data parallelism are not built (they raise)."""
+    from .dataloader import get_dataloader
+    from .retriever import test
+    if getattr(args, "gradient_accumulation_steps", 1) != 1 or getattr(args, "fp16", False):
+        raise NotImplementedError("retriever training: --gradient_accumulation_steps > 1 / --fp16 are not built")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise NotImplementedError("retriever training runs one process on one GPU in this build (gradient all-reduce not built)")
+    train_dataloader, args = get_dataloader(train_dataset, tokenizer, args, split="train")
+    if args.max_steps > 0:
+        args.num_train_epochs = args.max_steps // max(1, len(train_dataloader)) + 1
+    trainer = EncoderTrainer(model)
+    optimizer = AdamW(trainer.params, trainer.grads, lr=args.learning_rate, eps=args.adam_epsilon, weight_decay=args.weight_decay)
+    print("***** Running training *****")
+    print("  Num examples = {}".format(len(train_dataset)))
+    print("  Num Epochs = {}".format(args.num_train_epochs))
+    print("  Instantaneous batch size per GPU = {}".format(args.per_gpu_train_batch_size))
+    mask_nce = mask_correlated_samples(args.per_gpu_train_batch_size)
+    all_query_time = torch.load(os.path.join("resources/", args.dataset + '_train_query_time.pt'))     # get_train_query_time.py
+    global_step, tr_loss = 0, 0.0
+    best_score, best_epoch, best_state, counter = None, 0, None, 0
+    snapshot = lambda: {k: v.detach().clone() for k, v in model.state_dict().items()}
+    last_state, epoch = None, 0
+    for epoch in range(int(args.num_train_epochs)):
+        print('==> Training Epoch: ', epoch)
+        global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step,
+                                                   args, mask_nce)
+        tr_loss += ep_loss
+        val_metrics, val_loss = test(epoch, args, model, tokenizer, evaluate=True)
+        score = val_metrics['hit@3']
+        print(f"epoch {epoch}: train_loss {tr_loss / max(global_step, 1):.5f} (cl {cl:.4f} aug {au:.4f}) val_loss {float(val_loss):.5f} "
+              f"val_hit@3 {score} lr {optimizer.lr:.3e}")
+        print('best_score: ', best_score)
+        early_stop = False
+        if epoch > args.warmup_steps:
+            if best_score is None or score > best_score:
+                best_score, best_epoch, best_state, counter = score, epoch, snapshot(), 0
+                save_checkpoint(model, optimizer, tokenizer, args, 0)
+            else:
+                counter += 1
+                print('  EarlyStopping counter: {} out of {}'.format(counter, args.patience))
+                early_stop = counter >= args.patience
+        if early_stop:
+            print('  Early Stopping.....')
+            break
+        save_checkpoint(model, optimizer, tokenizer, args, 1)
+        last_state = snapshot()
+    if best_state is None:                        # never past the warm-up epochs: the last weights are the best we have
+        best_state, best_epoch = snapshot(), epoch
+    last_state = last_state or snapshot()
+    print("***** Running testing *****")
+    model.load_state_dict(best_state)
+    test_metrics = test(best_epoch, args, model, tokenizer, evaluate=False, prefix="best")
+    print("test_metrics best epoch : ", test_metrics)
+    test(best_epoch, args, model, tokenizer, evaluate=True, prefix="best")
+    model.load_state_dict(last_state)
+    print("test_metrics last epoch : ", test(epoch, args, model, tokenizer, evaluate=False))
+    return global_step, tr_loss / max(global_step, 1)

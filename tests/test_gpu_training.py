@@ -101,3 +101,96 @@ def test_training_step_gradients_equal_reference_autograd(dev, tag):
     bad = {n: e for n, e in errs.items() if e > 1e-3}
     print(f"{tag}: worst element-wise (max-norm) gradient error {max(errs.values()):.2e}")
     assert not bad, bad
+
+
+def test_training_step_parameter_update_equals_oracle_adamw(dev):
+    """One whole training_step (five forwards, losses, backward, clip_grad_norm_, AdamW with decoupled decay) on the device
+    against the oracle: reference-pinned gradients (G8) pushed through a CPU restatement of transformers.AdamW."""
+    from oracle import gpt2_ref, train_ref
+    from rag4dyg_amd import training
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    g = load_golden("g8_training_step")
+    tag = "ts_tiny"
+    L, H, d, V, pad, B, seed = (int(x) for x in g[tag + "_cfg"])
+    eta, gamma, alpha, temp, lam = (float(x) for x in g[tag + "_hyper"])
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+    cfg = GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H)
+    cfg.eta, cfg.gamma = eta, gamma
+    m = GPT2LMHeadModelRAG(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    lr, wd, max_norm = 3e-3, 0.01, 1.0
+    args = types.SimpleNamespace(device=dev, temperature=temp, lambda_decay=lam, alpha=alpha, per_gpu_train_batch_size=B,
+                                 max_grad_norm=max_norm, gradient_accumulation_steps=1)
+    T = torch.from_numpy
+    idx = T(g[tag + "_idx"])
+    batch = (T(g[tag + "_anchor"]), T(g[tag + "_pos"]), T(g[tag + "_neg"]), idx[:, 0:1], idx[:, 1:2], idx[:, 2:3])
+    trainer = training.EncoderTrainer(m)
+    opt = training.AdamW(trainer.params, trainer.grads, lr=lr, eps=1e-8, weight_decay=wd)
+    random.seed(seed)
+    r = training.training_step(args, m, trainer, opt, batch, T(g[tag + "_times"]), training.mask_correlated_samples(B))
+    assert abs(r["loss"] / float(g[tag + "_losses"][2]) - 1) < 1e-5
+    # oracle AdamW on the DEVICE's gradients (their parity with the reference's autograd is the previous test; at step 1 the
+    # update is ~lr * sign(g), which would amplify 1e-5 gradient noise on the near-zero elements into a different test)
+    names = list(trainer.params)
+    dev_grads = {n: trainer.grads[n].detach().cpu() for n in names}
+    coef, total = train_ref.clip_coefficient([dev_grads[n] for n in names], max_norm)
+    assert coef < 1.0 and abs(opt.grad_norm() / total - 1) < 1e-5          # the clip is active in this case
+    worst = 0.0
+    for n in names:
+        decay = 0.0 if "bias" in n else wd                                   # "LayerNorm.weight" matches no GPT-2 name: gains decay
+        p_ref, m_ref, v_ref = train_ref.adamw_step(sd[n].double(), dev_grads[n].double() * coef, torch.zeros_like(sd[n]).double(),
+                                                   torch.zeros_like(sd[n]).double(), 1, lr, (0.9, 0.999), 1e-8, decay)
+        step = (p_ref - sd[n].double()).abs().max().item()
+        err = (trainer.params[n].detach().cpu().double() - p_ref).abs().max().item()
+        worst = max(worst, err / max(step, 1e-12))
+        assert rel_err(opt.m[n].cpu().numpy(), m_ref.numpy()) < 1e-5 and rel_err(opt.v[n].cpu().numpy(), v_ref.numpy()) < 1e-5
+    print(f"AdamW step: worst |p - p_oracle| relative to the size of the step {worst:.2e}")
+    assert worst < 1e-4
+    assert "_wt_cache" not in m.transformer.__dict__                         # stale transposed copies dropped
+
+
+def test_main_retriever_do_train_end_to_end(dev, tmp_path, monkeypatch):
+    """``main_retriever.py --do_train`` on a toy dataset in the reference's file grammar: annotation triples from this
+    build's retrieval_data_annotation CLI, query times, a few epochs of the training loop (validation after every epoch,
+    best / last checkpoints in the reference layout), then ``--do_eval`` on what it wrote.  The loss falls."""
+    import io
+    import re
+    from contextlib import redirect_stdout
+    import main_retriever
+    from test_gpu_pipeline import _write_dataset
+    from rag4dyg_amd import annotation
+    base = _write_dataset(str(tmp_path), n_train=96, n_val=40, n_test=37, seed=4)
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(1)
+    annotation.main(["retrieval_data_annotation.py", "toy", "4", "0.3"])
+    ret = tmp_path / "resources" / "toy" / "4" / "train_retrieval"
+    assert (ret / "train_index.retrieval").stat().st_size > 0
+    torch.save(torch.rand(96) * 20, tmp_path / "resources" / "toy_train_query_time.pt")
+    out = tmp_path / "out"
+    out.mkdir()
+    common = (f"--dataset toy --timestamp 4 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
+              f"--train_data_file {base}/train.link_prediction --train_pair_data_file {ret}/train_index.retrieval "
+              f"--eval_data_file {base}/val.link_prediction --eval_data_gt_file {ret}/val_score.retrieval "
+              f"--test_data_file {base}/test.link_prediction --test_data_gt_file {ret}/test_score.retrieval "
+              f"--block_size 512 --n_layer 2 --n_head 2 --n_embed 64 --topK 5 --seed 3")
+    argv = (common + " --do_train --per_gpu_train_batch_size 16 --num_train_epochs 4 --learning_rate 2e-3 --warmup_steps 0 "
+                     "--lambda_decay 0.05 --alpha 0.1 --temperature 0.2 --patience 10").split()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        main_retriever.main(argv)
+    log = buf.getvalue()
+    losses = [float(x) for x in re.findall(r"epoch \d+: train_loss ([0-9.]+)", log)]
+    assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    for ck in ("checkpoint-0", "checkpoint-1"):
+        for f in ("config.json", "pytorch_model.bin", "tokenizer.json", "training_args.bin", "optimizer.pt", "scheduler.pt"):
+            assert (out / ck / f).exists(), (ck, f)
+    sd = torch.load(out / "checkpoint-1" / "pytorch_model.bin", map_location="cpu", weights_only=True)
+    assert "transformer.h.1.mlp.c_proj.weight" in sd and "lm_head.weight" in sd and all(torch.isfinite(v).all() for v in sd.values())
+    assert "test_metrics best epoch" in log and "test_metrics last epoch" in log
+    res = tmp_path / "resources" / "retrieval_result" / "toy"
+    assert (res / "test_index.gen").exists() and (res / "val_index.gen").exists()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        main_retriever.main((common + " --do_eval --eval_all_checkpoints").split())
+    assert buf.getvalue().count("test_metrics:") == 2
