@@ -329,6 +329,11 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
                                 int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
                                 const float* d_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Single backward ops, exported for per-op parity tests (the kernels the step launches). */
+/* Conv1D parameter gradients (modeling_utils.py:1267-1271 under autograd): dw_d [in,out] = x^T . dy, db_d [out] (nullable) =
+ * column sums of dy, for x_d [rows,in] and dy_d [rows,out]; in / out multiples of 4. */
+size_t r4d_weight_grad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features);
+int r4d_weight_grad_f32(const float* x_d, const float* dy_d, int32_t rows, int32_t in_features, int32_t out_features, float* dw_d,
+                        float* db_d, void* workspace_d, size_t workspace_bytes, void* stream);
 size_t r4d_layernorm_bwd_workspace_bytes(int32_t rows, int32_t d);
 /* dx = dLayerNorm/dx (+ add_d when given; add_d may be dx_d), dw / db = gains' and shifts' gradients (overwritten). */
 int r4d_layernorm_bwd_f32(const float* x_d, const float* w_d, const float* dy_d, const float* add_d, int32_t rows, int32_t d,

@@ -97,6 +97,8 @@ PROTOTYPES = {
                                              POINTER(c_int32), _P, _P, c_size_t, _P]),
     "r4d_gpt2_train_backward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GPT2GradsC), c_int32, POINTER(_P),
                                               POINTER(c_int32), POINTER(c_int32), _P, _P, c_size_t, _P]),
+    "r4d_weight_grad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "r4d_weight_grad_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "r4d_layernorm_bwd_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "r4d_gelu_new_f32": (c_int32, [_P, c_int64, _P, _P]),

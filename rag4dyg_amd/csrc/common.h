@@ -77,6 +77,10 @@ struct GemmArgs {
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given as [N,K]: k-contiguous kernel
+// C[M,N] = A[Kt,M]^T . B[Kt,N] (weight gradients), split-K partials in scratch (gemm_tn_scratch_floats floats)
+size_t gemm_tn_scratch_floats(int M, int N, int Kt);
+int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, int Kt, int lda, int ldb, float* scratch,
+                       hipStream_t stream);
 // gemm_skinny.hip: M <= 32 rows against a k-contiguous weight [N,K], K % 256 == 0 (decode step); split-K partials in scratch
 bool gemm_skinny_supported(int M, int K, int N);
 size_t gemm_skinny_scratch_floats(int K, int N);

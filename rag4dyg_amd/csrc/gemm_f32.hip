@@ -16,6 +16,7 @@
 // double-buffered and the next k-tile's global loads are issued before the MFMA phase (one barrier per
 // k-tile).  Tile shape is picked per launch by a wave-quantisation cost model (launch_gemm_f32).
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace r4d {
@@ -58,18 +59,23 @@ struct FragLoad<4> {
 // knows they are global (pointers inside a by-value struct are treated as generic -> flat_load, whose
 // out-of-order return couples every LDS wait to the global loads in flight).
 struct GemmShape {
-    int M, N, K, lda, ldb, ldc, ldr, b_rows, a_cols, nb1, epilogue, causal;
+    int M, N, K, lda, ldb, ldc, ldr, b_rows, a_cols, nb1, epilogue, causal, k_total;
     long long sA0, sA1, sB0, sB1, sC0, sC1;
     float scale_div;
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool BT>
+// AT: A is given as [K,M] (m-contiguous rows of k; weight gradients X^T . dY contract over the token rows of both
+// operands): its LDS image is a straight copy like a row-major B.  With g.k_total > 0 the launch is a split-K one: batch z
+// contracts rows [z*K, min((z+1)*K, k_total)) and writes its own partial C (reduced by splitk_reduce_kernel).
+template <int BM, int BN, int BK, int WGM, int WGN, bool BT, bool AT = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm_f32_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg,
                                                             float* __restrict__ Cg, const float* __restrict__ biasg,
                                                             const float* __restrict__ residg, const GemmShape g) {
     constexpr int NTHREADS = 64 * WGM * WGN;                          // WGM x WGN wavefronts
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    constexpr int LDA = BM + 2;                                      // even: keeps ds_read_b64 aligned
+    // A^T-on-write image: BM + 2 (even: keeps ds_read_b64 aligned).  Straight-copy image (AT): unpadded like a row-major B
+    // (the two k-rows of a fragment read belong to different 32-lane halves, which never conflict)
+    constexpr int LDA = AT ? BM : BM + 2;
     constexpr int LDB = BT ? BN + 2 : BN;
     constexpr int KV = BK / 4;                                       // float4 per tile row
     constexpr int NLA = BM * KV / NTHREADS;                          // float4 loads per thread, A tile
@@ -102,6 +108,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
 
     int kend = g.K;
     if (g.causal == CAUSAL_PV) kend = min(g.K, m0 + BM);             // keys beyond the tile's last row are masked
+    const int krows = g.k_total > 0 ? min(g.K, g.k_total - (int)blockIdx.z * g.K) : g.b_rows;   // valid rows of a [K,*] operand
+    if (g.k_total > 0) kend = krows;
     const int nkt = (kend + BK - 1) / BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -114,11 +122,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     const float* a_src[NLA]; bool a_ok[NLA]; int a_dst[NLA], a_k[NLA];
 #pragma unroll
     for (int r = 0; r < NLA; ++r) {
-        const int idx = tid + r * NTHREADS, row = idx / KV, c4 = idx % KV;
-        a_ok[r] = (m0 + row) < g.M;
-        a_k[r] = 4 * c4;
-        a_src[r] = A + (long long)min(m0 + row, g.M - 1) * g.lda + 4 * c4;
-        a_dst[r] = (4 * c4) * LDA + row;
+        const int idx = tid + r * NTHREADS;
+        if (AT) {
+            const int krow = idx / (BM / 4), c = idx % (BM / 4);
+            a_ok[r] = (m0 + 4 * c) < g.M;
+            a_k[r] = krow;
+            a_src[r] = A + (a_ok[r] ? m0 + 4 * c : 0);
+            a_dst[r] = krow * LDA + 4 * c;
+        } else {
+            const int row = idx / KV, c4 = idx % KV;
+            a_ok[r] = (m0 + row) < g.M;
+            a_k[r] = 4 * c4;
+            a_src[r] = A + (long long)min(m0 + row, g.M - 1) * g.lda + 4 * c4;
+            a_dst[r] = (4 * c4) * LDA + row;
+        }
     }
     const float* b_src[NLB]; bool b_ok[NLB]; int b_dst[NLB], b_k[NLB];
 #pragma unroll
@@ -149,9 +166,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     {                                                                                                              \
         const int k0_ = (KT) * BK;                                                                                 \
         _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
-            const bool kin_ = k0_ + a_k[r] < g.a_cols;                                                             \
-            ra_ok[r] = a_ok[r] && kin_;                                                                            \
-            ra[r] = *reinterpret_cast<const float4*>(a_src[r] + (kin_ ? k0_ : 0));                                 \
+            if (AT) {                                                                                              \
+                const int gk_ = k0_ + a_k[r];                                                                      \
+                ra_ok[r] = a_ok[r] && (gk_ < krows);                                                               \
+                ra[r] = *reinterpret_cast<const float4*>(a_src[r] + (long long)min(gk_, krows - 1) * g.lda);       \
+            } else {                                                                                               \
+                const bool kin_ = k0_ + a_k[r] < g.a_cols;                                                         \
+                ra_ok[r] = a_ok[r] && kin_;                                                                        \
+                ra[r] = *reinterpret_cast<const float4*>(a_src[r] + (kin_ ? k0_ : 0));                             \
+            }                                                                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
             if (BT) {                                                                                              \
@@ -160,8 +183,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
                 rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (kin_ ? k0_ : 0));                             \
             } else {                                                                                               \
                 const int gk_ = k0_ + b_k[r];                                                                      \
-                rb_ok[r] = b_ok[r] && (gk_ < g.b_rows);                                                            \
-                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (long long)min(gk_, g.b_rows - 1) * g.ldb);    \
+                rb_ok[r] = b_ok[r] && (gk_ < krows);                                                               \
+                rb[r] = *reinterpret_cast<const float4*>(b_src[r] + (long long)min(gk_, krows - 1) * g.ldb);       \
             }                                                                                                      \
         }                                                                                                          \
     }
@@ -169,8 +192,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     {                                                                                                              \
         _Pragma("unroll") for (int r = 0; r < NLA; ++r) {                                                          \
             R4D_ZERO_UNLESS(ra[r], ra_ok[r])                                                                       \
-            float* p = &As[BUF][a_dst[r]];                                                                         \
-            p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;                          \
+            if (AT) {                                                                                              \
+                *reinterpret_cast<float4*>(&As[BUF][a_dst[r]]) = ra[r];                                            \
+            } else {                                                                                               \
+                float* p = &As[BUF][a_dst[r]];                                                                     \
+                p[0] = ra[r].x; p[LDA] = ra[r].y; p[2 * LDA] = ra[r].z; p[3 * LDA] = ra[r].w;                      \
+            }                                                                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int r = 0; r < NLB; ++r) {                                                          \
             R4D_ZERO_UNLESS(rb[r], rb_ok[r])                                                                       \
@@ -280,6 +307,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void gemm
     }
 }
 
+// C[M,N] = sum over the S split-K partials part[s][M][N] (fixed order: deterministic), float4 per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long long mn4, int S,
+                                                            float* __restrict__ C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn4) return;
+    const float4* p = reinterpret_cast<const float4*>(part) + i;
+    float4 a = p[0];
+    for (int s = 1; s < S; ++s) {
+        const float4 b = p[(long long)s * mn4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(C)[i] = a;
+}
+
 // ---------------------------------------------------------------------------------------------- dispatch
 struct TileCfg { int bm, bn, cls, blocks_per_cu, waves_per_block; double eff; };
 // eff = steady-state fraction of the f32 MFMA peak measured for the tile on a saturating grid
@@ -306,7 +347,7 @@ static int launch_variant(const GemmArgs& g, int cls, hipStream_t stream) {
     sh.M = g.M; sh.N = g.N; sh.K = g.K; sh.lda = g.lda; sh.ldb = g.ldb; sh.ldc = g.ldc; sh.ldr = g.ldr;
     sh.b_rows = g.b_rows; sh.a_cols = g.a_cols; sh.nb1 = g.nb1; sh.epilogue = g.epilogue; sh.causal = g.causal;
     sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
-    sh.scale_div = g.scale_div;
+    sh.scale_div = g.scale_div; sh.k_total = 0;
     if (g.b_trans)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WGM, WGN, true>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
                            g.resid, sh);
@@ -341,6 +382,49 @@ static int pick_tile(const GemmArgs& g) {
         if (cost < best_cost) { best_cost = cost; best = t; }
     }
     return best;
+}
+
+// C[M,N] = A[Kt,M]^T . B[Kt,N]  (both operands row-major over the contraction index: weight gradients), split over the
+// contraction so that a small [M,N] still fills the chip: S partial products of ceil(Kt/S) rows each in `scratch`
+// (gemm_tn_scratch_floats), summed in a fixed order.  M, N multiples of 4.
+static int tn_splits(int M, int N, int Kt) {
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int S = cdiv(1024, tiles);                                       // ~4 workgroups per CU
+    const int smax = cdiv(Kt, 256);                                  // at least 8 k-tiles per split
+    if (S > smax) S = smax;
+    if (S > 64) S = 64;
+    return S < 1 ? 1 : S;
+}
+size_t gemm_tn_scratch_floats(int M, int N, int Kt) {
+    const int S = tn_splits(M, N, Kt);
+    return S > 1 ? (size_t)S * M * N : 0;
+}
+int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, int Kt, int lda, int ldb, float* scratch,
+                       hipStream_t stream) {
+    R4D_REQUIRE(M > 0 && N > 0 && Kt > 0 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
+                "gemm_tn: M=%d N=%d Kt=%d lda=%d ldb=%d (multiples of 4 wanted)", M, N, Kt, lda, ldb);
+    R4D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm_tn: 16-byte alignment");
+    const int S = tn_splits(M, N, Kt);
+    const int kper = cdiv(cdiv(Kt, S), BKT) * BKT;
+    const int Sx = cdiv(Kt, kper);                                   // splits that have rows
+    R4D_REQUIRE(S == 1 || scratch, "gemm_tn: split-K scratch missing");
+    GemmShape sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.M = M; sh.N = N; sh.K = Sx > 1 ? kper : Kt; sh.lda = lda; sh.ldb = ldb; sh.ldc = N; sh.ldr = N;
+    sh.b_rows = Kt; sh.a_cols = Kt; sh.nb1 = 1; sh.epilogue = EPI_NONE; sh.causal = CAUSAL_NONE; sh.k_total = Kt;
+    sh.sA0 = (long long)kper * lda; sh.sB0 = (long long)kper * ldb; sh.sC0 = (long long)M * N; sh.scale_div = 1.f;
+    {
+        ProfScope prof(PK_GEMM_128x128_NN, 2.0 * M * N * Kt, stream);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, BKT, 4, 2, false, true>), dim3(cdiv(M, 128) * cdiv(N, 128), 1, Sx), dim3(512), 0,
+                           stream, A, B, Sx > 1 ? scratch : C, nullptr, nullptr, sh);
+        R4D_CHECK_LAUNCH("gemm_f32_tn");
+    }
+    if (Sx > 1) {
+        const long long mn4 = (long long)M * N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, stream, scratch, mn4, Sx, C);
+        R4D_CHECK_LAUNCH("splitk_reduce");
+    }
+    return R4D_OK;
 }
 
 int launch_gemm_f32(const GemmArgs& g0, hipStream_t stream) {

@@ -6,13 +6,13 @@
 //            c_proj + x -> ln_2 -> c_fc (pre-activation kept) -> gelu_new -> c_proj + x;  ln_f -> mean over T
 //   backward (r4d_gpt2_train_backward_f32): d(mean-pooled embeddings) -> gradients of every parameter
 // Dense contractions run on the exact-f32 MFMA GEMMs of the forward path: data gradients dX = dY . W^T read the Conv1D
-// weight [in,out] as the k-contiguous B operand directly; weight gradients dW = X^T . dY go through one transposed copy
-// of X (train_ops.hip) and the [K,N]-operand GEMM; attention backward is four batched per-head GEMMs around a row kernel
+// weight [in,out] as the k-contiguous B operand directly; weight gradients dW = X^T . dY read BOTH operands row by row over
+// the contracted token index (the [K,M] x [K,N] form of gemm_f32_kernel, split over the tokens so that a d x d gradient still
+// fills the chip, partials summed in a fixed order); attention backward is four batched per-head GEMMs around a row kernel
 // (dP = dO . V^T,  dS = P (dP - rowsum(P dP)) / sqrt(hd),  dQ = dS . K,  dK = dS^T . Q,  dV = P^T . dO).
 // All batches of a step (anchor, positive, negative and the two augmented views) form ONE launch sequence over their
 // concatenated rows, like the inference path.  Dropout is the identity (documented deviation: the reference trains with
-// p = 0.1 drawn from its device RNG).  First version: correct and checked against the reference's autograd gradients; the
-// step is a few hundred small launches at the reference's batch sizes (4-32 sequences), i.e. latency-bound, not tuned.
+// p = 0.1 drawn from its device RNG).  Checked against the reference's autograd gradients (tests/test_gpu_training.py).
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -75,7 +75,13 @@ static TrainLayout layout(const r4d_gpt2_config* cfg, const TrainGroup* gs, int 
     t.x_out = take(t.M * d);
     t.pool_scratch = take(pool);
     t.dx = take(t.M * d); t.dy = take(t.M * d); t.dbig = take(t.M * 4 * d); t.dqkv = take(t.M * 3 * d);
-    t.xT = take((size_t)4 * d * up4((long long)t.M));
+    {   // split-K partials of the four weight-gradient shapes
+        size_t sk = gemm_tn_scratch_floats(4 * t.d, t.d, (int)t.M);
+        const size_t o[3] = {gemm_tn_scratch_floats(t.d, 4 * t.d, (int)t.M), gemm_tn_scratch_floats(t.d, t.d, (int)t.M),
+                             gemm_tn_scratch_floats(t.d, 3 * t.d, (int)t.M)};
+        for (size_t v : o) if (v > sk) sk = v;
+        t.xT = take(sk);
+    }
     t.dP = take(t.pmax); t.PT = take(t.pmax);
     size_t red = ln_bwd_scratch_floats((int)t.M, t.d);
     const size_t cs = colsum_scratch_floats((long long)t.M, 4 * t.d);
@@ -125,18 +131,12 @@ static int bwd_data(const float* dy, const float* w, int M, int K, int N, float*
     g.b_trans = 1; g.b_rows = K; g.nbatch = 1; g.nb1 = 1; g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
     return launch_gemm_f32(g, s);
 }
-// dW[K,N] = x[M,K]^T . dy[M,N]  through xT [K, up4(M)] (zero-padded columns); db[N] = column sums of dy
-static int bwd_weight(const float* x, const float* dy, int M, int K, int N, float* dW, float* db, float* xT, float* red,
+// dW[K,N] = x[M,K]^T . dy[M,N]: both operands read row by row over the contracted token index (split-K partials in `skp`);
+// db[N] = column sums of dy
+static int bwd_weight(const float* x, const float* dy, int M, int K, int N, float* dW, float* db, float* skp, float* red,
                       hipStream_t s) {
-    const int Mp = up4(M);
-    int rc = launch_transpose(x, M, K, K, 0, xT, Mp, 0, 1, s);
+    const int rc = launch_gemm_f32_tn(x, dy, dW, K, N, M, K, N, skp, s);
     if (rc) return rc;
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = xT; g.B = dy; g.C = dW;
-    g.M = K; g.N = N; g.K = Mp; g.lda = Mp; g.ldb = N; g.ldc = N;
-    g.b_trans = 0; g.b_rows = M; g.nbatch = 1; g.nb1 = 1; g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
-    if ((rc = launch_gemm_f32(g, s))) return rc;
     return db ? launch_colsum(dy, M, N, N, db, red, 0, s) : R4D_OK;
 }
 
@@ -226,6 +226,21 @@ static RowGroups row_groups_of(const std::vector<TrainGroup>& gs) {
 using namespace r4d;
 
 extern "C" {
+
+size_t r4d_weight_grad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {
+    if (rows <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    return (gemm_tn_scratch_floats(in_features, out_features, rows) + colsum_scratch_floats(rows, out_features) + 64) * sizeof(float);
+}
+
+int r4d_weight_grad_f32(const float* x_d, const float* dy_d, int32_t rows, int32_t in_features, int32_t out_features, float* dw_d,
+                        float* db_d, void* workspace_d, size_t workspace_bytes, void* stream) {
+    R4D_REQUIRE(x_d && dy_d && dw_d && rows > 0 && in_features > 0 && out_features > 0, "weight_grad: bad arguments");
+    R4D_REQUIRE(workspace_d && workspace_bytes >= r4d_weight_grad_workspace_bytes(rows, in_features, out_features),
+                "weight_grad: workspace too small");
+    float* skp = (float*)workspace_d;
+    float* red = skp + (gemm_tn_scratch_floats(in_features, out_features, rows) + 63) / 64 * 64;
+    return bwd_weight(x_d, dy_d, rows, in_features, out_features, dw_d, db_d, skp, red, (hipStream_t)stream);
+}
 
 size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs, const int32_t* Ts) {
     if (!cfg || n_groups <= 0 || n_groups > ATT_MAXG || !Bs || !Ts) return 0;

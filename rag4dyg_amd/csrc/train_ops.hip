@@ -19,51 +19,69 @@ __device__ __forceinline__ float wave_sum_t(float v) {
 // y = (x - mean) * rstd * w + b per row.  Given dy:  g = dy * w,  xh = (x - mean) * rstd,
 //   dx = rstd * (g - mean_c(g) - xh * mean_c(g * xh))   [+ add[m,:] when `add` is given: the residual branch's gradient]
 //   dw = sum_rows dy * xh,  db = sum_rows dy      (two deterministic stages: per-workgroup partial rows, then a column pass)
-// One wavefront per row (d <= 2048), statistics recomputed from x (two-pass like the forward kernel).
-constexpr int LNB_ROWS = 32;                                     // rows per workgroup (8 per wave)
+// One wavefront per row (d = 64 * nv <= 64 * NV), statistics recomputed from x (two-pass like the forward kernel).  A
+// workgroup owns `rows_per_wg` consecutive rows (its four waves interleaved), so the partial count is bounded by the grid
+// (<= LNB_MAX_WG), and the NEXT row's x / dy are in flight while the current row reduces: HBM-bound (3 reads + 1 write per
+// element), not latency-bound.  NV is a template parameter so the per-lane arrays stay in registers at 4+ waves per SIMD.
+constexpr int LNB_MAX_WG = 2048;
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ dy, const float* add, int rows,
+                                                     const float* __restrict__ dy, const float* add, int rows, int rows_per_wg,
                                                      int d, float eps, float* dx, float* __restrict__ part_w,
                                                      float* __restrict__ part_b) {          // `add` may alias `dx` (in-place residual)
     extern __shared__ float red[];                               // [2][4][d]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nv = d >> 6;                                       // d % 64 == 0
-    float aw[32], ab[32];
+    float aw[NV], ab[NV], wv[NV];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
-    for (int r = 0; r < LNB_ROWS / 4; ++r) {
-        const long long row = (long long)blockIdx.x * LNB_ROWS + wid + 4 * r;
-        if (row >= rows) break;                                  // wave-uniform
-        float xv[32], gv[32];
+    for (int i = 0; i < NV; ++i) { aw[i] = 0.f; ab[i] = 0.f; wv[i] = i < nv ? w[lane + 64 * i] : 0.f; }
+    const long long rbeg = (long long)blockIdx.x * rows_per_wg, rend = min((long long)rows, rbeg + rows_per_wg);
+    long long row = rbeg + wid;
+    float xn[NV], dn[NV];
+    if (row < rend) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (i < nv) { xn[i] = x[row * d + lane + 64 * i]; dn[i] = dy[row * d + lane + 64 * i]; }
+    }
+    for (; row < rend; row += 4) {                               // wave-uniform
+        float xv[NV], dv[NV], av[NV];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) if (i < nv) { xv[i] = x[row * d + lane + 64 * i]; s += xv[i]; }
+        for (int i = 0; i < NV; ++i) if (i < nv) { xv[i] = xn[i]; dv[i] = dn[i]; s += xv[i]; }
+        if (add) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nv) av[i] = add[row * d + lane + 64 * i];
+        }
+        if (row + 4 < rend) {                                    // next row of this wave: in flight under the reductions
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i < nv) { xn[i] = x[(row + 4) * d + lane + 64 * i]; dn[i] = dy[(row + 4) * d + lane + 64 * i]; }
+        }
         const float mean = wave_sum_t(s) / (float)d;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) if (i < nv) { xv[i] -= mean; q += xv[i] * xv[i]; }
+        for (int i = 0; i < NV; ++i) if (i < nv) { xv[i] -= mean; q += xv[i] * xv[i]; }
         const float rstd = rsqrtf(wave_sum_t(q) / (float)d + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < NV; ++i)
             if (i < nv) {
-                const float dyv = dy[row * d + lane + 64 * i];
                 xv[i] *= rstd;                                   // xh
-                gv[i] = dyv * w[lane + 64 * i];
-                sg += gv[i]; sgx += gv[i] * xv[i];
-                aw[i] += dyv * xv[i]; ab[i] += dyv;
+                const float gi = dv[i] * wv[i];
+                sg += gi; sgx += gi * xv[i];
+                aw[i] += dv[i] * xv[i]; ab[i] += dv[i];
+                dv[i] = gi;
             }
         const float mg = wave_sum_t(sg) / (float)d, mgx = wave_sum_t(sgx) / (float)d;
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < NV; ++i)
             if (i < nv) {
-                float v = rstd * (gv[i] - mg - xv[i] * mgx);
-                if (add) v += add[row * d + lane + 64 * i];
+                float v = rstd * (dv[i] - mg - xv[i] * mgx);
+                if (add) v += av[i];
                 dx[row * d + lane + 64 * i] = v;
             }
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) if (i < nv) { red[wid * d + lane + 64 * i] = aw[i]; red[(4 + wid) * d + lane + 64 * i] = ab[i]; }
+    for (int i = 0; i < NV; ++i) if (i < nv) { red[wid * d + lane + 64 * i] = aw[i]; red[(4 + wid) * d + lane + 64 * i] = ab[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {                 // waves combined in a fixed order
         part_w[(long long)blockIdx.x * d + c] = (red[c] + red[d + c]) + (red[2 * d + c] + red[3 * d + c]);
@@ -71,32 +89,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out[c] (+)= sum over rows of x[r, c]: one thread per column walks the rows in order (deterministic); rows is small here
-// (partials of ln_bwd_kernel / colsum_partial_kernel)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ x, int rows, int n, float* __restrict__ out,
-                                                           int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(long long)r * n + c];
-    out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= sum over rows of x[r, c] (partials of ln_bwd_kernel / colsum_partial_kernel): a workgroup owns 64 columns,
+// its 16 waves take rows w, w+16, ... (independent loads), combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ x, int rows, int n, float* __restrict__ out,
+                                                            int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        int r = wid;
+        for (; r + 16 < rows; r += 32) { s0 += x[(long long)r * n + c]; s1 += x[(long long)(r + 16) * n + c]; }
+        if (r < rows) s0 += x[(long long)r * n + c];
+    }
+    red[wid][lane] = s0 + s1;
+    __syncthreads();
+    if (wid == 0 && c < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][lane];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
-// partial[b, c] = sum of x[r, c] over the 256 rows of block b (4 waves x 64 rows, coalesced across c)
-constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int n, int ld,
+// partial[b, c] = sum of x[r, c] over the rows_per_block rows of block b (4 waves x a quarter each, coalesced across c)
+constexpr int CS_MAX_BLOCKS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int n, int ld, int rows_per_block,
                                                              float* __restrict__ partial) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const long long r0 = (long long)blockIdx.y * CS_ROWS + wid * 64;
-    float s = 0.f;
-    if (c < n)
-        for (int r = 0; r < 64; ++r) {
-            const long long row = r0 + r;
-            if (row < rows) s += x[row * ld + c];
+    const int q = rows_per_block >> 2;                           // rows_per_block % 4 == 0
+    const long long r0 = (long long)blockIdx.y * rows_per_block + (long long)wid * q;
+    const long long r1 = min((long long)rows, r0 + q);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < n) {
+        long long r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c];
         }
-    red[wid][lane] = s;
+        for (; r < r1; ++r) s0 += x[r * ld + c];
+    }
+    red[wid][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wid == 0 && c < n) partial[(long long)blockIdx.y * n + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
@@ -237,38 +271,72 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // ------------------------------------------------------------------------------------ launchers (used by train.hip)
-size_t ln_bwd_scratch_floats(int rows, int d) { return (size_t)2 * cdiv(rows, LNB_ROWS) * d; }
+static inline void ln_bwd_grid(int rows, int& nwg, int& rows_per_wg) {
+    rows_per_wg = cdiv(cdiv(rows, LNB_MAX_WG), 4) * 4;               // every wave of a workgroup gets whole rows
+    if (rows_per_wg < 8) rows_per_wg = 8;
+    nwg = cdiv(rows, rows_per_wg);
+}
+size_t ln_bwd_scratch_floats(int rows, int d) {
+    int nwg, rpw;
+    ln_bwd_grid(rows > 0 ? rows : 1, nwg, rpw);
+    return (size_t)2 * nwg * d;
+}
+
+template <int NV>
+static int launch_ln_bwd_nv(const float* x, const float* w, const float* dy, const float* add, int rows, int rpw, int nwg, int d,
+                            float eps, float* dx, float* pw, float* pb, hipStream_t s) {
+    const size_t lds = (size_t)8 * d * sizeof(float);
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            R4D_HIP(hipFuncSetAttribute((const void*)ln_bwd_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(nwg), dim3(256), lds, s, x, w, dy, add, rows, rpw, d, eps, dx, pw, pb);
+    R4D_CHECK_LAUNCH("ln_bwd");
+    return R4D_OK;
+}
 
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* add, int rows, int d, float eps, float* dx,
                   float* dw, float* db, float* scratch, int accumulate, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 2048, "layernorm_bwd: d=%d must be a multiple of 64 and <= 2048", d);
     if (rows <= 0) return R4D_OK;
-    const int nb = cdiv(rows, LNB_ROWS);
+    int nwg, rpw;
+    ln_bwd_grid(rows, nwg, rpw);
     float* pw = scratch;
-    float* pb = scratch + (size_t)nb * d;
-    const size_t lds = (size_t)8 * d * sizeof(float);
-    if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            R4D_HIP(hipFuncSetAttribute((const void*)ln_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4));
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), lds, s, x, w, dy, add, rows, d, eps, dx, pw, pb);
-    R4D_CHECK_LAUNCH("ln_bwd");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, pw, nb, d, dw, accumulate);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, pb, nb, d, db, accumulate);
+    float* pb = scratch + (size_t)nwg * d;
+    const int nv = d / 64;
+    int rc;
+    if (nv <= 4) rc = launch_ln_bwd_nv<4>(x, w, dy, add, rows, rpw, nwg, d, eps, dx, pw, pb, s);
+    else if (nv <= 8) rc = launch_ln_bwd_nv<8>(x, w, dy, add, rows, rpw, nwg, d, eps, dx, pw, pb, s);
+    else if (nv <= 12) rc = launch_ln_bwd_nv<12>(x, w, dy, add, rows, rpw, nwg, d, eps, dx, pw, pb, s);
+    else if (nv <= 16) rc = launch_ln_bwd_nv<16>(x, w, dy, add, rows, rpw, nwg, d, eps, dx, pw, pb, s);
+    else rc = launch_ln_bwd_nv<32>(x, w, dy, add, rows, rpw, nwg, d, eps, dx, pw, pb, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, s, pw, nwg, d, dw, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, s, pb, nwg, d, db, accumulate);
     R4D_CHECK_LAUNCH("ln_bwd colsum");
     return R4D_OK;
 }
 
-size_t colsum_scratch_floats(long long rows, int n) { return (size_t)cdiv((int)rows, CS_ROWS) * n; }
+static inline void colsum_grid(long long rows, int& nb, int& rows_per_block) {
+    rows_per_block = (int)cdiv((int)cdiv((int)rows, CS_MAX_BLOCKS), 4) * 4;
+    if (rows_per_block < 64) rows_per_block = 64;
+    nb = cdiv((int)rows, rows_per_block);
+}
+size_t colsum_scratch_floats(long long rows, int n) {
+    int nb, rpb;
+    colsum_grid(rows > 0 ? rows : 1, nb, rpb);
+    return (size_t)nb * n;
+}
 
 int launch_colsum(const float* x, long long rows, int n, int ld, float* out, float* scratch, int accumulate, hipStream_t s) {
     if (rows <= 0 || n <= 0) return R4D_OK;
-    const int nb = cdiv((int)rows, CS_ROWS);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, 64), nb), dim3(256), 0, s, x, (int)rows, n, ld, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scratch, nb, n, out, accumulate);
+    int nb, rpb;
+    colsum_grid(rows, nb, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, 64), nb), dim3(256), 0, s, x, (int)rows, n, ld, rpb, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, s, scratch, nb, n, out, accumulate);
     R4D_CHECK_LAUNCH("colsum");
     return R4D_OK;
 }

@@ -1,5 +1,7 @@
-"""GPU test of the retriever training step's FORWARD half (staged) against the reference's own step
-(tests/golden/g8_training_step.npz: five forwards, CLtime_loss + alpha * info_nce, computed by the reference on CPU)."""
+"""GPU tests of the retriever training step against the reference's own step (tests/golden/g8_training_step.npz:
+five forwards, CLtime_loss + alpha * info_nce, parameter gradients from the reference's autograd on CPU), of the optimizer
+against the restated transformers.AdamW, of each backward kernel against torch autograd in float64, and of the
+``main_retriever.py --do_train`` loop end to end."""
 import random
 import types
 
@@ -194,3 +196,89 @@ def test_main_retriever_do_train_end_to_end(dev, tmp_path, monkeypatch):
     with redirect_stdout(buf):
         main_retriever.main((common + " --do_eval --eval_all_checkpoints").split())
     assert buf.getvalue().count("test_metrics:") == 2
+
+
+# ------------------------------------------------------------------------------------------------ single backward ops
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("rows,d,with_add", [(1, 64, False), (37, 256, True), (5003, 512, True), (3000, 768, False),
+                                             (70001, 512, True), (260, 1024, True), (129, 2048, False)])
+def test_layernorm_backward_equals_autograd(dev, rows, d, with_add):
+    from rag4dyg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 1.7 + 0.3
+    w = torch.randn(d, generator=g) * 0.5 + 1.0
+    b = torch.randn(d, generator=g) * 0.1
+    dy = torch.randn(rows, d, generator=g)
+    add = torch.randn(rows, d, generator=g) if with_add else None
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5).backward(dy.double())
+    dx_ref = xr.grad + (add.double() if with_add else 0)
+    X, W, DY = x.to(dev), w.to(dev), dy.to(dev)
+    dx = add.to(dev).clone() if with_add else torch.empty_like(X)             # the in-place residual form: add aliases dx
+    dw, db = torch.empty(d, device=dev), torch.empty(d, device=dev)
+    ws = torch.empty(lib.r4d_layernorm_bwd_workspace_bytes(rows, d), dtype=torch.uint8, device=dev)
+    _lib.check(lib.r4d_layernorm_bwd_f32(X.data_ptr(), W.data_ptr(), DY.data_ptr(), dx.data_ptr() if with_add else None, rows, d, 1e-5,
+                                         dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ln_bwd")
+    assert elementwise_err(dx.cpu().numpy(), dx_ref.numpy()) < 1
+    assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < 1e-5 and rel_err(db.cpu().numpy(), br.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,fin,fout", [(1, 4, 4), (31, 64, 192), (1000, 132, 516), (9999, 512, 512), (20011, 256, 1024),
+                                           (70000, 128, 128)])
+def test_weight_gradient_equals_float64(dev, rows, fin, fout):
+    """dW = x^T . dy (the [K,M] x [K,N] split-K MFMA GEMM, ragged in every dimension) and db = column sums of dy."""
+    from rag4dyg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows)
+    x, dy = torch.randn(rows, fin, generator=g), torch.randn(rows, fout, generator=g)
+    X, DY = x.to(dev), dy.to(dev)
+    dw, db = torch.full((fin, fout), float("nan"), device=dev), torch.full((fout,), float("nan"), device=dev)
+    ws = torch.empty(lib.r4d_weight_grad_workspace_bytes(rows, fin, fout), dtype=torch.uint8, device=dev)
+    for _ in range(2):                                                         # second run: same bits (fixed summation order)
+        _lib.check(lib.r4d_weight_grad_f32(X.data_ptr(), DY.data_ptr(), rows, fin, fout, dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _stream()), "weight_grad")
+        got = (dw.cpu().clone(), db.cpu().clone())
+        if _ == 0:
+            first = got
+    assert torch.equal(first[0], got[0]) and torch.equal(first[1], got[1])
+    ref = x.double().t() @ dy.double()
+    scale = (x.double().abs().t() @ dy.double().abs())                         # fp32 dot-product error scales with sum |x||dy|
+    assert float(((got[0].double() - ref).abs() / scale).max()) < 2e-6
+    assert float(((got[1].double() - dy.double().sum(0)).abs() / dy.double().abs().sum(0)).max()) < 2e-6
+
+
+def test_gelu_and_causal_softmax_backward_equal_autograd(dev):
+    from rag4dyg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    pre, dy = torch.randn(1237, 96, generator=g) * 2.5, torch.randn(1237, 96, generator=g)
+    pr = pre.double().requires_grad_(True)
+    u = 0.7978845608028654 * (pr + 0.044715 * pr ** 3)
+    y_ref = 0.5 * pr * (1.0 + torch.tanh(u))                                    # gelu_new, modeling_gpt2.py:25
+    y_ref.backward(dy.double())
+    P, DY = pre.to(dev), dy.to(dev)
+    y, dx = torch.empty_like(P), torch.empty_like(P)
+    _lib.check(lib.r4d_gelu_new_f32(P.data_ptr(), P.numel(), y.data_ptr(), _stream()), "gelu")
+    _lib.check(lib.r4d_gelu_new_bwd_f32(P.data_ptr(), DY.data_ptr(), P.numel(), dx.data_ptr(), _stream()), "gelu_bwd")
+    assert elementwise_err(y.cpu().numpy(), y_ref.detach().numpy()) < 1 and elementwise_err(dx.cpu().numpy(), pr.grad.numpy()) < 1
+    # causal softmax backward on [nbh, T, ld] with the logits divided by sqrt(hd) first (modeling_gpt2.py:143-150)
+    nbh, T, ld, sd = 6, 45, 128, 8.0
+    logits = torch.randn(nbh, T, T, generator=g).double().requires_grad_(True)
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    probs = torch.softmax(torch.where(mask, logits / sd, torch.tensor(-1e4, dtype=torch.float64)), dim=-1)
+    dP = torch.randn(nbh, T, T, generator=g)
+    probs.backward(dP.double())
+    Pd = torch.zeros(nbh, T, ld)
+    Pd[:, :, :T] = torch.where(mask, probs.detach().float(), torch.zeros(()))
+    dPd = torch.zeros(nbh, T, ld)
+    dPd[:, :, :T] = dP
+    Pd, dPd = Pd.to(dev), dPd.to(dev)
+    _lib.check(lib.r4d_causal_softmax_bwd_f32(Pd.data_ptr(), dPd.data_ptr(), nbh, T, ld, sd, _stream()), "softmax_bwd")
+    got = dPd.cpu()[:, :, :T]
+    want = torch.where(mask, logits.grad, torch.zeros((), dtype=torch.float64))
+    assert elementwise_err(got.numpy(), want.numpy()) < 1
+    assert float(dPd.cpu()[:, :, T:].abs().max()) == 0.0

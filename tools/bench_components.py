@@ -243,6 +243,98 @@ print(json.dumps({"rows": rows, "cols": len(lists), "seconds": el}))
 """
 
 
+def training():
+    """one retriever training iteration (five forwards with saved activations, losses, encoder backward, clip,
+    AdamW) at the UCI_13 script's shape (L4 H2 d512, batch 64: scripts/train_retriever/train_retriever_UCI_13.sh:8-12) on
+    synthetic UCI_13-length sequences.  flop = 3 x the forward's algorithmic encoder flop (forward + dX + dW) of the five
+    padded batches; wall clock includes the host side of the step (aug, loss autograd over [5, B, d], ~40 optimizer launches)."""
+    import random
+    import types
+    from bench import build_model, f_enc
+    from rag4dyg_amd import training as tr
+    from rag4dyg_amd.retrieval import right_pad_batches
+    shape = synth.SHAPES["UCI_13"]
+    B = 64
+    m = build_model(shape, dev)
+    m.config.eta, m.config.gamma = 0.8, 0.4
+    nb = 12
+    seqs = synth.sequences(shape, 3 * B * nb, "query", seed=11)
+    args = types.SimpleNamespace(device=dev, temperature=0.1, lambda_decay=1e-4, alpha=1.0, per_gpu_train_batch_size=B,
+                                 max_grad_norm=1.0, gradient_accumulation_steps=1)
+    times = torch.rand(3 * B * nb) * 1e4
+    batches = []
+    for i in range(nb):
+        trip = [right_pad_batches(seqs[(3 * i + j) * B:(3 * i + j + 1) * B], B, shape.pad_id, dev)[0] for j in range(3)]
+        idx = [torch.arange((3 * i + j) * B, (3 * i + j + 1) * B).view(B, 1) for j in range(3)]
+        batches.append((*trip, *idx))
+    trainer = tr.EncoderTrainer(m)
+    opt = tr.AdamW(trainer.params, trainer.grads, lr=1e-5, eps=1e-8, weight_decay=0.0)
+    mask = tr.mask_correlated_samples(B)
+    random.seed(0)
+    for b in batches[:2]:
+        tr.training_step(args, m, trainer, opt, b, times, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    flop = 0.0
+    for b in batches[2:]:
+        tr.training_step(args, m, trainer, opt, b, times, mask)
+        flop += 3.0 * (f_enc(shape, B, b[0].shape[1]) * 3 + f_enc(shape, B, b[1].shape[1]) + f_enc(shape, B, b[2].shape[1]))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n = nb - 2
+    # device-side split of one step (forward / backward / optimizer) with events
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    b = batches[2]
+    a1, a2 = tr.aug(b[0], 0.8, 0.4, m.config.vocab_size - 1)
+    ev[0].record()
+    emb = trainer.forward([b[0], b[1], b[2], a1, a2])
+    ev[1].record()
+    trainer.backward(torch.randn_like(emb))
+    ev[2].record()
+    opt.step(1.0)
+    ev[3].record()
+    torch.cuda.synchronize()
+    emit(component="retriever_training_step", shape="UCI_13", batch=B, steps=n, ms_per_step=round(1e3 * el / n, 3),
+         sequences_per_s=round(5 * B * n / el, 1), tflops=round(flop / el / 1e12, 1),
+         forward_ms=round(ev[0].elapsed_time(ev[1]), 3), backward_ms=round(ev[1].elapsed_time(ev[2]), 3),
+         optimizer_ms=round(ev[2].elapsed_time(ev[3]), 3), padded_T=[int(x.shape[1]) for x in b[:3]])
+
+
+def training_cpu():
+    """The same training iteration on the host cores: the oracle's grad-enabled forward + torch CPU autograd + the restated
+    AdamW (oracle/train_ref.py), ONE step at batch 16 of the same sequence distribution (bounded sample)."""
+    import random
+    from oracle import gpt2_ref, train_ref
+    shape = synth.SHAPES["UCI_13"]
+    B = 16
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = gpt2_ref.make_state_dict(shape.n_layer, shape.n_embd, shape.vocab, n_positions=1024, seed=3)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    seqs = synth.sequences(shape, 3 * B, "query", seed=11)
+
+    def pad(chunk):
+        T = max(len(e) for e in chunk)
+        b = torch.full((len(chunk), T), int(shape.pad_id), dtype=torch.int64)
+        for i, e in enumerate(chunk):
+            b[i, :len(e)] = torch.as_tensor(e)
+        return b
+    a, p_, n_ = pad(seqs[:B]), pad(seqs[B:2 * B]), pad(seqs[2 * B:])
+    idx = torch.arange(3 * B).view(3, B).t().contiguous()
+    t0 = time.perf_counter()
+    r = train_ref.training_step(sd, shape.n_head, a, p_, n_, torch.rand(3 * B) * 1e4, idx, 0.8, 0.4, 1.0, 0.1, 1e-4,
+                                shape.vocab - 1, 0, with_grad=True)
+    r["loss"].backward()
+    names = [k for k in sd if sd[k].grad is not None]
+    coef, _ = train_ref.clip_coefficient([sd[k].grad for k in names], 1.0)
+    for k in names:
+        train_ref.adamw_step(sd[k].detach(), sd[k].grad * coef, torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1, 1e-5)
+    el = time.perf_counter() - t0
+    emit(component="retriever_training_step_cpu", kind="port", cores=cores, shape="UCI_13", batch=B,
+         sample=f"one step, batch {B} (5 x {B} sequences), padded T = {[int(a.shape[1]), int(p_.shape[1]), int(n_.shape[1])]}",
+         seconds=round(el, 2), sequences_per_s=round(5 * B / el, 2))
+
+
 def jaccard_cpu_all_cores():
     """the reference's python-set double loop (retrieval_data_annotation.py:36-41) on ALL host cores (row blocks in
     a process pool, started from a fresh interpreter that never touches the GPU) next to the single-thread line of jaccard()."""
@@ -256,6 +348,6 @@ def jaccard_cpu_all_cores():
 
 
 if __name__ == "__main__":
-    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "jaccard_cpu", "pool", "generator", "generator_reddit"]):
+    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "jaccard_cpu", "pool", "generator", "generator_reddit", "training", "training_cpu"]):
         {"scan": scan, "topk": topk, "jaccard": jaccard, "jaccard_cpu": jaccard_cpu_all_cores, "pool": pool, "generator": generator,
-         "generator_reddit": generator_reddit}[part]()
+         "generator_reddit": generator_reddit, "training": training, "training_cpu": training_cpu}[part]()
