@@ -345,7 +345,10 @@ int r4d_gelu_new_bwd_f32(const float* pre_d, const float* dy_d, int64_t n, float
  * dLoss/d(raw Q.K^T logits) on return (the logits were divided by scale_div before the softmax, modeling_gpt2.py:143);
  * columns right of the diagonal are written as zero. */
 int r4d_causal_softmax_bwd_f32(const float* p_d, float* dp_d, int32_t nbh, int32_t T, int32_t ld, float scale_div, void* stream);
-/* accum_d[0] += sum x^2 (total gradient norm of clip_grad_norm_, train_retriever.py:210; zero accum_d first). */
+/* accum_d[0] += sum x^2 (total gradient norm of clip_grad_norm_, train_retriever.py:210; zero accum_d[0] first).  accum_d is
+ * f32[R4D_SUMSQ_FLOATS]: element 0 the running total, the rest scratch of the two-stage sum (no atomics: the same bits on
+ * every data-parallel rank). */
+#define R4D_SUMSQ_FLOATS 1025
 int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* stream);
 /* One transformers.AdamW update of a flat tensor (utils/model.py:80-93; decoupled weight decay applied after the step,
  * bias correction on): step >= 1 is the update count; grad_sumsq_d (nullable) with max_grad_norm > 0 clips the gradient

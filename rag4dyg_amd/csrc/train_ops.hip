@@ -238,15 +238,27 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------ optimizer
-// accum[0] += sum x^2 (one atomic per workgroup; the total feeds clip_grad_norm_, train_retriever.py:210)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ accum) {
+// accum[0] += sum x^2 (the total feeds clip_grad_norm_, train_retriever.py:210).  Two stages, no atomics: the value must be
+// the same bits on every data-parallel rank (same gradients after the all-reduce), or the clip coefficient -- and with it the
+// weights -- drift apart between ranks.  part[b] = workgroup b's grid-strided share; then one workgroup adds them in order.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum_t(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(accum, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ accum) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = wave_sum_t(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) accum[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // transformers.AdamW.step (the optimizer utils/model.py:80-93 builds; third-party, restated from its published update):
@@ -416,8 +428,9 @@ int r4d_causal_softmax_bwd_f32(const float* p_d, float* dp_d, int32_t nbh, int32
 int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* stream) {
     R4D_REQUIRE(x_d && accum_d && n >= 0, "sumsq: bad arguments");
     if (n == 0) return R4D_OK;
-    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_d, n, accum_d);
+    const unsigned grid = (unsigned)((n + 255) / 256 < SUMSQ_BLOCKS ? (n + 255) / 256 : SUMSQ_BLOCKS);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_d, n, accum_d + 1);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, accum_d + 1, (int)grid, accum_d);
     R4D_CHECK_LAUNCH("sumsq");
     return R4D_OK;
 }

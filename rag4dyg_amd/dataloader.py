@@ -70,8 +70,12 @@ def get_dataloader(dataset, tokenizer, args, split='eval'):
     if split == 'train':
         from torch.utils.data import RandomSampler
         args.train_batch_size = args.per_gpu_train_batch_size * max(1, args.n_gpu)
-        loader = DataLoader(dataset, sampler=RandomSampler(dataset), batch_size=args.train_batch_size, collate_fn=collate,
-                            drop_last=False)
+        if getattr(args, "data_parallel_world", 1) <= 1:
+            sampler = RandomSampler(dataset)
+        else:                                                       # one process per GPU: each rank its share of the triples
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(dataset)
+        loader = DataLoader(dataset, sampler=sampler, batch_size=args.train_batch_size, collate_fn=collate, drop_last=False)
         return loader, args
     args.eval_batch_size = args.per_gpu_eval_batch_size * max(1, args.n_gpu)
     loader = DataLoader(dataset, sampler=SequentialSampler(dataset), batch_size=args.eval_batch_size,

@@ -158,7 +158,16 @@ class EncoderTrainer:
         for n, p in self.params.items():
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.R4DError(f"{n}: training needs contiguous fp32 parameters on the GPU (no CPU fallback)")
-        self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        # every gradient is a view of ONE flat buffer (64-float aligned slices): the gradient norm is one launch over it, an
+        # accumulation step one add, and a data-parallel step ONE all-reduce over RCCL instead of one per tensor
+        offs, total = {}, 0
+        for n, p in self.params.items():
+            offs[n] = total
+            total += (p.numel() + 63) // 64 * 64
+        dev = tr.wte.weight.device
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = {n: self.flat_grads[offs[n]:offs[n] + p.numel()].view_as(p) for n, p in self.params.items()}
+        self.flat_accum = None
         self._ws = None
         self._saved = None
 
@@ -216,6 +225,30 @@ class EncoderTrainer:
         self._saved = None
         return self.grads
 
+    @torch.no_grad()
+    def accumulate(self):
+        """``loss.backward()`` of a micro-step under ``--gradient_accumulation_steps`` > 1 (``train_retriever.py:202-212``): the
+        gradients just computed are added to the running sum."""
+        if self.flat_accum is None:
+            self.flat_accum = torch.zeros_like(self.flat_grads)
+        self.flat_accum.add_(self.flat_grads)
+
+    @torch.no_grad()
+    def take_accumulated(self):
+        """The running sum becomes the gradient the optimizer sees; the sum restarts at zero (``model.zero_grad()``)."""
+        if self.flat_accum is not None:
+            self.flat_grads.copy_(self.flat_accum)
+            self.flat_accum.zero_()
+
+    @torch.no_grad()
+    def all_reduce_mean(self):
+        """Data-parallel step (``DistributedDataParallel``, ``train_retriever.py:260-266``): gradients averaged over the ranks --
+        one collective over the flat buffer."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grads)
+            self.flat_grads.div_(dist.get_world_size())
+
 
 class AdamW:
     """``transformers.AdamW`` as ``utils/model.py:80-93`` configures it -- bias correction on, decoupled weight decay applied
@@ -223,8 +256,9 @@ class AdamW:
     ln_2 / ln_f, so their gains DO decay: upstream quirk kept) -- with ``clip_grad_norm_`` folded in: the squared norm of
     all gradients is accumulated on the device and every update kernel scales its gradient by the clip coefficient."""
 
-    def __init__(self, params, grads, lr, eps=1e-8, weight_decay=0.0, betas=(0.9, 0.999)):
+    def __init__(self, params, grads, lr, eps=1e-8, weight_decay=0.0, betas=(0.9, 0.999), flat_grads=None):
         self.params, self.grads = params, grads
+        self.flat_grads = flat_grads                 # EncoderTrainer.flat_grads: the norm is then one launch (padding is zero)
         self.lr, self.eps, self.betas = lr, eps, betas
         no_decay = ("bias", "LayerNorm.weight")
         self.wd = {n: (0.0 if any(nd in n for nd in no_decay) else weight_decay) for n in params}
@@ -232,7 +266,7 @@ class AdamW:
         self.v = {n: torch.zeros_like(p) for n, p in params.items()}
         self.t = 0
         dev = next(iter(params.values())).device
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1025, dtype=torch.float32, device=dev)        # R4D_SUMSQ_FLOATS: [0] total, rest scratch
 
     @torch.no_grad()
     def step(self, max_grad_norm=0.0):
@@ -241,7 +275,7 @@ class AdamW:
         self.t += 1
         self.sumsq.zero_()
         if max_grad_norm and max_grad_norm > 0:
-            for n, g in self.grads.items():
+            for g in ([self.flat_grads] if self.flat_grads is not None else self.grads.values()):
                 _lib.check(lib.r4d_sumsq_accumulate_f32(g.data_ptr(), g.numel(), self.sumsq.data_ptr(), stream), "sumsq")
         for n, p in self.params.items():
             _lib.check(lib.r4d_adamw_step_f32(p.data_ptr(), self.grads[n].data_ptr(), self.m[n].data_ptr(), self.v[n].data_ptr(),
@@ -250,13 +284,14 @@ class AdamW:
                                               float(max_grad_norm or 0.0), stream), "adamw")
 
     def grad_norm(self):
-        return float(self.sumsq.sqrt().item())
+        return float(self.sumsq[0].sqrt().item())
 
 
-def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None):
+def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None, micro_step=0):
     """One iteration of ``train_epoch`` (``train/train_retriever.py:164-214``) on the device: five forwards (one launch
-    sequence), the two contrastive losses (torch autograd over the [5, B, d] embeddings only), the encoder's backward pass,
-    gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss)."""
+    sequence), the two contrastive losses (torch autograd over the [5, B, d] embeddings only), the encoder's backward pass
+    and -- every ``gradient_accumulation_steps``-th micro-step -- the gradient average over the data-parallel ranks,
+    gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss, stepped)."""
     anchor_seq, pos_seq, neg_seq, anchor_idx, pos_idx, neg_idx = batch
     dev = args.device
     anchor_seq, pos_seq, neg_seq = anchor_seq.to(dev), pos_seq.to(dev), neg_seq.to(dev)
@@ -269,13 +304,21 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
         cl = CLtime_loss(args, leaf[0], leaf[1], leaf[2], t[anchor_idx], t[pos_idx], t[neg_idx])
         au = args.alpha * info_nce(args, leaf[3], leaf[4], args.temperature, B, mask_nce)
         loss = cl + au
-        if getattr(args, "gradient_accumulation_steps", 1) > 1:
-            loss = loss / args.gradient_accumulation_steps
+        gas = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
+        if gas > 1:
+            loss = loss / gas
         loss.backward()
     trainer.backward(leaf.grad.view(5 * B, -1))
-    optimizer.step(getattr(args, "max_grad_norm", 0.0))
-    model.transformer.__dict__.pop("_wt_cache", None)            # transposed weight copies of the inference path are stale now
-    return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()))
+    if gas > 1:
+        trainer.accumulate()
+    stepped = (micro_step + 1) % gas == 0
+    if stepped:
+        if gas > 1:
+            trainer.take_accumulated()
+        trainer.all_reduce_mean()
+        optimizer.step(getattr(args, "max_grad_norm", 0.0))
+        model.transformer.__dict__.pop("_wt_cache", None)        # transposed weight copies of the inference path are stale now
+    return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()), stepped=stepped)
 
 
 # ------------------------------------------------------------------------------------------------ training loop
@@ -325,31 +368,54 @@ def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataload
     for i, batch in enumerate(train_dataloader):
         if args.lrdecay == 1:
             adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
-        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce)
+        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce, micro_step=i)
         tr_loss += r["loss"]; tr_cl += r["cl_loss"]; tr_aug += r["aug_loss"]
-        global_step += 1
+        if r["stepped"]:                                       # an optimizer update (train_retriever.py:212-221)
+            global_step += 1
         if args.max_steps > 0 and global_step > args.max_steps:
             break
     return global_step, tr_loss, tr_cl, tr_aug
+
+
+def distributed_setup(args):
+    """(world size, rank) of a run started by ``torch.distributed.run``; joins the process group on first use.  One process
+    per GPU over RCCL (backend "nccl"); ``R4D_DIST_BACKEND=gloo`` lets several ranks share one card (tests)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.data_parallel_world = 1
+    if world <= 1:
+        return 1, 0
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("R4D_DIST_BACKEND", "nccl"))
+    args.data_parallel_world = dist.get_world_size()           # get_dataloader: DistributedSampler (dataloader/retriever.py:160)
+    return dist.get_world_size(), dist.get_rank()
 
 
 def train(args, train_dataset, model, tokenizer):
     """Drop-in for ``train/train_retriever.train`` (``:230-354``): AdamW on the time-decayed contrastive + InfoNCE loss, validation
     hit@3 after every epoch, best checkpoint as ``checkpoint-0`` (only once ``epoch > warmup_steps``, as upstream), last as
     ``checkpoint-1``, early stopping after ``--patience`` epochs without improvement, then the test / validation passes on
-    the best and the last weights.  Differences: dropout is the identity; ``--gradient_accumulation_steps`` > 1, ``--fp16``
-    and multi-process data parallelism are not built (they raise)."""
+    the best and the last weights.  Data parallel: launched under ``torch.distributed.run`` (one process per GPU) every rank
+    takes its ``DistributedSampler`` share of the triples and the gradients are averaged with one all-reduce per update (RCCL;
+    ``R4D_DIST_BACKEND=gloo`` for ranks that share a card); every rank validates (identical numbers, so the early-stopping
+    decision needs no broadcast), rank 0 writes the checkpoints.  Differences: ``--fp16`` (apex) is not built (raises)."""
     from .dataloader import get_dataloader
     from .retriever import test
-    if getattr(args, "gradient_accumulation_steps", 1) != 1 or getattr(args, "fp16", False):
-        raise NotImplementedError("retriever training: --gradient_accumulation_steps > 1 / --fp16 are not built")
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        raise NotImplementedError("retriever training runs one process on one GPU in this build (gradient all-reduce not built)")
+    if getattr(args, "fp16", False):
+        raise NotImplementedError("retriever training: --fp16 (apex mixed precision) is not built; the path is fp32")
+    world, rank = distributed_setup(args)
     train_dataloader, args = get_dataloader(train_dataset, tokenizer, args, split="train")
+    gas = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
     if args.max_steps > 0:
-        args.num_train_epochs = args.max_steps // max(1, len(train_dataloader)) + 1
+        args.num_train_epochs = args.max_steps // max(1, len(train_dataloader) // gas) + 1
     trainer = EncoderTrainer(model)
-    optimizer = AdamW(trainer.params, trainer.grads, lr=args.learning_rate, eps=args.adam_epsilon, weight_decay=args.weight_decay)
+    if world > 1:
+        import torch.distributed as dist
+        for p in trainer.params.values():                       # DistributedDataParallel's construction-time broadcast
+            dist.broadcast(p.data, src=0)
+    optimizer = AdamW(trainer.params, trainer.grads, lr=args.learning_rate, eps=args.adam_epsilon, weight_decay=args.weight_decay,
+                      flat_grads=trainer.flat_grads)
     print("***** Running training *****")
     print("  Num examples = {}".format(len(train_dataset)))
     print("  Num Epochs = {}".format(args.num_train_epochs))
@@ -374,7 +440,8 @@ def train(args, train_dataset, model, tokenizer):
         if epoch > args.warmup_steps:
             if best_score is None or score > best_score:
                 best_score, best_epoch, best_state, counter = score, epoch, snapshot(), 0
-                save_checkpoint(model, optimizer, tokenizer, args, 0)
+                if rank == 0:
+                    save_checkpoint(model, optimizer, tokenizer, args, 0)
             else:
                 counter += 1
                 print('  EarlyStopping counter: {} out of {}'.format(counter, args.patience))
@@ -382,7 +449,8 @@ def train(args, train_dataset, model, tokenizer):
         if early_stop:
             print('  Early Stopping.....')
             break
-        save_checkpoint(model, optimizer, tokenizer, args, 1)
+        if rank == 0:
+            save_checkpoint(model, optimizer, tokenizer, args, 1)
         last_state = snapshot()
     if best_state is None:                        # never past the warm-up epochs: the last weights are the best we have
         best_state, best_epoch = snapshot(), epoch

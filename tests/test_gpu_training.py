@@ -198,6 +198,154 @@ def test_main_retriever_do_train_end_to_end(dev, tmp_path, monkeypatch):
     assert buf.getvalue().count("test_metrics:") == 2
 
 
+def _tiny_step_inputs(dev, roll=0):
+    from oracle import gpt2_ref
+    from rag4dyg_amd import training
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    g = load_golden("g8_training_step")
+    tag = "ts_tiny"
+    L, H, d, V, pad, B, seed = (int(x) for x in g[tag + "_cfg"])
+    eta, gamma, alpha, temp, lam = (float(x) for x in g[tag + "_hyper"])
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+    cfg = GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H)
+    cfg.eta, cfg.gamma = eta, gamma
+    m = GPT2LMHeadModelRAG(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    T = torch.from_numpy
+    idx = T(g[tag + "_idx"])
+    # roll != 0: a different batch (the anchors, and their times, shifted against the positives / negatives)
+    batch = (torch.roll(T(g[tag + "_anchor"]), roll, 0), T(g[tag + "_pos"]), T(g[tag + "_neg"]), torch.roll(idx[:, 0:1], roll, 0),
+             idx[:, 1:2], idx[:, 2:3])
+    args = types.SimpleNamespace(device=dev, temperature=temp, lambda_decay=lam, alpha=alpha, per_gpu_train_batch_size=B,
+                                 max_grad_norm=1.0, gradient_accumulation_steps=1)
+    return m, args, batch, T(g[tag + "_times"]), training.mask_correlated_samples(B), seed
+
+
+def test_gradient_accumulation_equals_mean_of_micro_batch_gradients(dev):
+    """--gradient_accumulation_steps 2 (train_retriever.py:202-212): no update after the first micro-step, and the gradient the
+    optimizer sees after the second is (g1 + g2) / 2 of the two micro-batches' own gradients."""
+    from rag4dyg_amd import training
+    m, args, b1, times, mask, seed = _tiny_step_inputs(dev)
+    _, _, b2, _, _, _ = _tiny_step_inputs(dev, roll=1)
+    singles = []
+    for b in (b1, b2):                                           # each micro-batch alone (lr 0: the parameters stay put)
+        tr = training.EncoderTrainer(m)
+        opt = training.AdamW(tr.params, tr.grads, lr=0.0, flat_grads=tr.flat_grads)
+        random.seed(seed)
+        training.training_step(args, m, tr, opt, b, times, mask)
+        singles.append(tr.flat_grads.clone())
+    args.gradient_accumulation_steps = 2
+    tr = training.EncoderTrainer(m)
+    opt = training.AdamW(tr.params, tr.grads, lr=0.0, flat_grads=tr.flat_grads)
+    random.seed(seed)
+    r1 = training.training_step(args, m, tr, opt, b1, times, mask, micro_step=0)
+    assert not r1["stepped"] and opt.t == 0
+    random.seed(seed)
+    r2 = training.training_step(args, m, tr, opt, b2, times, mask, micro_step=1)
+    assert r2["stepped"] and opt.t == 1
+    want = (singles[0].double() + singles[1].double()) / 2
+    assert rel_err(tr.flat_grads.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    assert float(tr.flat_accum.abs().max()) == 0.0               # model.zero_grad()
+
+
+_DP_WORKER = r'''
+import os, random, sys, types
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from test_gpu_training import _tiny_step_inputs
+from rag4dyg_amd import training
+rank = int(os.environ["RANK"])
+dist.init_process_group(backend="gloo")
+dev = torch.device("cuda:0")
+m, args, batch, times, mask, seed = _tiny_step_inputs(dev, roll=rank)          # every rank its own batch
+tr = training.EncoderTrainer(m)
+opt = training.AdamW(tr.params, tr.grads, lr=1e-3, weight_decay=0.01, flat_grads=tr.flat_grads)
+random.seed(seed)
+# the local gradient is copied right before the collective
+orig = tr.all_reduce_mean
+local = {}
+def spy():
+    local["g"] = tr.flat_grads.clone()
+    orig()
+tr.all_reduce_mean = spy
+training.training_step(args, m, tr, opt, batch, times, mask)
+both = [torch.empty_like(local["g"]) for _ in range(2)]
+dist.all_gather(both, local["g"])
+want = (both[0].double() + both[1].double()) / 2
+err = float((tr.flat_grads.double() - want).abs().max() / want.abs().max())
+assert float((both[0] - both[1]).abs().max()) > 0, "the two ranks saw the same batch"
+assert err < 1e-6, err
+flat_p = torch.cat([p.detach().reshape(-1) for p in tr.params.values()])
+ps = [torch.empty_like(flat_p) for _ in range(2)]
+dist.all_gather(ps, flat_p)
+assert torch.equal(ps[0], ps[1]), "parameters diverged across ranks"
+print("DP_OK", err)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_step_averages_gradients_over_ranks(dev, tmp_path):
+    """Two ranks (gloo here: they share the one GPU; RCCL on a node) run one training step on DIFFERENT batches: the gradient
+    each optimizer sees is the mean of the two local gradients (one all-reduce over the flat buffer) and the updated
+    parameters are bit-identical on both ranks (DistributedDataParallel's contract, train_retriever.py:260-266)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), REPO],
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT="29541"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("DP_OK" in o for o in outs), [o[-2000:] for o in outs]
+
+
+def test_main_retriever_do_train_two_ranks(dev, tmp_path):
+    """``main_retriever.py --do_train`` as torch.distributed.run starts it (one process per rank; gloo on this one-GPU box):
+    DistributedSampler shares of the triples, averaged gradients, every rank validates, rank 0 writes the checkpoints."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    from test_gpu_pipeline import _write_dataset
+    from rag4dyg_amd import annotation
+    base = _write_dataset(str(tmp_path), n_train=96, n_val=40, n_test=37, seed=4)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        np.random.seed(1)
+        annotation.main(["retrieval_data_annotation.py", "toy", "4", "0.3"])
+    finally:
+        os.chdir(cwd)
+    ret = tmp_path / "resources" / "toy" / "4" / "train_retrieval"
+    torch.save(torch.rand(96) * 20, tmp_path / "resources" / "toy_train_query_time.pt")
+    out = tmp_path / "out"
+    out.mkdir()
+    argv = (f"--dataset toy --timestamp 4 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
+            f"--train_data_file {base}/train.link_prediction --train_pair_data_file {ret}/train_index.retrieval "
+            f"--eval_data_file {base}/val.link_prediction --eval_data_gt_file {ret}/val_score.retrieval "
+            f"--test_data_file {base}/test.link_prediction --test_data_gt_file {ret}/test_score.retrieval "
+            f"--block_size 512 --n_layer 2 --n_head 2 --n_embed 64 --topK 5 --seed 3 --do_train --per_gpu_train_batch_size 16 "
+            f"--num_train_epochs 3 --learning_rate 2e-3 --warmup_steps 0 --lambda_decay 0.05 --alpha 0.1 --temperature 0.2 "
+            f"--patience 10 --gradient_accumulation_steps 2").split()
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, R4D_DIST_BACKEND="gloo", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                   RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29542")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "main_retriever.py")] + argv, cwd=tmp_path, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    done = [pr.communicate(timeout=900) for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), [e[-2500:] for _, e in done]
+    import re
+    per_rank = [[float(x) for x in re.findall(r"val_hit@3 ([0-9.eE+-]+)", o)] for o, _ in done]
+    assert len(per_rank[0]) == 3 and per_rank[0] == per_rank[1]                # same weights on both ranks -> same validation
+    assert (out / "checkpoint-1" / "pytorch_model.bin").exists() and (out / "checkpoint-1" / "optimizer.pt").exists()
+    assert all("test_metrics last epoch" in o for o, _ in done)
+
+
 # ------------------------------------------------------------------------------------------------ single backward ops
 def _stream():
     return torch.cuda.current_stream().cuda_stream
