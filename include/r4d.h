@@ -313,6 +313,23 @@ typedef struct r4d_gpt2_grads {
     const r4d_gpt2_layer_grads* layers;   /* HOST array [n_layer] */
 } r4d_gpt2_grads;
 
+/* nn.Dropout of the training forward (model.train(), train_retriever.py:161): embd_p after wte + wpe (modeling_gpt2.py:337,427),
+ * attn_p on the attention probabilities (:153), resid_p on the two residual branches (:194, :212).  Masks come from a
+ * counter-based generator (Philox-4x32-10 keyed by `seed`, counter = (element index / 4, site, step)): the SAME struct must be
+ * passed to the forward and the backward call of a step; change `step` every step.  Sites: 4 * layer + {0: attention
+ * probabilities, 1: attention branch, 2: MLP branch}, R4D_DROPOUT_SITE_EMBD for the embeddings; element index = offset in the
+ * concatenated [rows, d] activations (rows of all batches in call order), for the probabilities the offset in the step's
+ * [B*H, T, ceil128(T)] blocks laid end to end in batch order.  A null pointer (or all p == 0) is the identity (model.eval()). */
+typedef struct {
+    float embd_p, attn_p, resid_p;
+    uint64_t seed, step;
+} r4d_train_dropout;
+#define R4D_DROPOUT_SITE_EMBD 65535u
+/* out = (resid_d ? resid_d : 0) + dropout_p(x_d) for one site (per-op tests; the kernel the step launches).  n and
+ * index_base multiples of 4; out_d may be x_d or resid_d. */
+int r4d_dropout_f32(const float* x_d, const float* resid_d, int64_t n, float* out_d, float p, uint64_t seed, uint64_t step,
+                    uint32_t site, uint64_t index_base, void* stream);
+
 /* Scratch of one step: the activations the backward pass needs (16 * rows * d floats per layer + the attention
  * probabilities) and the backward temporaries.  The SAME buffer goes to the forward and to the backward call. */
 size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs, const int32_t* Ts);
@@ -321,13 +338,14 @@ size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_grou
  * weights change every step).  out_meanpool_d f32 [sum(Bs), d] = torch.mean(h, dim=1) per sequence. */
 int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts, float* out_meanpool_d,
-                               void* workspace_d, size_t workspace_bytes, void* stream);
+                               const r4d_train_dropout* dropout, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Backward of the call above (same arguments, same workspace contents): d_meanpool_d f32 [sum(Bs), d] = dLoss / d(embeddings)
  * -> every gradient of `grads` is OVERWRITTEN with dLoss / d(parameter) (lm_head is not on this path: the retriever discards
  * the logits, train_retriever.py:177-179). */
 int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_gpt2_grads* grads,
                                 int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
-                                const float* d_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream);
+                                const float* d_meanpool_d, const r4d_train_dropout* dropout,
+                                void* workspace_d, size_t workspace_bytes, void* stream);
 /* Single backward ops, exported for per-op parity tests (the kernels the step launches). */
 /* Conv1D parameter gradients (modeling_utils.py:1267-1271 under autograd): dw_d [in,out] = x^T . dy, db_d [out] (nullable) =
  * column sums of dy, for x_d [rows,in] and dy_d [rows,out]; in / out multiples of 4. */

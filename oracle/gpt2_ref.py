@@ -41,7 +41,7 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
-def attn_core(q, k, v):
+def attn_core(q, k, v, drop=None):
     """``Attention._attn`` -- ``models/modeling_gpt2.py:140-160`` with ``scale=True`` (:338).
 
     q [B,H,T,hd], k [B,H,hd,T], v [B,H,T,hd].  The mask is the reference's
@@ -54,10 +54,12 @@ def attn_core(q, k, v):
     b = torch.tril(torch.ones(ns, ns, dtype=w.dtype))[ns - nd:ns, :ns].view(1, 1, nd, ns)
     w = w * b - 1e4 * (1 - b)
     w = torch.softmax(w, dim=-1)
+    if drop is not None:
+        w = drop(w)                                       # attn_dropout, :153 (training mode only)
     return torch.matmul(w, v)
 
 
-def attention(x, sd, prefix, n_head):
+def attention(x, sd, prefix, n_head, drop=None):
     """``Attention.forward`` -- ``models/modeling_gpt2.py:177-197`` (no past, no masks)."""
     B, T, d = x.shape
     hd = d // n_head
@@ -66,7 +68,7 @@ def attention(x, sd, prefix, n_head):
     q = q.view(B, T, n_head, hd).permute(0, 2, 1, 3)      # split_heads :166-172
     k = k.view(B, T, n_head, hd).permute(0, 2, 3, 1)      # k=True -> [B,H,hd,T]
     v = v.view(B, T, n_head, hd).permute(0, 2, 1, 3)
-    a = attn_core(q, k, v)
+    a = attn_core(q, k, v, drop)
     a = a.permute(0, 2, 1, 3).contiguous().view(B, T, d)  # merge_heads :161-164
     return conv1d(a, sd[prefix + "c_proj.weight"], sd[prefix + "c_proj.bias"])
 
@@ -77,12 +79,18 @@ def mlp(x, sd, prefix):
     return conv1d(h, sd[prefix + "c_proj.weight"], sd[prefix + "c_proj.bias"])
 
 
-def block(x, sd, i, n_head, eps):
-    """``Block.forward`` -- ``models/modeling_gpt2.py:224-235`` (pre-LN residual)."""
+def block(x, sd, i, n_head, eps, drop=None):
+    """``Block.forward`` -- ``models/modeling_gpt2.py:224-235`` (pre-LN residual).  ``drop(kind, layer, tensor)`` (training
+    mode only) stands for the three nn.Dropout modules of a block: "attn" (:153), "resid_attn" (:194), "resid_mlp" (:212)."""
     p = f"transformer.h.{i}."
-    a = attention(layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps), sd, p + "attn.", n_head)
+    a = attention(layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps), sd, p + "attn.", n_head,
+                  None if drop is None else (lambda w: drop("attn", i, w)))
+    if drop is not None:
+        a = drop("resid_attn", i, a)
     x = x + a
     m = mlp(layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps), sd, p + "mlp.")
+    if drop is not None:
+        m = drop("resid_mlp", i, m)
     return x + m
 
 
@@ -94,7 +102,7 @@ def n_layers_of(sd):
 
 
 @torch.no_grad()
-def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logits=True, want_layers=False):
+def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logits=True, want_layers=False, drop=None):
     """``GPT2Model.forward`` + ``GPT2LMHeadModel.forward`` --
     ``models/modeling_gpt2.py:400-509,583-603`` (== ``models/modeling_rag.py:455-564,664-687``).
 
@@ -110,9 +118,11 @@ def gpt2_forward(sd, input_ids, n_head, eps=1e-5, inputs_embeds=None, want_logit
         inputs_embeds = wte[input_ids]
     T = inputs_embeds.shape[1]
     x = inputs_embeds + wpe[torch.arange(T)].unsqueeze(0)
+    if drop is not None:
+        x = drop("embd", None, x)                         # self.drop, :337,427 (training mode only)
     layers = [x]
     for i in range(n_layers_of(sd)):
-        x = block(x, sd, i, n_head, eps)
+        x = block(x, sd, i, n_head, eps, drop)
         layers.append(x)
     h = layer_norm(x, sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"], eps)
     out = {"hidden": h}

@@ -91,12 +91,15 @@ def aug(batch_seqs, eta, gamma, mask_token):
 
 
 def training_step(sd, n_head, anchor, pos, neg, all_times, idx, eta, gamma, alpha, temperature, decay_rate, mask_token,
-                  seed, with_grad=False):
+                  seed, with_grad=False, drop=None):
     """The loss of one ``train_epoch`` iteration (``train/train_retriever.py:177-196``): three forwards + time-decayed
     contrastive loss, two augmented forwards + alpha * InfoNCE.  ``with_grad``: ``sd`` tensors must require grad; the
     returned loss is then differentiable (gradient fixtures)."""
     fwd = gpt2_ref.gpt2_forward.__wrapped__ if with_grad else gpt2_ref.gpt2_forward
-    emb = lambda ids: fwd(sd, ids, n_head, want_logits=False)["hidden"].mean(dim=1)
+    def emb(ids):                                         # ``drop``: a PhiloxDropout (training mode), told each batch's shape
+        if drop is not None:
+            drop.next_group(ids.shape[0], ids.shape[1])
+        return fwd(sd, ids, n_head, want_logits=False, drop=drop)["hidden"].mean(dim=1)
     h_a, h_p, h_n = emb(anchor), emb(pos), emb(neg)
     t = torch.as_tensor(all_times)
     cl = cltime_loss(temperature, decay_rate, h_a, h_p, h_n, t[idx[:, 0:1]], t[idx[:, 1:2]], t[idx[:, 2:3]])
@@ -126,3 +129,68 @@ def adamw_step(p, g, m, v, t, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0
     if weight_decay > 0.0:
         p = p - lr * weight_decay * p
     return p, m, v
+
+
+# ------------------------------------------------------------------------------------------------ dropout masks
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on numpy uint64 arrays
+    holding 32-bit words: ten rounds of (hi, lo) = M * c, key bumped by the Weyl constants after every round.  The device
+    generator (``rag4dyg_amd/csrc/train_ops.hip``) is this function."""
+    import numpy as np
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0) & MASK, np.uint64(k1) & MASK
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return c0, c1, c2, c3
+
+
+def philox_keep(n, p, seed, step, site, base=0):
+    """Keep-mask (bool [n]) of dropout probability ``p`` for elements base .. base + n - 1 of ``site`` at ``step``: element e takes
+    word e % 4 of the Philox block with counter (e // 4 low word, site + (e // 4 high word << 16), step low, step high) and key
+    (seed low, seed high); kept iff word >= floor(p * 2^32)."""
+    import numpy as np
+    assert n % 4 == 0 and base % 4 == 0
+    blk = np.arange(base // 4, (base + n) // 4, dtype=np.uint64)
+    site_w = np.uint64(site) + ((blk >> np.uint64(32)) << np.uint64(16))
+    w = philox4x32_10(blk & np.uint64(0xFFFFFFFF), site_w, np.uint64(step & 0xFFFFFFFF), np.uint64(step >> 32),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = np.stack(w, axis=1).reshape(-1)
+    return words >= np.uint64(int(p * 4294967296.0))
+
+
+class PhiloxDropout:
+    """The dropout modules of the training forward with the product's mask generator and element numbering (``include/r4d.h``
+    r4d_train_dropout): [rows, d] activations are numbered over the concatenated rows of a step's batches in call order,
+    attention probabilities over the [B*H, T, ceil128(T)] blocks laid end to end.  ``next_group(B, T)`` before each forward."""
+    SITE_EMBD = 65535
+
+    def __init__(self, embd_p, attn_p, resid_p, seed, step):
+        self.p = {"embd": embd_p, "attn": attn_p, "resid_attn": resid_p, "resid_mlp": resid_p}
+        self.seed, self.step = seed, step
+        self.row_next = self.p_next = 0
+        self.row0 = self.p0 = 0
+        self.masks = {}
+
+    def next_group(self, B, T):
+        self.row0, self.p0 = self.row_next, self.p_next
+        self.row_next += B * T
+        self._BT = (B, T)
+
+    def __call__(self, kind, layer, x):
+        p = self.p[kind]
+        if p <= 0:
+            return x
+        if kind == "attn":
+            B, H, T, _ = x.shape
+            ld = (T + 127) // 128 * 128
+            if layer == 0:
+                self.p_next = self.p0 + B * H * T * ld
+            keep = philox_keep(B * H * T * ld, p, self.seed, self.step, 4 * layer, self.p0).reshape(B, H, T, ld)[..., :T]
+        else:
+            site = self.SITE_EMBD if kind == "embd" else 4 * layer + (1 if kind == "resid_attn" else 2)
+            keep = philox_keep(x.numel(), p, self.seed, self.step, site, self.row0 * x.shape[-1]).reshape(tuple(x.shape))
+        m = torch.from_numpy(keep).to(x.dtype) / (1.0 - p)
+        return x * m

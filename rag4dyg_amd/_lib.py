@@ -4,7 +4,7 @@ The product path has NO fallback: if the shared library is missing or a call fai
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: tools/ A/B tuning only
@@ -35,6 +35,10 @@ class GreedyStateC(Structure):
 class GPT2LayerGradsC(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_1_w", "ln_1_b", "c_attn_w", "c_attn_b", "attn_proj_w", "attn_proj_b",
                                          "ln_2_w", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b")]
+
+
+class TrainDropoutC(Structure):                 # r4d_train_dropout
+    _fields_ = [("embd_p", c_float), ("attn_p", c_float), ("resid_p", c_float), ("seed", c_uint64), ("step", c_uint64)]
 
 
 class GPT2GradsC(Structure):
@@ -94,9 +98,10 @@ PROTOTYPES = {
     "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_gpt2_train_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "r4d_gpt2_train_forward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), c_int32, POINTER(_P), POINTER(c_int32),
-                                             POINTER(c_int32), _P, _P, c_size_t, _P]),
+                                             POINTER(c_int32), _P, POINTER(TrainDropoutC), _P, c_size_t, _P]),
     "r4d_gpt2_train_backward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GPT2GradsC), c_int32, POINTER(_P),
-                                              POINTER(c_int32), POINTER(c_int32), _P, _P, c_size_t, _P]),
+                                              POINTER(c_int32), POINTER(c_int32), _P, POINTER(TrainDropoutC), _P, c_size_t, _P]),
+    "r4d_dropout_f32": (c_int32, [_P, _P, c_int64, _P, c_float, c_uint64, c_uint64, c_uint32, c_uint64, _P]),
     "r4d_weight_grad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_weight_grad_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),

@@ -89,6 +89,12 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
                        const float* ln_b = nullptr, float ln_eps = 0.f);
 
+// ------------------------------------------------------------------ train_ops.hip
+struct DropKey { unsigned seed_lo, seed_hi, step_lo, step_hi; };      // Philox key (seed) and counter words 2-3 (step)
+// out = (resid ? resid : 0) + dropout_p(x): element i uses counter (base + i) / 4 of `site`; out may alias x / resid
+int launch_dropout(const float* x, const float* resid, long long n, float* out, float p, DropKey key, unsigned site,
+                   unsigned long long base, hipStream_t s);
+
 // ------------------------------------------------------------------ topk.hip
 // rows x n values -> rows x k best (value, global index), canonical order; `counters_zeroed`: the caller already cleared
 // the ticket counters (first rows * 4 bytes of ws) on this stream

@@ -11,8 +11,9 @@
 // fills the chip, partials summed in a fixed order); attention backward is four batched per-head GEMMs around a row kernel
 // (dP = dO . V^T,  dS = P (dP - rowsum(P dP)) / sqrt(hd),  dQ = dS . K,  dK = dS^T . Q,  dV = P^T . dO).
 // All batches of a step (anchor, positive, negative and the two augmented views) form ONE launch sequence over their
-// concatenated rows, like the inference path.  Dropout is the identity (documented deviation: the reference trains with
-// p = 0.1 drawn from its device RNG).  Checked against the reference's autograd gradients (tests/test_gpu_training.py).
+// concatenated rows, like the inference path.  Dropout (embeddings, attention probabilities, both residual branches) draws
+// its masks from a counter-based generator (train_ops.hip), so the backward regenerates them instead of storing them; the
+// reference's torch RNG stream cannot be reproduced, the distribution and the calculus are the same.  Checked against the reference's autograd gradients (tests/test_gpu_training.py).
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -141,7 +142,24 @@ static int bwd_weight(const float* x, const float* dy, int M, int K, int N, floa
 }
 
 // Attention._attn forward over one batch, probabilities kept in P [B*H, T, ld] with EVERY column right of the diagonal zero
-static int attn_fwd(const float* qkv, int B, int T, int H, int d, float* P, float* out, hipStream_t s) {
+struct DropCtx {                                                  // dropout of one step; p == 0 everywhere -> identity
+    float embd_p, attn_p, resid_p;
+    DropKey key;
+    bool on() const { return embd_p > 0.f || attn_p > 0.f || resid_p > 0.f; }
+};
+static int drop_ctx(const r4d_train_dropout* dp, DropCtx& c) {
+    c = DropCtx{0.f, 0.f, 0.f, DropKey{0, 0, 0, 0}};
+    if (!dp) return R4D_OK;
+    R4D_REQUIRE(dp->embd_p >= 0.f && dp->embd_p < 1.f && dp->attn_p >= 0.f && dp->attn_p < 1.f && dp->resid_p >= 0.f && dp->resid_p < 1.f,
+                "gpt2 train: dropout probabilities must be in [0, 1)");
+    c.embd_p = dp->embd_p; c.attn_p = dp->attn_p; c.resid_p = dp->resid_p;
+    c.key = DropKey{(unsigned)dp->seed, (unsigned)(dp->seed >> 32), (unsigned)dp->step, (unsigned)(dp->step >> 32)};
+    return R4D_OK;
+}
+
+// `Pdrop` (with attn_p > 0): scratch for the dropped-out probabilities the P.V product reads; P keeps the softmax output
+static int attn_fwd(const float* qkv, int B, int T, int H, int d, float* P, float* out, hipStream_t s, float attn_p = 0.f,
+                    DropKey key = DropKey{0, 0, 0, 0}, unsigned site = 0, unsigned long long pbase = 0, float* Pdrop = nullptr) {
     const int hd = d / H, ld = tpad128(T);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -154,8 +172,13 @@ static int attn_fwd(const float* qkv, int B, int T, int H, int d, float* P, floa
     int rc = launch_gemm_f32(g, s);
     if (rc) return rc;
     if ((rc = launch_causal_softmax(P, B * H, T, ld, ld, s))) return rc;          // row_tile = ld: zero-fill the whole row
+    const float* Pv = P;
+    if (attn_p > 0.f) {                                                            // attn_dropout(w), modeling_gpt2.py:153
+        if ((rc = launch_dropout(P, nullptr, (long long)B * H * T * ld, Pdrop, attn_p, key, site, pbase, s))) return rc;
+        Pv = Pdrop;
+    }
     memset(&g, 0, sizeof(g));
-    g.A = P; g.B = qkv + 2 * d; g.C = out;
+    g.A = Pv; g.B = qkv + 2 * d; g.C = out;
     g.M = T; g.N = hd; g.K = T; g.lda = ld; g.ldb = 3 * d; g.ldc = d;
     g.b_trans = 0; g.b_rows = T; g.nbatch = B * H; g.nb1 = H;
     g.sA0 = (long long)H * T * ld; g.sA1 = (long long)T * ld;
@@ -166,7 +189,8 @@ static int attn_fwd(const float* qkv, int B, int T, int H, int d, float* P, floa
 
 // Attention backward over one batch: dao [B,T,d] (merged heads) -> dqkv [B,T,3d]
 static int attn_bwd(const float* qkv, const float* P, const float* dao, int B, int T, int H, int d, float* dqkv, float* dP,
-                    float* PT, hipStream_t s) {
+                    float* PT, hipStream_t s, float attn_p = 0.f, DropKey key = DropKey{0, 0, 0, 0}, unsigned site = 0,
+                    unsigned long long pbase = 0) {
     const int hd = d / H, ld = tpad128(T), Tp = up4(T);
     const long long sP0 = (long long)H * T * ld, sP1 = (long long)T * ld;
     const long long sQ0 = (long long)T * 3 * d, sO0 = (long long)T * d;
@@ -180,6 +204,8 @@ static int attn_bwd(const float* qkv, const float* P, const float* dao, int B, i
     g.sA0 = sO0; g.sA1 = hd; g.sB0 = sQ0; g.sB1 = hd; g.sC0 = sP0; g.sC1 = sP1;
     g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
     if ((rc = launch_gemm_f32(g, s))) return rc;
+    if (attn_p > 0.f &&                                          // through attn_dropout: d(softmax out) = mask * dP / (1 - p)
+        (rc = launch_dropout(dP, nullptr, (long long)B * H * T * ld, dP, attn_p, key, site, pbase, s))) return rc;
     // dS (in place), logits were divided by sqrt(hd) before the softmax
     if ((rc = launch_softmax_bwd(P, dP, B * H, T, ld, (float)sqrt((double)hd), s))) return rc;
     // dQ = dS . K
@@ -199,8 +225,13 @@ static int attn_bwd(const float* qkv, const float* P, const float* dao, int B, i
     g.sA0 = sP0; g.sA1 = sP1; g.sB0 = sQ0; g.sB1 = hd; g.sC0 = sQ0; g.sC1 = hd;
     g.epilogue = EPI_NONE; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
     if ((rc = launch_gemm_f32(g, s))) return rc;
-    // dV = P^T . dO
-    if ((rc = launch_transpose(P, T, T, ld, sP1, PT, ld, sP1, B * H, s))) return rc;
+    // dV = P^T . dO  (the probabilities the forward multiplied V with: after dropout; dP's buffer is free by now)
+    const float* Pv = P;
+    if (attn_p > 0.f) {
+        if ((rc = launch_dropout(P, nullptr, (long long)B * H * T * ld, dP, attn_p, key, site, pbase, s))) return rc;
+        Pv = dP;
+    }
+    if ((rc = launch_transpose(Pv, T, T, ld, sP1, PT, ld, sP1, B * H, s))) return rc;
     memset(&g, 0, sizeof(g));
     g.A = PT; g.B = dao; g.C = dqkv + 2 * d;
     g.M = T; g.N = hd; g.K = Tp; g.lda = ld; g.ldb = d; g.ldc = 3 * d;
@@ -254,11 +285,13 @@ size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_grou
 
 int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts, float* out_meanpool_d,
-                               void* workspace_d, size_t workspace_bytes, void* stream) {
+                               const r4d_train_dropout* dropout, void* workspace_d, size_t workspace_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     std::vector<TrainGroup> gs;
     int rc = check_groups(cfg, n_groups, ids_d, Bs, Ts, gs);
     if (rc) return rc;
+    DropCtx dc;
+    if ((rc = drop_ctx(dropout, dc))) return rc;
     R4D_REQUIRE(w && w->wte && w->wpe && w->ln_f_w && w->ln_f_b && w->layers && out_meanpool_d, "gpt2 train: null pointer");
     const TrainLayout t = layout(cfg, gs.data(), n_groups);
     if (!workspace_d || workspace_bytes < t.total * sizeof(float)) {
@@ -278,15 +311,27 @@ int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
         else
             rc = launch_layernorm(x_in, Lw.ln_1_w, Lw.ln_1_b, M, d, cfg->ln_eps, ln1, s);
         if (rc) return rc;
+        if (l == 0 && dc.embd_p > 0.f) {                             // self.drop(inputs_embeds + position_embeds), :427
+            if ((rc = launch_dropout(x_in, nullptr, (long long)M * d, x_in, dc.embd_p, dc.key, R4D_DROPOUT_SITE_EMBD, 0, s))) return rc;
+            if ((rc = launch_layernorm(x_in, Lw.ln_1_w, Lw.ln_1_b, M, d, cfg->ln_eps, ln1, s))) return rc;
+        }
         if ((rc = fwd_linear(ln1, Lw.c_attn_w, Lw.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
         for (const TrainGroup& G : gs)
-            if ((rc = attn_fwd(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws + t.P[l] + G.p0, att + G.row0 * d, s))) return rc;
-        if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s))) return rc;
+            if ((rc = attn_fwd(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws + t.P[l] + G.p0, att + G.row0 * d, s, dc.attn_p, dc.key,
+                               4u * l + 0u, G.p0, ws + t.dP))) return rc;
+        float* branch = ws + t.dy;                                   // a backward temporary, free during the forward
+        if (dc.resid_p > 0.f) {                                      // x + resid_dropout(c_proj(a)), :194,229
+            if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_b, nullptr, M, d, d, EPI_NONE, branch, s))) return rc;
+            if ((rc = launch_dropout(branch, x_in, (long long)M * d, x_mid, dc.resid_p, dc.key, 4u * l + 1u, 0, s))) return rc;
+        } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s))) return rc;
         if ((rc = launch_layernorm(x_mid, Lw.ln_2_w, Lw.ln_2_b, M, d, cfg->ln_eps, ln2, s))) return rc;
         if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s))) return rc;
         if ((rc = launch_gelu_fwd(pre, (long long)M * 4 * d, f, s))) return rc;
         float* x_next = l + 1 < cfg->n_layer ? ws + t.x_in[l + 1] : ws + t.x_out;
-        if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s))) return rc;
+        if (dc.resid_p > 0.f) {                                      // x + dropout(c_proj(act(c_fc(x)))), :212,233
+            if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s))) return rc;
+            if ((rc = launch_dropout(branch, x_mid, (long long)M * d, x_next, dc.resid_p, dc.key, 4u * l + 2u, 0, s))) return rc;
+        } else if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s))) return rc;
     }
     return launch_lnf_meanpool_groups(R, ws + t.x_out, w->ln_f_w, w->ln_f_b, d, cfg->ln_eps, nullptr, out_meanpool_d,
                                       ws + t.pool_scratch, s);
@@ -294,11 +339,14 @@ int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
 
 int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const r4d_gpt2_grads* gr,
                                 int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
-                                const float* d_meanpool_d, void* workspace_d, size_t workspace_bytes, void* stream) {
+                                const float* d_meanpool_d, const r4d_train_dropout* dropout, void* workspace_d,
+                                size_t workspace_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     std::vector<TrainGroup> gs;
     int rc = check_groups(cfg, n_groups, ids_d, Bs, Ts, gs);
     if (rc) return rc;
+    DropCtx dc;
+    if ((rc = drop_ctx(dropout, dc))) return rc;
     R4D_REQUIRE(w && w->layers && gr && gr->layers && gr->wte && gr->wpe && gr->ln_f_w && gr->ln_f_b && d_meanpool_d,
                 "gpt2 train backward: null pointer");
     const TrainLayout t = layout(cfg, gs.data(), n_groups);
@@ -321,23 +369,35 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
         float *x_in = ws + t.x_in[l], *ln1 = ws + t.ln1[l], *qkv = ws + t.qkv[l], *att = ws + t.att[l];
         float *x_mid = ws + t.x_mid[l], *ln2 = ws + t.ln2[l], *pre = ws + t.pre[l], *f = ws + t.f[l];
         // ---- MLP: x_out = x_mid + gelu(ln_2(x_mid) Wfc + bfc) Wp + bp ;  dx holds d(x_out)
-        if ((rc = bwd_weight(f, dx, M, 4 * d, d, Lg.mlp_proj_w, Lg.mlp_proj_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dx, Lw.mlp_proj_w, M, 4 * d, d, dbig, s))) return rc;                         // d(f)
+        const float* dbr = dx;                                       // gradient of the branch output: through its dropout mask
+        if (dc.resid_p > 0.f) {
+            if ((rc = launch_dropout(dx, nullptr, (long long)M * d, dy, dc.resid_p, dc.key, 4u * l + 2u, 0, s))) return rc;
+            dbr = dy;
+        }
+        if ((rc = bwd_weight(f, dbr, M, 4 * d, d, Lg.mlp_proj_w, Lg.mlp_proj_b, xT, red, s))) return rc;
+        if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s))) return rc;                        // d(f)
         if ((rc = launch_gelu_bwd(pre, dbig, (long long)M * 4 * d, dbig, s))) return rc;                  // d(pre), in place
         if ((rc = bwd_weight(ln2, dbig, M, d, 4 * d, Lg.c_fc_w, Lg.c_fc_b, xT, red, s))) return rc;
         if ((rc = bwd_data(dbig, Lw.c_fc_w, M, d, 4 * d, dy, s))) return rc;                              // d(ln_2 out)
         if ((rc = launch_ln_bwd(x_mid, Lw.ln_2_w, dy, dx, M, d, cfg->ln_eps, dx, Lg.ln_2_w, Lg.ln_2_b, red, 0, s))) return rc;   // dx = d(x_mid)
         // ---- attention: x_mid = x_in + attn(ln_1(x_in)) Wo + bo
-        if ((rc = bwd_weight(att, dx, M, d, d, Lg.attn_proj_w, Lg.attn_proj_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dx, Lw.attn_proj_w, M, d, d, dy, s))) return rc;                               // d(att), merged heads
+        dbr = dx;
+        if (dc.resid_p > 0.f) {                                      // dbig (M x 4d) is free here
+            if ((rc = launch_dropout(dx, nullptr, (long long)M * d, dbig, dc.resid_p, dc.key, 4u * l + 1u, 0, s))) return rc;
+            dbr = dbig;
+        }
+        if ((rc = bwd_weight(att, dbr, M, d, d, Lg.attn_proj_w, Lg.attn_proj_b, xT, red, s))) return rc;
+        if ((rc = bwd_data(dbr, Lw.attn_proj_w, M, d, d, dy, s))) return rc;                              // d(att), merged heads
         for (const TrainGroup& G : gs)
             if ((rc = attn_bwd(qkv + G.row0 * 3 * d, ws + t.P[l] + G.p0, dy + G.row0 * d, G.B, G.T, H, d, dqkv + G.row0 * 3 * d,
-                               ws + t.dP, ws + t.PT, s))) return rc;
+                               ws + t.dP, ws + t.PT, s, dc.attn_p, dc.key, 4u * l + 0u, G.p0))) return rc;
         if ((rc = bwd_weight(ln1, dqkv, M, d, 3 * d, Lg.c_attn_w, Lg.c_attn_b, xT, red, s))) return rc;
         if ((rc = bwd_data(dqkv, Lw.c_attn_w, M, d, 3 * d, dy, s))) return rc;                            // d(ln_1 out)
         if ((rc = launch_ln_bwd(x_in, Lw.ln_1_w, dy, dx, M, d, cfg->ln_eps, dx, Lg.ln_1_w, Lg.ln_1_b, red, 0, s))) return rc;    // dx = d(x_in)
     }
-    // embeddings: x_in[0] = wte[ids] + wpe[0..T-1]
+    // embeddings: x_in[0] = drop(wte[ids] + wpe[0..T-1])
+    if (dc.embd_p > 0.f && (rc = launch_dropout(dx, nullptr, (long long)M * d, dx, dc.embd_p, dc.key, R4D_DROPOUT_SITE_EMBD, 0, s)))
+        return rc;
     R4D_HIP(hipMemsetAsync(gr->wte, 0, (size_t)cfg->vocab * d * sizeof(float), s));
     R4D_HIP(hipMemsetAsync(gr->wpe, 0, (size_t)cfg->n_positions * d * sizeof(float), s));
     for (const TrainGroup& G : gs)

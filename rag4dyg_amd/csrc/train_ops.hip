@@ -237,6 +237,54 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
     dh[i] = d_pool[(row / T) * d + i % d] / (float)T;
 }
 
+// ------------------------------------------------------------------------------------ dropout
+// nn.Dropout of the training forward (modeling_gpt2.py:114-115,153,194,207-212,337,427): keep with probability 1 - p, scale the
+// kept values by 1 / (1 - p).  The reference draws its masks from torch's device RNG stream, which no other implementation can
+// reproduce; this build draws them from a COUNTER-BASED generator -- Philox-4x32-10 (Salmon et al., SC'11) keyed by the run's
+// seed, counter = (element index / 4, site, step low, step high) -- so a mask is a pure function of (seed, step, site, index):
+// nothing is stored between forward and backward (the backward regenerates it), the result does not depend on the launch
+// geometry, and the oracle restates the generator in numpy (oracle/train_ref.py philox_keep) to check forward AND gradients.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+// out[i] = (resid ? resid[i] : 0) + keep(base + i) * x[i] / (1 - p), four elements (one Philox block) per thread; n, base % 4 == 0
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, const float* resid, long long n4, float* out,
+                                                      unsigned threshold, float scale, DropKey key, unsigned site,
+                                                      unsigned long long base4) {   // resid / x may alias out
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const unsigned long long c = base4 + (unsigned long long)i;
+    const uint4 r = philox4x32_10(make_uint4((unsigned)c, site + ((unsigned)(c >> 32) << 16), key.step_lo, key.step_hi),
+                                  make_uint2(key.seed_lo, key.seed_hi));
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o = make_float4(r.x >= threshold ? v.x * scale : 0.f, r.y >= threshold ? v.y * scale : 0.f,
+                           r.z >= threshold ? v.z * scale : 0.f, r.w >= threshold ? v.w * scale : 0.f);
+    if (resid) {
+        const float4 q = reinterpret_cast<const float4*>(resid)[i];
+        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+
+int launch_dropout(const float* x, const float* resid, long long n, float* out, float p, DropKey key, unsigned site,
+                   unsigned long long base, hipStream_t s) {
+    R4D_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%g outside [0, 1)", (double)p);
+    R4D_REQUIRE(n % 4 == 0 && base % 4 == 0 && site < 65536u, "dropout: n=%lld base=%llu must be multiples of 4", n, base);
+    if (n == 0) return R4D_OK;
+    const unsigned threshold = (unsigned)((double)p * 4294967296.0);               // keep iff u32 >= threshold
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, resid, n / 4, out, threshold,
+                       1.0f / (1.0f - p), key, site, base / 4);
+    R4D_CHECK_LAUNCH("dropout");
+    return R4D_OK;
+}
+
 // ------------------------------------------------------------------------------------ optimizer
 // accum[0] += sum x^2 (the total feeds clip_grad_norm_, train_retriever.py:210).  Two stages, no atomics: the value must be
 // the same bits on every data-parallel rank (same gradients after the all-reduce), or the clip coefficient -- and with it the
@@ -424,6 +472,12 @@ int r4d_gelu_new_bwd_f32(const float* pre_d, const float* dy_d, int64_t n, float
 int r4d_causal_softmax_bwd_f32(const float* p_d, float* dp_d, int32_t nbh, int32_t T, int32_t ld, float scale_div, void* stream) {
     R4D_REQUIRE(p_d && dp_d && nbh >= 1, "causal_softmax_bwd: bad arguments");
     return launch_softmax_bwd(p_d, dp_d, nbh, T, ld, scale_div, (hipStream_t)stream);
+}
+int r4d_dropout_f32(const float* x_d, const float* resid_d, int64_t n, float* out_d, float p, uint64_t seed, uint64_t step,
+                    uint32_t site, uint64_t index_base, void* stream) {
+    R4D_REQUIRE(x_d && out_d && n >= 0, "dropout: bad arguments");
+    const DropKey key{(unsigned)seed, (unsigned)(seed >> 32), (unsigned)step, (unsigned)(step >> 32)};
+    return launch_dropout(x_d, resid_d, n, out_d, p, key, site, index_base, (hipStream_t)stream);
 }
 int r4d_sumsq_accumulate_f32(const float* x_d, int64_t n, float* accum_d, void* stream) {
     R4D_REQUIRE(x_d && accum_d && n >= 0, "sumsq: bad arguments");

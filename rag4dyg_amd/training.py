@@ -1,14 +1,15 @@
-"""Retriever TRAINING step, forward side (staged): the data, the augmentation, the five encoder
-forwards on the gfx950 kernels and the two contrastive losses of one ``train_epoch`` iteration.
+"""Retriever TRAINING: the data, the augmentation, one ``train_epoch`` iteration on the gfx950 kernels
+(five encoder forwards with saved activations, the two contrastive losses, the encoder's backward pass, gradient clipping and
+the AdamW update) and the training loop of ``main_retriever.py --do_train``.
 
-Mirrors ``dataloader/retriever.py:68-111`` (``PairSequenceDataset``), ``models/modeling_rag.py:774-840`` (``_aug``) and
-``train/train_retriever.py:40-98,177-196`` (``CLtime_loss``, ``mask_correlated_samples``, ``info_nce``, the step).  The
-BACKWARD pass (dgrad / wgrad of the GEMMs, LayerNorm, GELU and attention backward) and the optimizer are not built yet:
-``main_retriever.py --do_train`` still raises.  What is here runs the forward half exactly as the reference computes it in
-``model.eval()`` terms -- dropout is the identity (the reference trains with p = 0.1 drawn from its device RNG, which no
-other device reproduces) -- so that the loss values can be checked against the reference before any backward kernel exists.
-The five batches of a step (anchor, positive, hard negative, two augmented views) go through ONE fused launch sequence
-(``r4d_gpt2_encode_groups_f32``); the losses themselves are [B, 3B] / [2B, 2B] similarity tables: torch ops on the device.
+Mirrors ``dataloader/retriever.py:68-111`` (``PairSequenceDataset``), ``models/modeling_rag.py:774-840`` (``_aug``),
+``train/train_retriever.py:40-98,120-354`` (``CLtime_loss``, ``mask_correlated_samples``, ``info_nce``, ``adjust_learning_rate``,
+``train_epoch``, ``train``) and ``utils/model.py:56-102`` (checkpoints, the ``transformers.AdamW`` configuration).  The five
+batches of a step (anchor, positive, hard negative, two augmented views) go through ONE launch sequence over their concatenated
+rows (``r4d_gpt2_train_forward_f32`` / ``_backward_f32``); the losses themselves are [B, 3B] / [2B, 2B] similarity tables:
+torch ops (and torch autograd) on the [5, B, d] embeddings only.  In ``model.eval()`` terms the forward, the losses and every
+parameter gradient equal the reference's (tests/golden/g8); in training mode dropout draws its masks from the library's
+counter-based generator (the reference's torch RNG stream cannot be reproduced), checked against the oracle given the same masks.
 """
 import math
 import os
@@ -99,6 +100,9 @@ def mask_correlated_samples(batch_size):
     return mask
 
 
+_NCE_COLS = {}
+
+
 def info_nce(args, z_i, z_j, temp, batch_size, mask):
     """``train/train_retriever.py:84-98`` (the mask is rebuilt for a last, smaller batch, :92-93)."""
     N = 2 * batch_size
@@ -107,7 +111,16 @@ def info_nce(args, z_i, z_j, temp, batch_size, mask):
     positive = torch.cat((torch.diag(sim, batch_size), torch.diag(sim, -batch_size)), dim=0).reshape(N, 1)
     if mask is None or batch_size != args.per_gpu_train_batch_size:
         mask = mask_correlated_samples(batch_size)
-    negative = sim[mask.to(sim.device)].reshape(N, -1)
+    # ``sim[mask].reshape(N, -1)`` as a gather: every row of the mask keeps the same number of columns, so the selected
+    # columns are a fixed [N, N - 2] index table -- boolean indexing would make the host wait for the device (nonzero count)
+    key = (id(mask), batch_size, str(sim.device))
+    cols = _NCE_COLS.get(key)
+    if cols is None:
+        cols = mask.nonzero()[:, 1].reshape(N, -1).to(sim.device)
+        _NCE_COLS.clear()
+        _NCE_COLS[key] = cols
+        _NCE_COLS["mask"] = mask                                # keeps id(mask) from being reused while cached
+    negative = sim.gather(1, cols)
     labels = torch.zeros(N, device=sim.device).long()
     return F.cross_entropy(torch.cat((positive, negative), dim=1), labels)
 
@@ -146,8 +159,13 @@ class EncoderTrainer:
     on the GPU.  ``grads`` maps the reference's parameter names (``transformer.h.0.attn.c_attn.weight`` ...) to gradient
     tensors; ``lm_head.weight`` has none (the retriever discards the logits) unless it is the tied ``wte`` Parameter."""
 
-    def __init__(self, model):
+    def __init__(self, model, dropout=None, seed=0):
+        """``dropout``: None -> the model config's ``embd_pdrop`` / ``attn_pdrop`` / ``resid_pdrop`` when the module is in
+        training mode (``model.train()``, ``train_retriever.py:161``), the identity in eval mode; or an explicit
+        (embd_p, attn_p, resid_p).  ``seed`` keys the counter-based mask generator; every forward advances its step."""
         self.model = model
+        self.dropout, self.seed, self.step = dropout, int(seed), 0
+        self._drop_struct = None
         tr = model.transformer
         self.params = {"transformer.wte.weight": tr.wte.weight, "transformer.wpe.weight": tr.wpe.weight,
                        "transformer.ln_f.weight": tr.ln_f.weight, "transformer.ln_f.bias": tr.ln_f.bias}
@@ -188,6 +206,18 @@ class EncoderTrainer:
                             self.grads["transformer.ln_f.weight"].data_ptr(), self.grads["transformer.ln_f.bias"].data_ptr(), glayers)
         return c, w, g, (layers, glayers)
 
+    def _dropout_struct(self):
+        if self.dropout is not None:
+            pe, pa, pr = self.dropout
+        elif self.model.training:
+            c = self.model.config
+            pe, pa, pr = c.embd_pdrop, c.attn_pdrop, c.resid_pdrop
+        else:
+            return None
+        if pe <= 0 and pa <= 0 and pr <= 0:
+            return None
+        return _lib.TrainDropoutC(float(pe), float(pa), float(pr), self.seed & (2 ** 64 - 1), self.step)
+
     @torch.no_grad()
     def forward(self, batches):
         """Mean-pooled embeddings [sum B, d] of the right-padded id batches; keeps the activations for ``backward``."""
@@ -204,7 +234,10 @@ class EncoderTrainer:
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         out = torch.empty(sum(int(t.shape[0]) for t in ids), self.model.config.n_embd, dtype=torch.float32, device=dev)
+        self.step += 1
+        self._drop_struct = self._dropout_struct()                 # the backward of this step regenerates the same masks
         _lib.check(lib.r4d_gpt2_train_forward_f32(ctypes.byref(c), ctypes.byref(w), n, ptrs, Bs, Ts, out.data_ptr(),
+                                                  ctypes.byref(self._drop_struct) if self._drop_struct is not None else None,
                                                   self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
                    "gpt2_train_forward")
         self._saved = (ids, n, Bs, Ts, ptrs)
@@ -220,6 +253,7 @@ class EncoderTrainer:
         c, w, g, keep = self._structs()
         de = d_embeddings.to(torch.float32).contiguous()
         _lib.check(lib.r4d_gpt2_train_backward_f32(ctypes.byref(c), ctypes.byref(w), ctypes.byref(g), n, ptrs, Bs, Ts, de.data_ptr(),
+                                                   ctypes.byref(self._drop_struct) if self._drop_struct is not None else None,
                                                    self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
                    "gpt2_train_backward")
         self._saved = None
@@ -287,15 +321,28 @@ class AdamW:
         return float(self.sumsq[0].sqrt().item())
 
 
-def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None, micro_step=0):
+def _to_device(x, dev):
+    """Host tensor -> device through pinned memory, asynchronously: a pageable ``.to(device)`` is a blocking copy that first
+    waits for everything queued on the stream, i.e. for the previous training step."""
+    if x.is_cuda or torch.device(dev).type != "cuda":
+        return x.to(dev)
+    return x.pin_memory().to(dev, non_blocking=True)
+
+
+def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None, micro_step=0, sync=True):
     """One iteration of ``train_epoch`` (``train/train_retriever.py:164-214``) on the device: five forwards (one launch
     sequence), the two contrastive losses (torch autograd over the [5, B, d] embeddings only), the encoder's backward pass
     and -- every ``gradient_accumulation_steps``-th micro-step -- the gradient average over the data-parallel ranks,
-    gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss, stepped)."""
+    gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss, stepped); with ``sync=False`` the three
+    losses are 0-d device tensors instead of floats, so the host does not wait for the GPU and prepares the next batch (the
+    python ``random`` augmentation, ~10 ms per 64 sequences) while this one computes."""
     anchor_seq, pos_seq, neg_seq, anchor_idx, pos_idx, neg_idx = batch
     dev = args.device
-    anchor_seq, pos_seq, neg_seq = anchor_seq.to(dev), pos_seq.to(dev), neg_seq.to(dev)
+    # augmentation on the loader's HOST copy: no device-to-host round trip (and no wait for the previous step) before the launch
     aug1, aug2 = aug(anchor_seq, model.config.eta, model.config.gamma, model.config.vocab_size - 1)
+    anchor_seq, pos_seq, neg_seq, aug1, aug2 = (_to_device(x, dev) for x in (anchor_seq, pos_seq, neg_seq, aug1, aug2))
+    if all_query_time.device == anchor_seq.device:              # times resident on the GPU (train()): index them there
+        anchor_idx, pos_idx, neg_idx = (_to_device(x, dev) for x in (anchor_idx, pos_idx, neg_idx))
     B = anchor_seq.size(0)
     emb = trainer.forward([anchor_seq, pos_seq, neg_seq, aug1, aug2])
     leaf = emb.view(5, B, -1).detach().requires_grad_(True)
@@ -318,6 +365,8 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
         trainer.all_reduce_mean()
         optimizer.step(getattr(args, "max_grad_norm", 0.0))
         model.transformer.__dict__.pop("_wt_cache", None)        # transposed weight copies of the inference path are stale now
+    if not sync:
+        return dict(loss=loss.detach(), cl_loss=cl.detach(), aug_loss=au.detach(), stepped=stepped)
     return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()), stepped=stepped)
 
 
@@ -365,16 +414,17 @@ def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataload
     """``train/train_retriever.py:132-227``: one pass over the shuffled triples.  Returns (global_step, summed loss,
     summed contrastive loss, summed augmentation loss)."""
     tr_loss = tr_cl = tr_aug = 0.0
+    model.train()                                              # :161 -- dropout on (EncoderTrainer reads model.training)
     for i, batch in enumerate(train_dataloader):
         if args.lrdecay == 1:
             adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
-        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce, micro_step=i)
-        tr_loss += r["loss"]; tr_cl += r["cl_loss"]; tr_aug += r["aug_loss"]
+        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce, micro_step=i, sync=False)
+        tr_loss = tr_loss + r["loss"]; tr_cl = tr_cl + r["cl_loss"]; tr_aug = tr_aug + r["aug_loss"]   # device sums: no wait per step
         if r["stepped"]:                                       # an optimizer update (train_retriever.py:212-221)
             global_step += 1
         if args.max_steps > 0 and global_step > args.max_steps:
             break
-    return global_step, tr_loss, tr_cl, tr_aug
+    return global_step, float(tr_loss), float(tr_cl), float(tr_aug)
 
 
 def distributed_setup(args):
@@ -399,7 +449,9 @@ def train(args, train_dataset, model, tokenizer):
     the best and the last weights.  Data parallel: launched under ``torch.distributed.run`` (one process per GPU) every rank
     takes its ``DistributedSampler`` share of the triples and the gradients are averaged with one all-reduce per update (RCCL;
     ``R4D_DIST_BACKEND=gloo`` for ranks that share a card); every rank validates (identical numbers, so the early-stopping
-    decision needs no broadcast), rank 0 writes the checkpoints.  Differences: ``--fp16`` (apex) is not built (raises)."""
+    decision needs no broadcast), rank 0 writes the checkpoints.  Dropout (``model.train()``) draws its masks from the
+    library's counter-based generator keyed by ``--seed`` instead of torch's RNG stream.  Differences: ``--fp16`` (apex) is
+    not built (raises)."""
     from .dataloader import get_dataloader
     from .retriever import test
     if getattr(args, "fp16", False):
@@ -409,7 +461,7 @@ def train(args, train_dataset, model, tokenizer):
     gas = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
     if args.max_steps > 0:
         args.num_train_epochs = args.max_steps // max(1, len(train_dataloader) // gas) + 1
-    trainer = EncoderTrainer(model)
+    trainer = EncoderTrainer(model, seed=int(getattr(args, "seed", 0)) + 7919 * rank)      # every rank its own masks
     if world > 1:
         import torch.distributed as dist
         for p in trainer.params.values():                       # DistributedDataParallel's construction-time broadcast
@@ -422,6 +474,7 @@ def train(args, train_dataset, model, tokenizer):
     print("  Instantaneous batch size per GPU = {}".format(args.per_gpu_train_batch_size))
     mask_nce = mask_correlated_samples(args.per_gpu_train_batch_size)
     all_query_time = torch.load(os.path.join("resources/", args.dataset + '_train_query_time.pt'))     # get_train_query_time.py
+    all_query_time = torch.as_tensor(all_query_time).to(args.device)
     global_step, tr_loss = 0, 0.0
     best_score, best_epoch, best_state, counter = None, 0, None, 0
     snapshot = lambda: {k: v.detach().clone() for k, v in model.state_dict().items()}

@@ -346,6 +346,80 @@ def test_main_retriever_do_train_two_ranks(dev, tmp_path):
     assert all("test_metrics last epoch" in o for o, _ in done)
 
 
+# ------------------------------------------------------------------------------------------------ dropout (training mode)
+@pytest.mark.parametrize("n,p,site,base", [(4, 0.1, 0, 0), (10000, 0.1, 6, 4096), (40000, 0.5, 65535, 4 * (2 ** 32 + 5)),
+                                           (1 << 20, 0.25, 9, 0)])
+def test_dropout_kernel_equals_oracle_generator(dev, n, p, site, base):
+    """The device's Philox-4x32-10 masks are the oracle's (bit for bit), the kept values x / (1 - p) in fp32, the residual added
+    after; the keep rate is 1 - p."""
+    from oracle import train_ref
+    from rag4dyg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    x, r = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    seed, step = 0x1234_5678_9ABC_DEF0, 2 ** 33 + 17
+    keep = train_ref.philox_keep(n, p, seed, step, site, base)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    want = np.where(keep, x.numpy() * scale, np.float32(0.0)).astype(np.float32)
+    X, R = x.to(dev), r.to(dev)
+    out = torch.empty_like(X)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.r4d_dropout_f32(X.data_ptr(), None, n, out.data_ptr(), p, seed, step, site, base, st), "dropout")
+    assert np.array_equal(out.cpu().numpy(), want)
+    _lib.check(lib.r4d_dropout_f32(X.data_ptr(), R.data_ptr(), n, R.data_ptr(), p, seed, step, site, base, st), "dropout")   # in place
+    assert np.array_equal(R.cpu().numpy(), (r.numpy() + want).astype(np.float32))
+    if n >= 10000:
+        assert abs(keep.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n)
+
+
+def test_training_step_with_dropout_equals_oracle_given_the_same_masks(dev):
+    """model.train(): embeddings, loss and EVERY parameter gradient of a step with dropout 0.1 / 0.15 / 0.2 (embeddings,
+    attention probabilities, residual branches) against the oracle's grad-enabled forward applying the SAME masks (the
+    oracle restates the generator and the element numbering) -- i.e. forward and backward use one consistent mask per site,
+    scaled by 1 / (1 - p), at the places modeling_gpt2.py:153,194,212,427 put nn.Dropout; a second step draws new masks."""
+    from oracle import gpt2_ref, train_ref
+    from rag4dyg_amd import training
+    m, args, batch, times, mask, seed = _tiny_step_inputs(dev)
+    g = load_golden("g8_training_step")
+    tag = "ts_tiny"
+    L, H, d, V, pad, B, _ = (int(x) for x in g[tag + "_cfg"])
+    eta, gamma, alpha, temp, lam = (float(x) for x in g[tag + "_hyper"])
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+    ps = (0.1, 0.15, 0.2)
+    trainer = training.EncoderTrainer(m, dropout=ps, seed=991)
+    anchor, pos, neg = (b.to(dev) for b in batch[:3])
+    idx = torch.cat(batch[3:6], dim=1)
+    embs = []
+    for step in (1, 2):
+        random.seed(seed)
+        aug1, aug2 = training.aug(anchor, eta, gamma, V - 1)
+        emb = trainer.forward([anchor, pos, neg, aug1, aug2])
+        embs.append(emb.clone())
+        leaf = emb.view(5, B, -1).detach().requires_grad_(True)
+        with torch.enable_grad():
+            cl = training.CLtime_loss(args, leaf[0], leaf[1], leaf[2], times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
+            au = alpha * training.info_nce(args, leaf[3], leaf[4], temp, B, mask)
+            (cl + au).backward()
+        grads = trainer.backward(leaf.grad.view(5 * B, -1))
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "lm_head.weight"}
+        sdg["lm_head.weight"] = sdg["transformer.wte.weight"]
+        drop = train_ref.PhiloxDropout(*ps, seed=991, step=step)
+        r = train_ref.training_step(sdg, H, anchor.cpu(), pos.cpu(), neg.cpu(), times, idx, eta, gamma, alpha, temp, lam, V - 1, seed,
+                                    with_grad=True, drop=drop)
+        assert rel_err(emb.view(5, B, -1).cpu().numpy(), r["emb"].detach().numpy()) < 1e-4
+        assert abs(float((cl + au).item()) / float(r["loss"].item()) - 1) < 1e-4
+        r["loss"].backward()
+        errs = {n: rel_err(grads[n].cpu().numpy(), sdg[n].grad.numpy()) for n in grads}
+        print(f"dropout step {step}: worst element-wise (max-norm) gradient error {max(errs.values()):.2e}")
+        assert max(errs.values()) < 1e-3, {n: e for n, e in errs.items() if e > 1e-3}
+    assert rel_err(embs[0].cpu().numpy(), embs[1].cpu().numpy()) > 1e-2          # new masks every step
+    assert rel_err(embs[0].view(5, B, -1).cpu().numpy(), g[tag + "_emb"]) > 1e-2   # and not the eval-mode forward
+    m.train()                                                                    # config probabilities when the module trains
+    assert training.EncoderTrainer(m)._dropout_struct().resid_p == pytest.approx(m.config.resid_pdrop)
+    m.eval()
+    assert training.EncoderTrainer(m)._dropout_struct() is None
+
+
 # ------------------------------------------------------------------------------------------------ single backward ops
 def _stream():
     return torch.cuda.current_stream().cuda_stream

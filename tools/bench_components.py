@@ -257,45 +257,51 @@ def training():
     B = 64
     m = build_model(shape, dev)
     m.config.eta, m.config.gamma = 0.8, 0.4
-    nb = 12
+    nb = 22
     seqs = synth.sequences(shape, 3 * B * nb, "query", seed=11)
     args = types.SimpleNamespace(device=dev, temperature=0.1, lambda_decay=1e-4, alpha=1.0, per_gpu_train_batch_size=B,
                                  max_grad_norm=1.0, gradient_accumulation_steps=1)
-    times = torch.rand(3 * B * nb) * 1e4
+    times = (torch.rand(3 * B * nb) * 1e4).to(dev)
     batches = []
     for i in range(nb):
-        trip = [right_pad_batches(seqs[(3 * i + j) * B:(3 * i + j + 1) * B], B, shape.pad_id, dev)[0] for j in range(3)]
+        trip = [right_pad_batches(seqs[(3 * i + j) * B:(3 * i + j + 1) * B], B, shape.pad_id, "cpu")[0] for j in range(3)]   # as the DataLoader hands them over
         idx = [torch.arange((3 * i + j) * B, (3 * i + j + 1) * B).view(B, 1) for j in range(3)]
         batches.append((*trip, *idx))
-    trainer = tr.EncoderTrainer(m)
-    opt = tr.AdamW(trainer.params, trainer.grads, lr=1e-5, eps=1e-8, weight_decay=0.0)
     mask = tr.mask_correlated_samples(B)
-    random.seed(0)
-    for b in batches[:2]:
-        tr.training_step(args, m, trainer, opt, b, times, mask)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    flop = 0.0
-    for b in batches[2:]:
-        tr.training_step(args, m, trainer, opt, b, times, mask)
-        flop += 3.0 * (f_enc(shape, B, b[0].shape[1]) * 3 + f_enc(shape, B, b[1].shape[1]) + f_enc(shape, B, b[2].shape[1]))
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
     n = nb - 2
+    flop = sum(3.0 * (f_enc(shape, B, b[0].shape[1]) * 3 + f_enc(shape, B, b[1].shape[1]) + f_enc(shape, B, b[2].shape[1]))
+               for b in batches[2:])
+    wall = {}
+    for mode in ("warm", "eval", "train"):               # "train": model.train(), dropout 0.1 at the four sites like the reference
+        m.train(mode == "train")
+        trainer = tr.EncoderTrainer(m, seed=42)
+        opt = tr.AdamW(trainer.params, trainer.grads, lr=1e-5, eps=1e-8, weight_decay=0.0, flat_grads=trainer.flat_grads)
+        random.seed(0)
+        for b in batches[:2]:
+            tr.training_step(args, m, trainer, opt, b, times, mask)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches[2:]:
+            tr.training_step(args, m, trainer, opt, b, times, mask, sync=False)      # as train_epoch runs it: losses summed on the device
+        torch.cuda.synchronize()
+        wall[mode] = time.perf_counter() - t0
+    el = wall["train"]
     # device-side split of one step (forward / backward / optimizer) with events
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     b = batches[2]
     a1, a2 = tr.aug(b[0], 0.8, 0.4, m.config.vocab_size - 1)
+    torch.cuda.synchronize()
     ev[0].record()
-    emb = trainer.forward([b[0], b[1], b[2], a1, a2])
+    emb = trainer.forward([x.to(dev) for x in (b[0], b[1], b[2], a1, a2)])
     ev[1].record()
     trainer.backward(torch.randn_like(emb))
     ev[2].record()
     opt.step(1.0)
     ev[3].record()
     torch.cuda.synchronize()
-    emit(component="retriever_training_step", shape="UCI_13", batch=B, steps=n, ms_per_step=round(1e3 * el / n, 3),
+    emit(component="retriever_training_step", shape="UCI_13", batch=B, steps=n, dropout=0.1, ms_per_step=round(1e3 * el / n, 3),
          sequences_per_s=round(5 * B * n / el, 1), tflops=round(flop / el / 1e12, 1),
+         ms_per_step_dropout_off=round(1e3 * wall["eval"] / n, 3),
          forward_ms=round(ev[0].elapsed_time(ev[1]), 3), backward_ms=round(ev[1].elapsed_time(ev[2]), 3),
          optimizer_ms=round(ev[2].elapsed_time(ev[3]), 3), padded_T=[int(x.shape[1]) for x in b[:3]])
 
