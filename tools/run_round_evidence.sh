@@ -19,4 +19,7 @@ echo "== profile scan" >> $LOG
 bash tools/profile_scan.sh $TAG >> $LOG 2>&1
 echo "== profile jaccard" >> $LOG
 bash tools/profile_jaccard.sh $TAG >> $LOG 2>&1
+echo "== profile training step" >> $LOG
+bash tools/profile_training.sh gpurun_out/train_prof >> $LOG 2>&1
+cp gpurun_out/train_prof/train_kernel_stats.csv gpurun_out/${TAG}_training_step_kernel_stats.csv
 echo "== done" >> $LOG
