@@ -85,9 +85,12 @@ int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, i
 bool gemm_skinny_supported(int M, int K, int N);
 size_t gemm_skinny_scratch_floats(int K, int N);
 bool gemm_skinny_fuses_ln(int M, int K, int N);       // y = epilogue(LayerNorm(x) . wT^T + bias) in one launch
+// `counters_zeroed`: the caller cleared the split-K ticket counters (gemm_skinny_counters) on this stream since the last
+// aborted launch (a completed launch leaves them at zero); otherwise the launcher clears them itself when K is split
+void* gemm_skinny_counters(float* scratch, size_t* bytes);
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
-                       const float* ln_b = nullptr, float ln_eps = 0.f);
+                       const float* ln_b = nullptr, float ln_eps = 0.f, bool counters_zeroed = false);
 
 // ------------------------------------------------------------------ train_ops.hip
 struct DropKey { unsigned seed_lo, seed_hi, step_lo, step_hi; };      // Philox key (seed) and counter words 2-3 (step)
@@ -121,7 +124,8 @@ int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStr
 // decode step (one new position per sequence): x = (ids ? wte[id] : emb) + wpe[pos], y = LayerNorm(x)
 int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32_t* pos, const float* wte,
                                const float* wpe, int vocab, int n_positions, int t_cap, int B, int d, const float* w,
-                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s);
+                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s,
+                               void* zero_words = nullptr, size_t zero_bytes = 0);   // also clears zero_bytes at zero_words
 // one query per (sequence, head) against the cached keys/values; writes the new K/V row into the cache first
 int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t* pos, int B, int t_cap, int H, int d,
                             float* out, hipStream_t s);

@@ -16,9 +16,10 @@ void set_error(const char* fmt, ...) {
 }
 
 static int conv1d(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K,
-                  int N, int epilogue, float* y, hipStream_t s, float* skinny_scratch = nullptr) {
+                  int N, int epilogue, float* y, hipStream_t s, float* skinny_scratch = nullptr, bool sk_counters_zeroed = false) {
     if (skinny_scratch && wT && gemm_skinny_supported(M, K, N))        // decode step: a weight stream, not a tiled GEMM
-        return launch_gemm_skinny(x, wT, bias, resid, M, K, N, epilogue, y, skinny_scratch, s);
+        return launch_gemm_skinny(x, wT, bias, resid, M, K, N, epilogue, y, skinny_scratch, s, nullptr, nullptr, 0.f,
+                                  sk_counters_zeroed);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = x; g.C = y; g.bias = bias; g.resid = resid;
@@ -334,6 +335,8 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
     }
     float* sk = (sk_floats && B <= 32) ? ws.pool : nullptr;         // M <= 32: the projections run as weight streams
     const size_t layer_stride = (size_t)B * t_cap * 2 * d;
+    size_t cbytes = 0;                                              // split-K ticket counters of the projections: cleared once per
+    void* cnt = sk ? gemm_skinny_counters(sk, &cbytes) : nullptr;   // step, by the step's first kernel
     for (int l = 0; l < cfg->n_layer; ++l) {
         const r4d_gpt2_layer& L = w->layers[l];
         R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
@@ -343,28 +346,28 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         const bool fuse_ln = sk && L.c_attn_wT && L.c_fc_wT && gemm_skinny_fuses_ln(B, d, 3 * d);
         if (l == 0)
             rc = launch_embed_pos_layernorm(ids_d, inputs_embeds_d, pos_d, w->wte, w->wpe, cfg->vocab, cfg->n_positions,
-                                            t_cap, B, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s);
+                                            t_cap, B, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s, cnt, cbytes);
         else if (!fuse_ln)
             rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
         if (rc) return rc;
         if (fuse_ln && l > 0)
             rc = launch_gemm_skinny(ws.x, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, L.ln_1_w,
-                                    L.ln_1_b, cfg->ln_eps);
+                                    L.ln_1_b, cfg->ln_eps, true);
         else
             rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s, sk);
         if (rc) return rc;
         if ((rc = launch_decode_attention(ws.qkv, kv_cache_d + (size_t)l * layer_stride, pos_d, B, t_cap, H, d, ws.att, s)))
             return rc;
-        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s, sk, true))) return rc;
         if (fuse_ln) {
             rc = launch_gemm_skinny(ws.x, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, sk, s, L.ln_2_w, L.ln_2_b,
-                                    cfg->ln_eps);
+                                    cfg->ln_eps, true);
         } else {
             if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
             rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s, sk);
         }
         if (rc) return rc;
-        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s, sk))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s, sk, true))) return rc;
     }
     return launch_layernorm(ws.x, w->ln_f_w, w->ln_f_b, B, d, cfg->ln_eps, out_hidden_d, s);
 }

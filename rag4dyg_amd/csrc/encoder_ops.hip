@@ -184,7 +184,11 @@ __global__ __launch_bounds__(256) void embed_pos_ln_kernel(const int64_t* __rest
                                                            const float* __restrict__ wpe, int vocab, int n_positions,
                                                            int t_cap, int B, int d, const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps,
-                                                           float* __restrict__ x_out, float* __restrict__ y_out) {
+                                                           float* __restrict__ x_out, float* __restrict__ y_out,
+                                                           unsigned* __restrict__ zero_words, int n_zero) {
+    // first kernel of a decode step: also clears the split-K ticket counters of the step's projections (no memset node)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
@@ -216,12 +220,13 @@ __global__ __launch_bounds__(256) void embed_pos_ln_kernel(const int64_t* __rest
 
 int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32_t* pos, const float* wte,
                                const float* wpe, int vocab, int n_positions, int t_cap, int B, int d, const float* w,
-                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s) {
+                               const float* b, float eps, float* x_out, float* y_out, hipStream_t s, void* zero_words,
+                               size_t zero_bytes) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     if (B <= 0) return R4D_OK;
     ProfScope prof(PK_EMBED_LN, 12.0 * B * d + 12.0 * B, s);
     hipLaunchKernelGGL(embed_pos_ln_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, ids, emb, pos, wte, wpe, vocab,
-                       n_positions, t_cap, B, d, w, b, eps, x_out, y_out);
+                       n_positions, t_cap, B, d, w, b, eps, x_out, y_out, (unsigned*)zero_words, (int)(zero_bytes / 4));
     R4D_CHECK_LAUNCH("embed_pos_layernorm");
     return R4D_OK;
 }

@@ -18,6 +18,7 @@
 // epilogue and -- for the two projections that read a LayerNorm -- the LayerNorm itself (row statistics recomputed
 // per workgroup from the L2-resident x, applied to the fragments) run in the same launch.  K = 4d (mlp c_proj) still
 // splits over gridDim.y and keeps the epilogue kernel.
+#include <stdlib.h>
 #include "common.h"
 
 namespace r4d {
@@ -254,22 +255,224 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny8_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- 16-column kernel
+// Same plan as gemm_skinny8_kernel with HALF the columns per workgroup (16 rows of wT, v_mfma_f32_16x16x4_f32 on two 16-row
+// halves of x): a projection is spread over twice as many CUs (N = 768: 48 instead of 24; N = 2304: 144; N = 3072: 192), so
+// both per-CU costs of the chain halve -- the exact-f32 MFMA work of a tile (8 waves x 48 MFMAs x 64 clocks = 2.6 us per CU
+// with 32 columns) and the tile's weight bytes through the CU's one L1.  Two more seams are gone:
+//  * the LayerNorm of c_attn / c_fc no longer sits in front of the MFMAs.  LN(x) . W = rstd * (sum_k x_k g_k W_kn - mean * c1_n)
+//    + c2_n with c1_n = sum_k g_k W_kn and c2_n = sum_k b_k W_kn: the MFMAs start on x_k * g_k as soon as the operands have
+//    landed, while mean / variance (two-pass, from the same fragments) and c1 / c2 (two FMAs per weight element a lane holds
+//    anyway) are formed beside them and meet the tiles in the LDS reduction.
+//  * K = 4d (mlp c_proj) splits over gridDim.y as before, but the slices are combined by the LAST workgroup of a column
+//    tile to arrive (write-through partials + one relaxed ticket, Guideline 16; slices added in slice order whoever arrives
+//    last: deterministic) -- no epilogue launch.
+constexpr int S16_LDR = 17;                            // partial-tile row stride in LDS (floats)
+constexpr int S16_MAX_TILES = 256;                     // ticket counters at the head of the scratch (KS > 1): N <= 4096
+
+__device__ __forceinline__ void publish_sk(float* p, float v) {      // write-through (sc1) store, see topk.hip
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float consume_sk(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+// grid (ceil(N/16), KS), 512 threads.  KS == 1: y = epilogue(x' . wT^T + bias), x' = LN ? LayerNorm(x) : x.
+// KS > 1 (never with LN): partial[ks][32][N] + counters[tile]; the last arriver writes y.
+template <int NG, bool LN>
+__global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* __restrict__ x, const float* __restrict__ wT,
+                                                                   int M, int N, int K, const float* __restrict__ bias,
+                                                                   const float* __restrict__ resid, int epilogue,
+                                                                   float* __restrict__ y, float* partial, unsigned* counters,
+                                                                   const float* __restrict__ ln_w,
+                                                                   const float* __restrict__ ln_b, float eps) {
+    constexpr int KW = 32 * NG, SL = S8_NW * KW, NJ = KW / 16;
+    constexpr int LDX = KW + 4, PPR = KW / 4, RPP = 64 / PPR, NPASS = 32 / RPP;
+    __shared__ __attribute__((aligned(16))) float xs_all[S8_NW * 32 * LDX];
+    __shared__ float red_t[S8_NW * 32 * S16_LDR];
+    __shared__ float red_s[LN ? 2 * S8_NW * 32 : 1];   // [0]: piece sums, [1]: centred squares, per (wave, row)
+    __shared__ float red_c[LN ? 2 * S8_NW * 16 : 1];   // c1 / c2 pieces per (wave, column)
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n16 = lane & 15, q = lane >> 4;
+    const int KS = gridDim.y;
+    const int k0 = blockIdx.y * SL + wid * KW;
+    const int col = blockIdx.x * 16 + n16;
+    const float* __restrict__ wrow = wT + (long long)min(col, N - 1) * K + k0 + 4 * q;
+    float* xs = xs_all + wid * 32 * LDX;
+    const int pr = lane / PPR, pc = lane % PPR;
+    // every global load of the kernel up front: weights (HBM latency), x pieces (L2), LayerNorm gain / shift, bias, residual
+    float4 b[NJ], gw[LN ? NJ : 1], gb[LN ? NJ : 1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4*>(wrow + 16 * j);
+    float4 xv[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {                  // rows >= M repeat row M-1: computed, never stored
+        const int r = min(min(j * RPP + pr, 31), M - 1);
+        xv[j] = reinterpret_cast<const float4*>(x + (long long)r * K + k0)[pc];
+    }
+    if (LN) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gw[j] = *reinterpret_cast<const float4*>(ln_w + k0 + 16 * j + 4 * q);
+            gb[j] = *reinterpret_cast<const float4*>(ln_b + k0 + 16 * j + 4 * q);
+        }
+    }
+    const int em = tid >> 4, en = blockIdx.x * 16 + (tid & 15);      // epilogue: one output per thread, 16 columns per row
+    const int enc = min(en, N - 1), emc = min(em, M - 1);
+    const bool fused = KS == 1;
+    const float bias_n = bias ? bias[enc] : 0.f;
+    const float res = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)emc * N + enc] : 0.f;
+    if (pr < RPP)
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) *reinterpret_cast<float4*>(xs + (j * RPP + pr) * LDX + 4 * pc) = xv[j];
+    __syncthreads();
+    float4 a[2][NJ];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[t][j] = *reinterpret_cast<const float4*>(xs + (16 * t + n16) * LDX + 16 * j + 4 * q);
+    f32x4g acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = f32x4g{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 g = LN ? gw[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].x * g.x : a[t][j].x, b[j].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].y * g.y : a[t][j].y, b[j].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].z * g.z : a[t][j].z, b[j].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].w * g.w : a[t][j].w, b[j].w, acc[t], 0, 0, 0);
+        }
+    if (LN) {
+        // row statistics from the fragments (lane (n16, q) holds row 16t + n16, k = 16j + 4q + c of this wave's piece) and the
+        // column constants c1 / c2 from the weights it holds: piece sums meet in LDS (two-pass variance like ln4_kernel)
+        float s_[2], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s_[t] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s_[t] += (a[t][j].x + a[t][j].y) + (a[t][j].z + a[t][j].w);
+            s_[t] += __shfl_xor(s_[t], 16);
+            s_[t] += __shfl_xor(s_[t], 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            c1 += (gw[j].x * b[j].x + gw[j].y * b[j].y) + (gw[j].z * b[j].z + gw[j].w * b[j].w);
+            c2 += (gb[j].x * b[j].x + gb[j].y * b[j].y) + (gb[j].z * b[j].z + gb[j].w * b[j].w);
+        }
+        c1 += __shfl_xor(c1, 16); c1 += __shfl_xor(c1, 32);
+        c2 += __shfl_xor(c2, 16); c2 += __shfl_xor(c2, 32);
+        if (q == 0) {
+            red_s[wid * 32 + n16] = s_[0]; red_s[wid * 32 + 16 + n16] = s_[1];
+            red_c[wid * 16 + n16] = c1; red_c[S8_NW * 16 + wid * 16 + n16] = c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < S8_NW; ++w) mean += red_s[w * 32 + 16 * t + n16];
+            mean /= (float)K;
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float dx = a[t][j].x - mean, dy = a[t][j].y - mean, dz = a[t][j].z - mean, dw = a[t][j].w - mean;
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            qq += __shfl_xor(qq, 16);
+            qq += __shfl_xor(qq, 32);
+            if (q == 0) red_s[S8_NW * 32 + wid * 32 + 16 * t + n16] = qq;
+        }
+    }
+    float* mine = red_t + wid * 32 * S16_LDR;          // C layout of 16x16x4: lane (n16, q) holds rows 4q + r, column n16
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(16 * t + 4 * q + r) * S16_LDR + n16] = acc[t][r];
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < S8_NW; ++w) v += red_t[(w * 32 + em) * S16_LDR + (tid & 15)];      // wave order: deterministic
+    if (LN) {
+        float mean = 0.f, var = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < S8_NW; ++w) {
+            mean += red_s[w * 32 + em]; var += red_s[S8_NW * 32 + w * 32 + em];
+            c1 += red_c[w * 16 + (tid & 15)]; c2 += red_c[S8_NW * 16 + w * 16 + (tid & 15)];
+        }
+        mean /= (float)K;
+        v = rsqrtf(var / (float)K + eps) * (v - mean * c1) + c2;
+    }
+    if (fused) {
+        if (en < N && em < M) {
+            v += bias_n;
+            if (epilogue == EPI_GELU) v = gelu_new_sk(v);
+            else if (epilogue == EPI_RESIDUAL) v += res;
+            y[(long long)em * N + en] = v;
+        }
+        return;
+    }
+    // split-K: publish this slice's tile, take a ticket; the last workgroup of the column tile adds the slices in order
+    if (en < N) publish_sk(partial + ((long long)blockIdx.y * 32 + em) * N + en, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)KS - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(&counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (en < N && em < M) {
+        float o = 0.f;
+        for (int ks = 0; ks < KS; ++ks) o += consume_sk(partial + ((long long)ks * 32 + em) * N + en);
+        o += bias_n;
+        if (epilogue == EPI_GELU) o = gelu_new_sk(o);
+        else if (epilogue == EPI_RESIDUAL) o += resid[(long long)em * N + en];
+        y[(long long)em * N + en] = o;
+    }
+}
+
 static int skinny8_ng(int K) { return K % 768 == 0 ? 3 : (K % 512 == 0 ? 2 : 0); }       // 0: the 4-wave kernel
 
 bool gemm_skinny_fuses_ln(int M, int K, int N) { return gemm_skinny_supported(M, K, N) && (K == 768 || K == 512); }
 
-size_t gemm_skinny_scratch_floats(int K, int N) { return (size_t)cdiv(K, SK_KC) * 32 * N; }
+size_t gemm_skinny_scratch_floats(int K, int N) { return (size_t)cdiv(K, SK_KC) * 32 * N + S16_MAX_TILES; }   // + ticket counters
 
 bool gemm_skinny_supported(int M, int K, int N) { return M >= 1 && M <= 32 && K % SK_KC == 0 && K >= SK_KC && N >= 1; }
 
+void* gemm_skinny_counters(float* scratch, size_t* bytes) { *bytes = S16_MAX_TILES * sizeof(unsigned); return scratch; }
+
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w, const float* ln_b,
-                       float ln_eps) {
+                       float ln_eps, bool counters_zeroed) {
     R4D_REQUIRE(gemm_skinny_supported(M, K, N) && scratch, "skinny gemm: unsupported shape M=%d K=%d N=%d", M, K, N);
     R4D_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wT % 16) == 0, "skinny gemm: operands must be 16-byte aligned");
     R4D_REQUIRE(!ln_w || (ln_b && gemm_skinny_fuses_ln(M, K, N)), "skinny gemm: no fused LayerNorm for K=%d", K);
     const int ng = skinny8_ng(K);
     int KS;
+    static int use16 = -1;
+    if (use16 < 0) { const char* e = getenv("R4D_SKINNY16"); use16 = e ? atoi(e) : 1; }      // tuning aid: 0 -> the 32-column kernels
+    if (ng && use16 && (K / (S8_NW * 32 * ng) == 1 || cdiv(N, 16) <= S16_MAX_TILES)) {      // 8 waves per 16-row tile of wT
+        const int SL = S8_NW * 32 * ng;
+        KS = K / SL;
+        R4D_REQUIRE(KS == 1 || !ln_w, "skinny gemm: no fused LayerNorm across k slices");
+        unsigned* counters = reinterpret_cast<unsigned*>(scratch);
+        float* partial = KS > 1 ? scratch + S16_MAX_TILES : nullptr;
+        if (KS > 1 && !counters_zeroed) R4D_HIP(hipMemsetAsync(counters, 0, S16_MAX_TILES * sizeof(unsigned), s));
+        ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + (KS > 1 ? 8.0 * KS * 32.0 * N : 4.0 * M * N), s);
+        const dim3 grid(cdiv(N, 16), KS), block(64 * S8_NW);
+#define SK16_(NG_, LN_)                                                                                                    \
+    hipLaunchKernelGGL((gemm_skinny16_kernel<NG_, LN_>), grid, block, 0, s, x, wT, M, N, K, bias, resid, epilogue, y, partial, \
+                       counters, ln_w, ln_b, ln_eps)
+        if (ng == 3) { if (ln_w) SK16_(3, true); else SK16_(3, false); }
+        else         { if (ln_w) SK16_(2, true); else SK16_(2, false); }
+#undef SK16_
+        R4D_CHECK_LAUNCH("gemm_skinny16");
+        return R4D_OK;
+    }
     if (ng) {                                          // 8 waves per 32-row tile of wT
         const int SL = S8_NW * 32 * ng;
         KS = K / SL;
