@@ -334,8 +334,8 @@ int r4d_dropout_f32(const float* x_d, const float* resid_d, int64_t n, float* ou
  * probabilities) and the backward temporaries.  The SAME buffer goes to the forward and to the backward call. */
 size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_groups, const int32_t* Bs, const int32_t* Ts);
 /* Forward over up to 16 right-padded id batches (one launch sequence over their concatenated rows) that keeps every
- * activation the backward pass reads.  Weights in the reference layout only (the optional wT copies are ignored: the
- * weights change every step).  out_meanpool_d f32 [sum(Bs), d] = torch.mean(h, dim=1) per sequence. */
+ * activation the backward pass reads.  The optional wT copies of the layers are USED when present (faster forward GEMMs): the
+ * caller must refresh them after every optimizer step; the backward pass reads the reference layout only.  out_meanpool_d f32 [sum(Bs), d] = torch.mean(h, dim=1) per sequence. */
 int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts, float* out_meanpool_d,
                                const r4d_train_dropout* dropout, void* workspace_d, size_t workspace_bytes, void* stream);

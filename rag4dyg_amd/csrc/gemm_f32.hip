@@ -415,6 +415,7 @@ int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, i
     sh.sA0 = (long long)kper * lda; sh.sB0 = (long long)kper * ldb; sh.sC0 = (long long)M * N; sh.scale_div = 1.f;
     {
         ProfScope prof(PK_GEMM_128x128_NN, 2.0 * M * N * Kt, stream);
+        // (tried: 2 x 2 waves with 64 x 64 wave tiles -- twice the MFMAs per LDS read, half the waves: no change, 48.4 vs 48.1 ms backward)
         hipLaunchKernelGGL((gemm_f32_kernel<128, 128, BKT, 4, 2, false, true>), dim3(cdiv(M, 128) * cdiv(N, 128), 1, Sx), dim3(512), 0,
                            stream, A, B, Sx > 1 ? scratch : C, nullptr, nullptr, sh);
         R4D_CHECK_LAUNCH("gemm_f32_tn");

@@ -112,15 +112,17 @@ static int check_groups(const r4d_gpt2_config* cfg, int n_groups, const int64_t*
     return R4D_OK;
 }
 
-// y[M,N] = epilogue(x[M,K] . W[K,N] + bias)   (Conv1D.forward, modeling_utils.py:1267-1271; reference layout, no wT copy:
-// the weights change every step)
-static int fwd_linear(const float* x, const float* w, const float* bias, const float* resid, int M, int K, int N, int epi, float* y,
-                      hipStream_t s) {
+// y[M,N] = epilogue(x[M,K] . W[K,N] + bias)   (Conv1D.forward, modeling_utils.py:1267-1271).  `wT` (nullable): the caller's
+// CURRENT [N,K] copy of the weight (refreshed after every optimizer step) -> the k-contiguous kernel; else the reference layout
+static int fwd_linear(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K, int N,
+                      int epi, float* y, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = x; g.B = w; g.C = y; g.bias = bias; g.resid = resid;
-    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = N; g.ldc = N; g.ldr = N;
-    g.b_trans = 0; g.b_rows = K; g.nbatch = 1; g.nb1 = 1; g.epilogue = epi; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
+    g.A = x; g.C = y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
+    if (wT) { g.B = wT; g.ldb = K; g.b_trans = 1; g.b_rows = N; }
+    else { g.B = w; g.ldb = N; g.b_trans = 0; g.b_rows = K; }
+    g.nbatch = 1; g.nb1 = 1; g.epilogue = epi; g.scale_div = 1.f; g.causal = CAUSAL_NONE;
     return launch_gemm_f32(g, s);
 }
 // dx[M,K] = dy[M,N] . W[K,N]^T : W's rows are k(N)-contiguous, i.e. W IS the [N' = K, K' = N] operand of the fast kernel
@@ -315,23 +317,23 @@ int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
             if ((rc = launch_dropout(x_in, nullptr, (long long)M * d, x_in, dc.embd_p, dc.key, R4D_DROPOUT_SITE_EMBD, 0, s))) return rc;
             if ((rc = launch_layernorm(x_in, Lw.ln_1_w, Lw.ln_1_b, M, d, cfg->ln_eps, ln1, s))) return rc;
         }
-        if ((rc = fwd_linear(ln1, Lw.c_attn_w, Lw.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
+        if ((rc = fwd_linear(ln1, Lw.c_attn_w, Lw.c_attn_wT, Lw.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s))) return rc;
         for (const TrainGroup& G : gs)
             if ((rc = attn_fwd(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws + t.P[l] + G.p0, att + G.row0 * d, s, dc.attn_p, dc.key,
                                4u * l + 0u, G.p0, ws + t.dP))) return rc;
         float* branch = ws + t.dy;                                   // a backward temporary, free during the forward
         if (dc.resid_p > 0.f) {                                      // x + resid_dropout(c_proj(a)), :194,229
-            if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_b, nullptr, M, d, d, EPI_NONE, branch, s))) return rc;
+            if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, nullptr, M, d, d, EPI_NONE, branch, s))) return rc;
             if ((rc = launch_dropout(branch, x_in, (long long)M * d, x_mid, dc.resid_p, dc.key, 4u * l + 1u, 0, s))) return rc;
-        } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s))) return rc;
+        } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s))) return rc;
         if ((rc = launch_layernorm(x_mid, Lw.ln_2_w, Lw.ln_2_b, M, d, cfg->ln_eps, ln2, s))) return rc;
-        if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s))) return rc;
+        if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s))) return rc;
         if ((rc = launch_gelu_fwd(pre, (long long)M * 4 * d, f, s))) return rc;
         float* x_next = l + 1 < cfg->n_layer ? ws + t.x_in[l + 1] : ws + t.x_out;
         if (dc.resid_p > 0.f) {                                      // x + dropout(c_proj(act(c_fc(x)))), :212,233
-            if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s))) return rc;
+            if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s))) return rc;
             if ((rc = launch_dropout(branch, x_mid, (long long)M * d, x_next, dc.resid_p, dc.key, 4u * l + 2u, 0, s))) return rc;
-        } else if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s))) return rc;
+        } else if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s))) return rc;
     }
     return launch_lnf_meanpool_groups(R, ws + t.x_out, w->ln_f_w, w->ln_f_b, d, cfg->ln_eps, nullptr, out_meanpool_d,
                                       ws + t.pool_scratch, s);

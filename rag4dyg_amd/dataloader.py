@@ -74,7 +74,8 @@ def get_dataloader(dataset, tokenizer, args, split='eval'):
             sampler = RandomSampler(dataset)
         else:                                                       # one process per GPU: each rank its share of the triples
             from torch.utils.data.distributed import DistributedSampler
-            sampler = DistributedSampler(dataset)
+            sampler = DistributedSampler(dataset, num_replicas=int(args.data_parallel_world),
+                                         rank=int(getattr(args, "data_parallel_rank", 0)))
         loader = DataLoader(dataset, sampler=sampler, batch_size=args.train_batch_size, collate_fn=collate, drop_last=False)
         return loader, args
     args.eval_batch_size = args.per_gpu_eval_batch_size * max(1, args.n_gpu)

@@ -188,6 +188,22 @@ class EncoderTrainer:
         self.flat_accum = None
         self._ws = None
         self._saved = None
+        # [out,in] copies of the four Conv1D weights of every block for the forward GEMMs (both operands k-contiguous: the
+        # fast kernel); refreshed by ``refresh_transposed()`` after every parameter update
+        self.use_wt = os.environ.get("R4D_TRAIN_WT", "1") != "0"
+        self._wt = {}
+        if self.use_wt:
+            for i in range(len(tr.h)):
+                for f in ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w"):
+                    w = self.params[f"transformer.h.{i}.{dict(_LAYER_PARAMS)[f]}"]
+                    self._wt[(i, f)] = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev)
+            self.refresh_transposed()
+
+    @torch.no_grad()
+    def refresh_transposed(self):
+        """Bring the [out,in] weight copies up to date (call after every optimizer step / load_state_dict)."""
+        for (i, f), wt in self._wt.items():
+            wt.copy_(self.params[f"transformer.h.{i}.{dict(_LAYER_PARAMS)[f]}"].t())
 
     def _structs(self):
         tr = self.model.transformer
@@ -198,7 +214,8 @@ class EncoderTrainer:
         glayers = (_lib.GPT2LayerGradsC * cfg.n_layer)()
         for i in range(cfg.n_layer):
             vals = [self.params[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS]
-            layers[i] = _lib.GPT2LayerC(*vals, None, None, None, None)                       # no wT copies: weights change
+            wts = [self._wt[(i, f)].data_ptr() if self.use_wt else None for f in ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w")]
+            layers[i] = _lib.GPT2LayerC(*vals, *wts)                                         # wT copies kept current by refresh_transposed
             glayers[i] = _lib.GPT2LayerGradsC(*[self.grads[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS])
         w = _lib.GPT2WeightsC(tr.wte.weight.data_ptr(), tr.wpe.weight.data_ptr(), tr.ln_f.weight.data_ptr(),
                               tr.ln_f.bias.data_ptr(), layers, None)
@@ -364,6 +381,7 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
             trainer.take_accumulated()
         trainer.all_reduce_mean()
         optimizer.step(getattr(args, "max_grad_norm", 0.0))
+        trainer.refresh_transposed()
         model.transformer.__dict__.pop("_wt_cache", None)        # transposed weight copies of the inference path are stale now
     if not sync:
         return dict(loss=loss.detach(), cl_loss=cl.detach(), aug_loss=au.detach(), stepped=stepped)
@@ -439,6 +457,7 @@ def distributed_setup(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=os.environ.get("R4D_DIST_BACKEND", "nccl"))
     args.data_parallel_world = dist.get_world_size()           # get_dataloader: DistributedSampler (dataloader/retriever.py:160)
+    args.data_parallel_rank = dist.get_rank()
     return dist.get_world_size(), dist.get_rank()
 
 

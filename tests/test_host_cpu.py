@@ -307,6 +307,14 @@ def test_dataset_classes_and_eval_batching(tmp_path):
     assert a0[3].shape == (4, 1) and sorted(int(x) for b in got for x in b[3].flatten()) == [0, 3, 6, 9, 12]
     row = int(a0[3][0, 0])
     assert a0[0][0, :len(pairs.anchor[row // 3])].tolist() == pairs.anchor[row // 3] == hist[row].tolist()
+    # data-parallel ranks (dataloader/retriever.py:160 DistributedSampler): every rank its share, together the whole set
+    seen = []
+    for rk in range(2):
+        args.data_parallel_world, args.data_parallel_rank = 2, rk
+        part, _ = get_dataloader(pairs, tok, args, split="train")
+        seen.append(sorted(int(x) for bt in part for x in bt[3].flatten()))
+        assert len(seen[-1]) == 3                                      # ceil(5 / 2): the sampler pads the short rank
+    assert sorted(set(seen[0] + seen[1])) == [0, 3, 6, 9, 12]
 
 
 def test_annotation_parsing_matches_oracle():
