@@ -203,6 +203,15 @@ def generator(shape_name="UCI_13", L=6, H=8, d=768, topk=7, pool_n=512):
         ntok += sum(len(o) - len(q) for o, q in zip(outs, qs))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # the same queries at --per_gpu_eval_batch_size 128 (the throughput lever of a latency-bound step: same ids per query)
+    big = [(queries[b0:b0 + 128], idxs[b0:b0 + 128]) for b0 in range(0, len(queries), 128)]
+    list(gen.decode_rag_batches(args, model, tok, ds, big[:1], "val", 1024, 12)); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ntok128 = 0
+    for (qs, _ix), outs in zip(big, gen.decode_rag_batches(args, model, tok, ds, big, "val", 1024, 12)):
+        ntok128 += sum(len(o) - len(q) for o, q in zip(outs, qs))
+    torch.cuda.synchronize()
+    el128 = time.perf_counter() - t0
     t0 = time.perf_counter()
     ncpu = 0
     for q, ix in list(zip(queries, idxs))[:3]:
@@ -213,7 +222,7 @@ def generator(shape_name="UCI_13", L=6, H=8, d=768, topk=7, pool_n=512):
     emit(component="generator_decode", shape=shape_name, model=f"L{L} H{H} d{d} V{V}", pool=pool_n, fusion="graphpooling", topK=topk,
          queries=len(queries), mean_query_len=round(float(np.mean([len(q) for q in queries])), 1), tokens=ntok,
          tokens_per_s=round(ntok / el, 1), queries_per_s=round(len(queries) / el, 2), batch=32,
-         tokens_per_s_batch1=round(ntok1 / el1, 1),
+         tokens_per_s_batch1=round(ntok1 / el1, 1), tokens_per_s_batch128=round(ntok128 / el128, 1),
          cpu_baseline={"kind": "port", "cores": host_cores(), "tokens_per_s": round(ncpu / elc, 2),
                        "sample": "3 queries, oracle torch-CPU fp32 (fusion + full forward per token, as the reference)"})
 

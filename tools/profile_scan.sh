@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_scan_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export R4D_SCAN_CASES=${R4D_SCAN_CASES:-12500x512,100000x512}
+export R4D_SCAN_CASES=${R4D_SCAN_CASES:-12500x512,100000x512,100000x768}
 # one pool size per process, so that the per-kernel averages and the per-launch counter means are not a mix of sizes
 for size in ${R4D_SCAN_CASES//,/ }; do
   echo "trace $size" >> $OUT/progress.log
@@ -35,5 +35,23 @@ for d in sorted(glob.glob("$OUT/pmc_*_*")):
     for k, (v, n) in sorted(agg.items()):
         if "scan" in k or "topk" in k:
             print(size, grp, k, "launches", n, "mean", round(v / n, 1))
+PY
+# profiles/pmc_scan.json: what bench.py's extras.scan_q32 reports as `traffic` (stamped with the sources it was measured on)
+python3 - > $OUT/pmc_scan.json <<PY
+import json, re, sys
+sys.path.insert(0, "$R")
+from bench import source_sha
+out = {"_workload": {"source_sha": source_sha(), "queries": 32,
+                     "command": "tools/profile_scan.sh: R4D_SCAN_CASES=<size> rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/bench_components.py scan (one counter and one size per pass)"}}
+vals = {}
+for line in open("$OUT/pmc.txt"):
+    m = re.match(r"(\d+x\d+) (FETCH_SIZE|WRITE_SIZE) (\S+) launches \d+ mean ([0-9.]+)", line)
+    if m and "pool_scan" in m.group(3):
+        vals.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+for size, v in vals.items():
+    if len(v) == 2:
+        out[size] = {"fetch_kib_raw": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
+                     "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
+print(json.dumps(out, indent=1))
 PY
 cat $OUT/pmc.txt; for f in $OUT/kernel_stats_*.csv; do echo "== $f"; grep -i "scan\|topk\|Name" $f; done
