@@ -45,7 +45,7 @@ out = {"_workload": {"source_sha": source_sha(), "queries": 32,
                      "command": "tools/profile_scan.sh: R4D_SCAN_CASES=<size> rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/bench_components.py scan (one counter and one size per pass)"}}
 vals = {}
 for line in open("$OUT/pmc.txt"):
-    m = re.match(r"(\d+x\d+) (FETCH_SIZE|WRITE_SIZE) (\S+) launches \d+ mean ([0-9.]+)", line)
+    m = re.match(r"(\d+x\d+) (FETCH_SIZE|WRITE_SIZE) (.+?) launches \d+ mean ([0-9.]+)", line)
     if m and "pool_scan" in m.group(3):
         vals.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
 for size, v in vals.items():
