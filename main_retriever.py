@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Drop-in for the reference ``main_retriever.py`` on the MI355X: same flags (``utils/args_parser_retriever.py``),
-same checkpoint / tokenizer / result-file layout, evaluation (``--do_eval``) running on the gfx950 library.
+same checkpoint / tokenizer / result-file layout, training (``--do_train``: ``rag4dyg_amd.training.train``) and evaluation
+(``--do_eval``) running on the gfx950 library.
 
 Differences from the reference ``main()`` (``main_retriever.py:45-164``):
-  * ``--do_train`` raises: retriever TRAINING (backward pass, ``train/train_retriever.py:132-354``) is outside
-    the encode-and-retrieve path this build accelerates;
+  * ``--do_train``: dropout masks come from the library's counter-based generator (keyed by ``--seed``), ``--fp16`` (apex)
+    raises, resuming from ``--model_name_or_path checkpoint-<n>`` is not built (upstream restores the optimizer state and
+    the step counters there, not the weights); started once per GPU the triples are sharded over the ranks and the
+    gradients averaged (RCCL);
   * wandb is not imported (logging only); ``--model_name_or_path gpt2`` does not touch the network;
   * the eval batch stays ``per_gpu_eval_batch_size`` (32): ``n_gpu`` is pinned to 1 for BATCHING because a mean-
     pooled embedding depends on its padded batch (``train_retriever.py:420``) -- with 8 visible GPUs the reference
