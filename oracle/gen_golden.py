@@ -598,9 +598,35 @@ def g8_training_step():
     _save("g8_training_step", **out)
 
 
+def g9_query_times():
+    """get_train_query_time.py (the training loop's ``resources/<ds>_train_query_time.pt``): the reference's own ``load_data`` /
+    ``get_query_time`` run on the shipped event tables of all three datasets; committed: the event columns the functions
+    read (u, i, ts, timestamp), the ego id of every training line and the resulting times (float32 after the scale)."""
+    import importlib.util
+    import pandas as pd
+    spec = importlib.util.spec_from_file_location("ref_get_train_query_time", os.path.join(REF, "get_train_query_time.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                                   # the __main__ block is guarded
+    scales = {"UCI_13": 3600 * 24, "hepth": 3600 * 24 * 30, "dialog": 1}
+    out = {}
+    for ds, ts in (("UCI_13", "12"), ("hepth", "11"), ("dialog", "15")):
+        ml = mod.load_data(ds, ts)
+        with open(os.path.join("resources", ds, ts, "train.link_prediction")) as f:
+            lines = [ln for ln in f.read().splitlines() if len(ln) > 0 and not ln.isspace()]
+        egos = [int(ln.split('<|history|>')[1].split(' ')[1]) for ln in lines]
+        times = [mod.get_query_time(ml, q, ts) / scales[ds] for q in egos]
+        raw = pd.read_csv(os.path.join("resources", ds, ts, f"ml_{ds}.csv"))
+        out[f"{ds}_u"] = raw["u"].to_numpy(np.int64); out[f"{ds}_i"] = raw["i"].to_numpy(np.int64)
+        out[f"{ds}_ts"] = raw["ts"].to_numpy(np.float64); out[f"{ds}_snapshot"] = raw["timestamp"].to_numpy(np.int64)
+        out[f"{ds}_egos"] = np.array(egos, np.int64)
+        out[f"{ds}_times"] = torch.tensor(times, dtype=torch.float).numpy()
+        out[f"{ds}_cfg"] = np.array([int(ts), scales[ds]], np.int64)
+    _save("g9_query_times", **out)
+
+
 def main():
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
-              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step}
+              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g9": g9_query_times}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

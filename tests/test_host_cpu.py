@@ -632,3 +632,33 @@ def test_pair_sequence_dataset_matches_reference_class(tmp_path):
     assert [list(x) for x in ds.negative] == unrag(g["pair_neg_flat"], g["pair_neg_off"])
     it = ds[2]
     assert it[0].tolist() == g["pair_item2_anchor"].tolist() and [int(it[3]), int(it[4]), int(it[5])] == g["pair_item2_idx"].tolist()
+
+
+def test_train_query_times_match_reference_on_all_shipped_datasets(tmp_path, monkeypatch):
+    """get_train_query_time.py mirror (rag4dyg_amd/query_time.py) against the reference's own load_data / get_query_time run
+    on the shipped event tables (G9): every training line's query time, bit for bit, UCI_13 / hepth / dialog; and the CLI
+    writes the float32 tensor the training loop loads."""
+    import pandas as pd
+    import torch
+    from rag4dyg_amd import query_time
+    g = load_golden("g9_query_times")
+    for ds in ("UCI_13", "hepth", "dialog"):
+        t, scale = (int(x) for x in g[ds + "_cfg"])
+        assert scale == query_time.SCALES[ds]
+        got = query_time.query_times(g[ds + "_u"], g[ds + "_i"], g[ds + "_ts"], g[ds + "_snapshot"], g[ds + "_egos"], t, scale)
+        assert got.dtype == np.float32 and np.array_equal(got, g[ds + "_times"]), ds
+    # CLI on a small table in the reference's file layout
+    d = tmp_path / "resources" / "toy" / "5"
+    d.mkdir(parents=True)
+    pd.DataFrame({"u": [0, 0, 1, 2, 0], "i": [1, 2, 2, 0, 1], "ts": [10., 20., 30., 40., 50.], "label": 0,
+                  "timestamp": [0, 1, 1, 3, 4], "idx": range(5)}).to_csv(d / "ml_toy.csv")
+    (d / "train.link_prediction").write_text("<|endoftext|> <|history|> 0 <|time0|> 1 <|endofhistory|> <|pre|> <|time1|> 2 <|endofpre|> <|endoftext|>\n"
+                                             "<|endoftext|> <|history|> 1 <|time0|> 0 <|endofhistory|> <|pre|> <|time1|> 2 <|endofpre|> <|endoftext|>\n")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setitem(query_time.SCALES, "toy", 10)
+    query_time.main(["get_train_query_time.py", "toy", "5"])
+    got = torch.load(tmp_path / "resources" / "toy_train_query_time.pt")
+    # node 0: events up to snapshot 3 at (ts, snapshot) (10,0) (20,1) (40,3) -> last before snapshot 3: 20; node 1: (10,0) (30,1) -> 10
+    assert got.dtype == torch.float32 and got.tolist() == [2.0, 1.0]
+    with pytest.raises(ValueError):
+        query_time.query_times([0], [1], [1.0], [9], [0], 5, 1)           # no event early enough
