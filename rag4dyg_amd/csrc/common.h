@@ -135,7 +135,10 @@ struct GreedyState {
     const int32_t* params;       // device int32[8]: max_gen, len_limit, n_eos, eos[0..3], 0
     int out_cap, t_cap;
 };
-int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s);
+// optional second job of the bookkeeping kernel: the decode step's input rows x[b,:] = wte[next[b]] + wpe[pos[b]] and the
+// clearing of `n_zero` 32-bit words (the step's split-K ticket counters)
+struct GreedyEmbed { const float* wte; const float* wpe; float* x_out; unsigned* zero_words; int vocab, n_positions, d, n_zero; };
+int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s, const GreedyEmbed* embed = nullptr);
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
 int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,

@@ -315,15 +315,17 @@ size_t r4d_gpt2_decode_workspace_bytes(const r4d_gpt2_config* cfg, int32_t B) {
     return carve(nullptr, (size_t)B, 0, decode_skinny_floats(cfg->n_embd), cfg->n_embd).bytes;
 }
 
-int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
-                             const float* inputs_embeds_d, const int32_t* pos_d, float* kv_cache_d, int32_t B,
-                             int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
-                             void* stream) {
+// `x_ready`: the un-normalised input rows are already in the workspace's x buffer and the ticket counters are clear (the
+// greedy step's bookkeeping kernel did both): no embedding launch, layer 0 reads its LayerNorm like every other layer
+static int decode_step_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                            const float* inputs_embeds_d, const int32_t* pos_d, float* kv_cache_d, int32_t B,
+                            int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
+                            void* stream, bool x_ready) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_cfg(cfg);
     if (rc) return rc;
     R4D_REQUIRE(w && w->wte && w->wpe && w->ln_f_w && w->ln_f_b && w->layers, "gpt2 decode: null weights");
-    R4D_REQUIRE((ids_d != nullptr) != (inputs_embeds_d != nullptr), "gpt2 decode: specify exactly one of ids and inputs_embeds");
+    R4D_REQUIRE(x_ready || (ids_d != nullptr) != (inputs_embeds_d != nullptr), "gpt2 decode: specify exactly one of ids and inputs_embeds");
     R4D_REQUIRE(pos_d && kv_cache_d && out_hidden_d, "gpt2 decode: null pointer");
     R4D_REQUIRE(B >= 1 && t_cap >= 1, "gpt2 decode: B=%d t_cap=%d", B, t_cap);
     const int d = cfg->n_embd, H = cfg->n_head;
@@ -344,13 +346,13 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         // M <= 32 and d in {512, 768}: LayerNorm runs inside the projection that reads it (gemm_skinny8_kernel) -- x stays
         // the un-normalised residual stream and two launches per layer disappear
         const bool fuse_ln = sk && L.c_attn_wT && L.c_fc_wT && gemm_skinny_fuses_ln(B, d, 3 * d);
-        if (l == 0)
+        if (l == 0 && !x_ready)
             rc = launch_embed_pos_layernorm(ids_d, inputs_embeds_d, pos_d, w->wte, w->wpe, cfg->vocab, cfg->n_positions,
                                             t_cap, B, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps, ws.x, ws.ln, s, cnt, cbytes);
         else if (!fuse_ln)
             rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
         if (rc) return rc;
-        if (fuse_ln && l > 0)
+        if (fuse_ln && (l > 0 || x_ready))
             rc = launch_gemm_skinny(ws.x, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, L.ln_1_w,
                                     L.ln_1_b, cfg->ln_eps, true);
         else
@@ -370,6 +372,14 @@ int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
         if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, B, 4 * d, d, EPI_RESIDUAL, ws.x, s, sk, true))) return rc;
     }
     return launch_layernorm(ws.x, w->ln_f_w, w->ln_f_b, B, d, cfg->ln_eps, out_hidden_d, s);
+}
+
+int r4d_gpt2_decode_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, const int64_t* ids_d,
+                             const float* inputs_embeds_d, const int32_t* pos_d, float* kv_cache_d, int32_t B,
+                             int32_t t_cap, float* out_hidden_d, void* workspace_d, size_t workspace_bytes,
+                             void* stream) {
+    return decode_step_impl(cfg, w, ids_d, inputs_embeds_d, pos_d, kv_cache_d, B, t_cap, out_hidden_d, workspace_d, workspace_bytes,
+                            stream, false);
 }
 
 static size_t greedy_pool_floats(const r4d_gpt2_config* cfg) {
@@ -406,9 +416,15 @@ int r4d_gpt2_greedy_step_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights*
     GreedyState g;
     g.next = st->next_d; g.lens = st->lens_d; g.pos = st->pos_d; g.active = st->active_d; g.gen_len = st->gen_len_d;
     g.out_tokens = st->out_tokens_d; g.params = st->params_d; g.out_cap = st->out_cap; g.t_cap = t_cap;
-    if ((rc = launch_greedy_advance(st->logits_d, B, V, g, s))) return rc;
-    return r4d_gpt2_decode_step_f32(cfg, w, st->next_d, nullptr, st->pos_d, kv_cache_d, B, t_cap, st->last_d, workspace_d,
-                                    workspace_bytes, stream);
+    // the bookkeeping kernel also writes the chosen token's input row into the step's x buffer and clears the ticket counters
+    GreedyEmbed ge;
+    ge.wte = w->wte; ge.wpe = w->wpe; ge.x_out = ws.x; ge.vocab = cfg->vocab; ge.n_positions = cfg->n_positions; ge.d = d;
+    size_t cbytes = 0;
+    void* cnt = ws.pool ? gemm_skinny_counters(ws.pool, &cbytes) : nullptr;
+    ge.zero_words = (unsigned*)cnt; ge.n_zero = (int)(cbytes / 4);
+    if ((rc = launch_greedy_advance(st->logits_d, B, V, g, s, &ge))) return rc;
+    return decode_step_impl(cfg, w, st->next_d, nullptr, st->pos_d, kv_cache_d, B, t_cap, st->last_d, workspace_d, workspace_bytes,
+                            stream, true);
 }
 
 struct r4d_decode_graph { hipGraph_t graph; hipGraphExec_t exec; };

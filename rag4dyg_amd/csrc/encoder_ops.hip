@@ -1,6 +1,7 @@
 // HBM-bound row kernels of the encoder (gfx950): embedding gather + LayerNorm, LayerNorm, causal
 // softmax, ln_f + mean-pool.  One 64-lane wavefront owns one row; reductions are wavefront shuffles
 // (no LDS, no atomics -> bitwise reproducible run to run).
+#include <string.h>
 #include "common.h"
 
 namespace r4d {
@@ -352,10 +353,18 @@ int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t
 // (lowest index among equal maxima) and the stop rules of the reference's greedy loops
 // (Evaluation_SimpleDyG.py:126-145, Evaluation_generator.py:153-175) -- so that a step needs no host round trip and
 // the whole step can be replayed as a captured graph.
-__global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __restrict__ logits, int V, GreedyState st) {
+//
+// With `emb.x_out` the kernel is ALSO the first kernel of the decode step that follows: it writes the un-normalised input row
+// x[b,:] = wte[next] + wpe[pos] of the token it has just chosen (the id and the position are in its registers: the separate
+// embedding kernel spent most of its 11 us on the two dependent loads id -> row), and clears the step's split-K ticket counters.
+__global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __restrict__ logits, int V, GreedyState st,
+                                                             GreedyEmbed emb) {
     __shared__ float sv[4];
     __shared__ int si[4];
+    __shared__ int s_next, s_pos;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (b == 0)
+        for (int i = tid; i < emb.n_zero; i += 256) emb.zero_words[i] = 0u;
     const float* row = logits + (long long)b * V;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -371,34 +380,49 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
     }
     if (lane == 0) { sv[wid] = best; si[wid] = bi; }
     __syncthreads();
-    if (tid != 0) return;
-    for (int w = 1; w < 4; ++w)
-        if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-    int a = st.active[b];
-    const int len = st.lens[b];
-    if (a) {
-        int g = st.gen_len[b];
-        if (g < st.out_cap) st.out_tokens[(long long)b * st.out_cap + g] = bi;
-        ++g;
-        st.gen_len[b] = g;
-        const int max_gen = st.params[0], len_limit = min(st.params[1], st.t_cap), n_eos = min(st.params[2], 4);
-        bool stop = g >= max_gen || g >= st.out_cap || len + 1 >= len_limit;      // the cache row written next is `len`
-        for (int e = 0; e < n_eos; ++e) stop |= bi == st.params[3 + e];
-        if (stop) a = 0;
-        st.active[b] = a;
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        int a = st.active[b];
+        const int len = st.lens[b];
+        if (a) {
+            int g = st.gen_len[b];
+            if (g < st.out_cap) st.out_tokens[(long long)b * st.out_cap + g] = bi;
+            ++g;
+            st.gen_len[b] = g;
+            const int max_gen = st.params[0], len_limit = min(st.params[1], st.t_cap), n_eos = min(st.params[2], 4);
+            bool stop = g >= max_gen || g >= st.out_cap || len + 1 >= len_limit;      // the cache row written next is `len`
+            for (int e = 0; e < n_eos; ++e) stop |= bi == st.params[3 + e];
+            if (stop) a = 0;
+            st.active[b] = a;
+        }
+        st.next[b] = bi;
+        st.pos[b] = a ? len : 0;                 // finished sequences rewrite their row 0: harmless, they are never read again
+        st.lens[b] = len + a;
+        s_next = bi; s_pos = a ? len : 0;
     }
-    st.next[b] = bi;
-    st.pos[b] = a ? len : 0;                     // finished sequences rewrite their row 0: harmless, they are never read again
-    st.lens[b] = len + a;
+    if (!emb.x_out) return;                      // (uniform per launch)
+    __syncthreads();
+    const int id = s_next, p = s_pos;
+    const bool bad = p < 0 || p >= emb.n_positions || p >= st.t_cap || id < 0 || id >= emb.vocab;   // as embed_pos_ln_kernel: poison, never fault
+    const float* src = emb.wte + (long long)(bad ? 0 : id) * emb.d;
+    const float* pe = emb.wpe + (long long)(bad ? 0 : p) * emb.d;
+    for (int c = tid; c < emb.d; c += 256) emb.x_out[(long long)b * emb.d + c] = bad ? __builtin_nanf("") : src[c] + pe[c];
 }
 
-int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s) {
+int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s, const GreedyEmbed* embed) {
     R4D_REQUIRE(logits && st.next && st.lens && st.pos && st.active && st.gen_len && st.out_tokens && st.params,
                 "greedy advance: null pointer");
     R4D_REQUIRE(V >= 1 && st.out_cap >= 1 && st.t_cap >= 1, "greedy advance: V=%d out_cap=%d t_cap=%d", V, st.out_cap, st.t_cap);
     if (B <= 0) return R4D_OK;
     ProfScope prof(PK_GREEDY_ADVANCE, 4.0 * B * (double)V, s);
-    hipLaunchKernelGGL(greedy_advance_kernel, dim3(B), dim3(256), 0, s, logits, V, st);
+    GreedyEmbed e;
+    memset(&e, 0, sizeof(e));
+    if (embed) {
+        e = *embed;
+        R4D_REQUIRE(e.wte && e.wpe && e.x_out && e.d >= 1, "greedy advance: bad embedding arguments");
+    }
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(B), dim3(256), 0, s, logits, V, st, e);
     R4D_CHECK_LAUNCH("greedy_advance");
     return R4D_OK;
 }
