@@ -153,6 +153,60 @@ def test_training_step_parameter_update_equals_oracle_adamw(dev):
     assert "_wt_cache" not in m.transformer.__dict__                         # stale transposed copies dropped
 
 
+@pytest.mark.parametrize("L,H,d,V,B,Ts", [(2, 6, 768, 300, 4, (37, 50, 23)),      # wikiv2 script shape (head_dim 128)
+                                           (3, 2, 256, 200, 5, (21, 33, 40)),      # hepth script shape (head_dim 128, d = 256)
+                                           (1, 8, 512, 500, 3, (130, 9, 64)),      # reddit shape (head_dim 64), one batch > 128 positions
+                                           (2, 4, 64, 60, 2, (25, 30, 22))])       # head_dim 16
+def test_training_gradients_other_shapes_equal_oracle(dev, L, H, d, V, B, Ts):
+    """The training forward + backward at the model shapes of the other reference scripts (wikiv2, hepth, reddit; ragged padded
+    lengths, also above one 128-position attention tile) against the oracle's grad-enabled forward + CPU autograd (pinned by G8):
+    embeddings, the loss and every parameter gradient element-wise (max-norm)."""
+    from oracle import gpt2_ref, train_ref
+    from rag4dyg_amd import training
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    seed = L * 100 + d
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+    cfg = GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H)
+    cfg.eta, cfg.gamma = 0.8, 0.4
+    m = GPT2LMHeadModelRAG(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(seed)
+    pad = V - 2
+
+    def batch(T):
+        ids = torch.randint(0, V - 2, (B, T), generator=g)
+        for i in range(B):                                        # right-padded ragged rows
+            n = int(torch.randint(max(5, T // 2), T + 1, (1,), generator=g))
+            ids[i, n:] = pad
+        ids[0, :] = torch.randint(0, V - 2, (T,), generator=g)      # one full-length row
+        return ids
+    anchor, pos, neg = batch(Ts[0]), batch(Ts[1]), batch(Ts[2])
+    times = torch.rand(3 * B, generator=g) * 50
+    idx = torch.arange(3 * B).view(3, B).t().contiguous()
+    alpha, temp, lam = 0.7, 0.2, 0.05
+    args = types.SimpleNamespace(device=dev, temperature=temp, lambda_decay=lam, alpha=alpha, per_gpu_train_batch_size=B)
+    random.seed(seed)
+    aug1, aug2 = training.aug(anchor, cfg.eta, cfg.gamma, V - 1)
+    trainer = training.EncoderTrainer(m)
+    emb = trainer.forward([t.to(dev) for t in (anchor, pos, neg, aug1, aug2)])
+    leaf = emb.view(5, B, -1).detach().requires_grad_(True)
+    with torch.enable_grad():
+        cl = training.CLtime_loss(args, leaf[0], leaf[1], leaf[2], times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
+        au = alpha * training.info_nce(args, leaf[3], leaf[4], temp, B, training.mask_correlated_samples(B))
+        (cl + au).backward()
+    grads = trainer.backward(leaf.grad.view(5 * B, -1))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "lm_head.weight"}
+    sdg["lm_head.weight"] = sdg["transformer.wte.weight"]
+    r = train_ref.training_step(sdg, H, anchor, pos, neg, times, idx, cfg.eta, cfg.gamma, alpha, temp, lam, V - 1, seed, with_grad=True)
+    assert rel_err(emb.view(5, B, -1).cpu().numpy(), r["emb"].detach().numpy()) < 1e-4
+    assert abs(float((cl + au).item()) / float(r["loss"].item()) - 1) < 1e-4
+    r["loss"].backward()
+    errs = {n: rel_err(grads[n].cpu().numpy(), sdg[n].grad.numpy()) for n in grads}
+    print(f"L{L} H{H} d{d}: worst element-wise (max-norm) gradient error {max(errs.values()):.2e}")
+    assert max(errs.values()) < 1e-3, {n: e for n, e in errs.items() if e > 1e-3}
+
+
 def test_three_training_steps_track_the_oracle(dev):
     """Three consecutive updates (clip + AdamW, lr large enough to move the weights visibly) on the device against the oracle's
     loop (grad-enabled forward, CPU autograd, restated clip_grad_norm_ + transformers.AdamW): the loss of EVERY step -- steps 2
