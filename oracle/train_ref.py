@@ -3,8 +3,18 @@
 Follows ``train/train_retriever.py:40-98`` (``CLtime_loss``, ``mask_correlated_samples``, ``info_nce``), ``:177-196`` (the five
 forwards and the loss of ``train_epoch``) and ``models/modeling_rag.py:774-840`` (``_aug``).  Pinned by
 ``tests/golden/g8_training_step.npz`` (the reference's own functions and autograd, run by ``oracle/gen_golden.py g8``).
-Dropout is the identity here (the fixtures were generated with all dropout probabilities 0: the reference's p = 0.1 masks
-come from the device RNG and cannot be reproduced on another device).
+Dropout is the identity in the fixtures (generated with all dropout probabilities 0: the reference's p = 0.1 masks come from
+the device RNG and cannot be reproduced on another device); ``PhiloxDropout`` restates the PRODUCT's mask generator so that a
+training-mode step can be checked given the same masks.
+
+PARITY NOTE -- the optimizer update is unpinned.  ``adamw_step`` / ``clip_coefficient`` restate ``transformers.AdamW.step``
+(the class ``utils/model.py:80-93`` instantiates; third-party, README.md:9 ``transformers>=4.24.0``) and
+``torch.nn.utils.clip_grad_norm_``.  ``transformers.AdamW`` does not exist in the installed transformers 5.15 (removed upstream)
+and is not in the reference tree, so the restatement follows its published algorithm -- bias-corrected step size
+``lr * sqrt(1 - b2^t) / (1 - b1^t)``, denominator ``sqrt(v) + eps`` (eps NOT bias-corrected), decoupled decay
+``p -= lr * wd * p`` applied AFTER the update -- and is cross-checked against ``torch.optim.AdamW``, an independent
+implementation of the same moments, in the one regime where the two coincide exactly (no decay, torch's eps rescaled by
+``1 / sqrt(1 - b2^t)``; ``tests/test_oracle_golden.py``).  Loss values, embeddings and gradients ARE pinned (G8).
 """
 import math
 import random
