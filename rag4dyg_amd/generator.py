@@ -256,12 +256,20 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
         cached keys/values (``modeling_gpt2.py:177-197`` ``layer_past`` semantics), lm_head on those rows only.
     Same tokens as the one-at-a-time loop up to fp32 summation order.  Finished queries keep their slot (their rows
     are ignored); argmax and the stop rules run on the device (``GreedyDecoder``), one captured graph per token."""
+    if len(token_lists) == 0:
+        return []
+    return _rag_batch_finish(_rag_batch_start(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl, prep))
+
+
+@torch.no_grad()
+def _rag_batch_start(args, model, tokenizer, dataset, token_lists, index_lists, mode, max_len, n_spl, prep=None, slot=0):
+    """First half of ``greedy_decode_rag_batch``, everything up to the filled key/value cache: fusion rows, augmented prompt
+    embeddings, length-grouped prefill.  All of it is queued on the CURRENT stream without a host wait; ``slot`` picks one
+    of the decoders kept per batch shape, so that the next batch can be prefilled while this one still decodes."""
     tr = model.transformer
     wte = tr.wte.weight
     dev = wte.device
     n = len(token_lists)
-    if n == 0:
-        return []
     sims = fusion_rows_batch(args, model, tokenizer, dataset, index_lists, args.topK, prep)                 # [n, r, d]
     r = sims.shape[1]
     eos = tokenizer.encode("<|endoftext|>")
@@ -276,34 +284,64 @@ def greedy_decode_rag_batch(args, model, tokenizer, dataset, token_lists, index_
         ids_h[i, 2 + r:len(t) + r] = t[2:]
     H_aug = wte[torch.from_numpy(ids_h).to(dev)]
     H_aug[:, 2:2 + r] = sims
-    dec = tr.greedy_decoder(n, cap)
+    dec = tr.greedy_decoder(n, cap, slot)
     last = tr.prefill_last(dec.cache, lens0, inputs_embeds=H_aug)      # length-grouped forwards, cache rows [0, lens)
-    lens = torch.tensor(lens0, dtype=torch.int32, device=dev)
+    lens = torch.tensor(lens0, dtype=torch.int32).to(dev, non_blocking=True)
     # stop rules of Evaluation_generator.py:168-175 in augmented positions (r fused rows sit inside every prompt)
     limit = cap if mode == "val" else min(cap, max_len - n_spl + r)
-    gen = dec.run(last, lens, 11 if mode == "val" else cap, limit, eos)
-    for t, g in zip(toks, gen):
+    return dict(dec=dec, last=last, lens=lens, toks=toks, max_gen=11 if mode == "val" else cap, limit=limit, eos=eos)
+
+
+@torch.no_grad()
+def _rag_batch_finish(st):
+    """Second half: the device greedy loop on the CURRENT stream (waits for the generated ids), prompts + generated ids."""
+    gen = st["dec"].run(st["last"], st["lens"], st["max_gen"], st["limit"], st["eos"])
+    for t, g in zip(st["toks"], gen):
         t.extend(g)
-    return toks
+    return st["toks"]
 
 
 def decode_rag_batches(args, model, tokenizer, dataset, batches, mode, max_len, n_spl):
-    """``greedy_decode_rag_batch`` over a list of (token_lists, index_lists) batches, yielding each batch's outputs.  The
-    host half of the NEXT batch's fusion (graph construction, pure Python / numpy) runs on a helper thread while the
-    current batch decodes -- the main thread spends that time waiting for the GPU."""
+    """``greedy_decode_rag_batch`` over a list of (token_lists, index_lists) batches, yielding each batch's outputs.  The host
+    half of the next batch's fusion (graph construction, pure Python / numpy) runs on a helper thread while the current batch
+    decodes.  ``R4D_DECODE_PIPELINE=1`` (off by default) additionally runs batch b + 1's fusion rows and prefill on a second
+    HIP stream, into a second decoder slot, while batch b decodes -- identical ids, but MEASURED SLOWER (UCI_13 shape, batch 32:
+    35.5 k against 38.2 k tokens/s): the prefill's GEMM workgroups hold every CU for tens of microseconds at a time, and each
+    of the decode step's 33 dependent launches then queues behind them; the decode chain loses more than the prefill hides."""
     from concurrent.futures import ThreadPoolExecutor
     if not batches:
         return
+    pipelined = os.environ.get("R4D_DECODE_PIPELINE", "0") == "1" and len(batches) > 1
+    cur = torch.cuda.current_stream()
+    s_fill, s_dec = (torch.cuda.Stream(), torch.cuda.Stream()) if pipelined else (cur, cur)
+    if pipelined:
+        s_fill.wait_stream(cur); s_dec.wait_stream(cur)
+
+    def start(b, prep):
+        toks, idxs = batches[b]
+        with torch.cuda.stream(s_fill):
+            st = _rag_batch_start(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl, prep, slot=b % 2)
+            st["ready"] = s_fill.record_event() if pipelined else None
+        return st
+
     with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(fusion_host_prep, args, model, dataset, batches[0][1], args.topK)
-        for b, (toks, idxs) in enumerate(batches):
-            prep = fut.result()
-            if b + 1 < len(batches):
-                fut = pool.submit(fusion_host_prep, args, model, dataset, batches[b + 1][1], args.topK)
-            if prep is None:                                           # other fusion modes: everything in-line
-                yield greedy_decode_rag_batch(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl)
-            else:
-                yield greedy_decode_rag_batch(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl, prep)
+        nxt = start(0, pool.submit(fusion_host_prep, args, model, dataset, batches[0][1], args.topK).result())
+        fut = pool.submit(fusion_host_prep, args, model, dataset, batches[1][1], args.topK) if len(batches) > 1 else None
+        for b in range(len(batches)):
+            st = nxt
+            if b + 1 < len(batches):                                   # queue the next batch's fill BEFORE waiting on this decode
+                prep = fut.result()
+                if b + 2 < len(batches):
+                    fut = pool.submit(fusion_host_prep, args, model, dataset, batches[b + 2][1], args.topK)
+                nxt = start(b + 1, prep)                               # its decoder slot was released by finish(b - 1)
+            with torch.cuda.stream(s_dec):
+                if pipelined:
+                    s_dec.wait_event(st["ready"])
+                    st["last"].record_stream(s_dec); st["lens"].record_stream(s_dec)
+                out = _rag_batch_finish(st)
+            yield out
+    if pipelined:
+        cur.wait_stream(s_fill); cur.wait_stream(s_dec)
 
 
 # ------------------------------------------------------------------------------------------------ dataset / eval

@@ -404,17 +404,18 @@ class GPT2Model(_PreTrained):
                    "gpt2_decode_step")
         return hidden
 
-    def greedy_decoder(self, B, t_cap):
+    def greedy_decoder(self, B, t_cap, slot=0):
         """A ``GreedyDecoder`` with room for ``B`` sequences of ``t_cap`` positions, reused across batches (its captured
-        graph and buffers are keyed by (B, rounded t_cap))."""
+        graph and buffers are keyed by (B, rounded t_cap)).  ``slot``: independent decoders of the same shape (one batch
+        decodes while the next is prefilled into the other)."""
         t_cap = (int(t_cap) + 127) // 128 * 128
         cache = self.__dict__.setdefault("_greedy_decoders", {})
-        fits = [k for k in cache if k[0] == B and k[1] >= t_cap]
+        fits = [k for k in cache if k[0] == B and k[1] >= t_cap and k[2] == slot]
         if fits:
             return cache[min(fits)]
-        for k in [k for k in cache if k[0] == B]:                            # a larger cache replaces the smaller ones
+        for k in [k for k in cache if k[0] == B and k[2] == slot]:           # a larger cache replaces the smaller ones
             cache.pop(k).close()
-        dec = cache[(B, t_cap)] = GreedyDecoder(self, B, t_cap)
+        dec = cache[(B, t_cap, slot)] = GreedyDecoder(self, B, t_cap)
         return dec
 
     @torch.no_grad()

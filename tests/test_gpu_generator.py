@@ -162,3 +162,31 @@ def test_reddit_shape_graphpooling_decode_batch32(dev, topk):
         exact += assert_tokens_equal_or_tie(many[qi][len(q):], want, logits_at, f"reddit top-{topk} query {qi}")
         assert len(many[qi]) - len(q) == len(want)
     print(f"reddit top-{topk}: {exact} of 32 generated lists identical to the oracle's")
+
+
+def test_pipelined_batches_equal_one_batch_at_a_time(dev, monkeypatch):
+    """decode_rag_batches overlaps batch b's decode with batch b + 1's fusion + prefill on a second stream (two decoder
+    slots): the ids must be those of the one-batch-at-a-time form, for ragged batch sizes, with the overlap on and off."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd import generator, synth
+    sh = synth.SHAPES["reddit"]
+    L, H, d, V = 2, 8, 512, sh.vocab_generator
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=56, random_affine=True)
+    model = _rag_model(sd, L, H, d, V, dev)
+    model.get_gnn(d, d // 2, d, 1, 0.2)
+    model = model.to(dev).eval()
+    pool = [s.tolist() for s in synth.sequences(sh, 600, "pool", seed=5)]
+    queries = [s.tolist() for s in synth.sequences(sh, 100, "query", seed=6)]
+    rng = np.random.default_rng(1)
+    idxs = [rng.permutation(600)[:7].tolist() for _ in queries]
+    ds = types.SimpleNamespace(retrieval_sources=pool)
+    args = types.SimpleNamespace(fusion="graphpooling", m=1, topK=7)
+    tok = _Tok(sh.pad_id, sh.v0)
+    cuts = [0, 32, 64, 96, 100]                                        # three full batches and a ragged last one
+    batches = [(queries[a:b], idxs[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    want = [generator.greedy_decode_rag_batch(args, model, tok, ds, q, ix, "val", 1024, 19) for q, ix in batches]
+    for mode_env in ("1", "0"):
+        monkeypatch.setenv("R4D_DECODE_PIPELINE", mode_env)
+        got = list(generator.decode_rag_batches(args, model, tok, ds, batches, "val", 1024, 19))
+        assert got == want, mode_env
+    torch.cuda.synchronize()

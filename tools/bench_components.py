@@ -194,18 +194,18 @@ def generator(shape_name="UCI_13", L=6, H=8, d=768, topk=7, pool_n=512):
     t0 = time.perf_counter()
     ntok1 = run_gpu(list(zip(queries[:16], idxs[:16])))
     el1 = time.perf_counter() - t0
-    gen.greedy_decode_rag_batch(args, model, tok, ds, queries[:32], idxs[:32], "val", 1024, 12)     # warm-up (decoder, graph)
+    batches = [(queries[b0:b0 + 32], idxs[b0:b0 + 32]) for b0 in range(0, len(queries), 32)]     # --per_gpu_eval_batch_size 32
+    list(gen.decode_rag_batches(args, model, tok, ds, batches[:3], "val", 1024, 12))                # warm-up (both decoder slots, graphs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ntok = 0
-    batches = [(queries[b0:b0 + 32], idxs[b0:b0 + 32]) for b0 in range(0, len(queries), 32)]     # --per_gpu_eval_batch_size 32
     for (qs, _ix), outs in zip(batches, gen.decode_rag_batches(args, model, tok, ds, batches, "val", 1024, 12)):
         ntok += sum(len(o) - len(q) for o, q in zip(outs, qs))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     # the same queries at --per_gpu_eval_batch_size 128 (the throughput lever of a latency-bound step: same ids per query)
     big = [(queries[b0:b0 + 128], idxs[b0:b0 + 128]) for b0 in range(0, len(queries), 128)]
-    list(gen.decode_rag_batches(args, model, tok, ds, big[:1], "val", 1024, 12)); torch.cuda.synchronize()
+    list(gen.decode_rag_batches(args, model, tok, ds, big[:2], "val", 1024, 12)); torch.cuda.synchronize()
     t0 = time.perf_counter()
     ntok128 = 0
     for (qs, _ix), outs in zip(big, gen.decode_rag_batches(args, model, tok, ds, big, "val", 1024, 12)):
