@@ -228,6 +228,49 @@ def generator(shape_name="UCI_13", L=6, H=8, d=768, topk=7, pool_n=512):
 
 
 
+def simpledyg_eval():
+    """SimpleDyG greedy link-prediction decode (utils/Evaluation_SimpleDyG.py:120-145) at BASELINE config 1's model
+    (L6 H8 d768 V1800): test-set histories of the UCI_13 length distribution, val mode (11 tokens per query) and test mode
+    (until <|endoftext|> or the context limit; random-init weights rarely emit it, so this is the long-generation case), batch 32,
+    next to the oracle's one-at-a-time loop on the host cores."""
+    import types
+    from oracle import gpt2_ref
+    from rag4dyg_amd import evaluation
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    shape = synth.SHAPES["UCI_13"]
+    L, H, d, V = 6, 8, 768, shape.vocab - 1                    # SimpleDyG omits [MASK] (main_SimpleDyG.py:91-95)
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=9, random_affine=True)
+    model = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=1024, n_ctx=1024, n_embd=d, n_layer=L, n_head=H))
+    model.load_state_dict(sd, strict=False); model.tie_weights()
+    model = model.to(dev).eval()
+    queries = [s.tolist() for s in synth.sequences(shape, 256, "query", seed=3)]
+    tok = types.SimpleNamespace(encode=lambda s: [shape.v0], pad_token_id=shape.pad_id)
+    out = {}
+    for mode, budget in (("val", None), ("test", 160)):
+        max_len = 1024 if mode == "val" else None
+        evaluation.greedy_decode_batch(model, tok, queries[:32], mode, 1024 if mode == "val" else max(len(q) for q in queries[:32]) + budget, 0, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ntok = 0
+        for b0 in range(0, len(queries), 32):
+            qs = queries[b0:b0 + 32]
+            ml = 1024 if mode == "val" else max(len(q) for q in qs) + budget      # test mode: a context limit `budget` tokens past the longest prompt
+            outs = evaluation.greedy_decode_batch(model, tok, qs, mode, ml, 0, dev)
+            ntok += sum(len(o) - len(q) for o, q in zip(outs, qs))
+        torch.cuda.synchronize()
+        out[mode] = (ntok, time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    ncpu = 0
+    for q in queries[:2]:
+        ncpu += len(gpt2_ref.greedy_decode(sd, H, q, shape.v0, "val")) - len(q)
+    elc = time.perf_counter() - t0
+    emit(component="simpledyg_greedy_eval", shape="UCI_13", model=f"L{L} H{H} d{d} V{V}", queries=len(queries), batch=32,
+         val_tokens_per_s=round(out["val"][0] / out["val"][1], 1), val_queries_per_s=round(len(queries) / out["val"][1], 1),
+         test_tokens=out["test"][0], test_tokens_per_s=round(out["test"][0] / out["test"][1], 1),
+         cpu_baseline={"kind": "port", "cores": host_cores(), "tokens_per_s": round(ncpu / elc, 2),
+                       "sample": "2 queries, val mode, oracle torch-CPU fp32 (full forward per token, as the reference)"})
+
+
 def generator_reddit():
     """BASELINE config 5 shape: reddit t=11, L2 H8 d512, V = 11,919, pool 10,527, top-7 (the script) and top-5 (BASELINE.json)."""
     generator("reddit", 2, 8, 512, 7, 10527)
@@ -363,6 +406,6 @@ def jaccard_cpu_all_cores():
 
 
 if __name__ == "__main__":
-    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "jaccard_cpu", "pool", "generator", "generator_reddit", "training", "training_cpu"]):
+    for part in (sys.argv[1:] or ["scan", "topk", "jaccard", "jaccard_cpu", "pool", "generator", "generator_reddit", "simpledyg", "training", "training_cpu"]):
         {"scan": scan, "topk": topk, "jaccard": jaccard, "jaccard_cpu": jaccard_cpu_all_cores, "pool": pool, "generator": generator,
-         "generator_reddit": generator_reddit, "training": training, "training_cpu": training_cpu}[part]()
+         "generator_reddit": generator_reddit, "simpledyg": simpledyg_eval, "training": training, "training_cpu": training_cpu}[part]()
