@@ -476,7 +476,7 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
     if (ng) {                                          // 8 waves per 32-row tile of wT
         const int SL = S8_NW * 32 * ng;
         KS = K / SL;
-        float* partial = KS > 1 ? scratch : nullptr;
+        float* partial = KS > 1 ? scratch + S16_MAX_TILES : nullptr;    // never the ticket counters at the head of the scratch
         ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + (KS > 1 ? 4.0 * KS * 32.0 * N : 4.0 * M * N), s);
         const dim3 grid(cdiv(N, 32), KS), block(64 * S8_NW);
 #define SK8_(NG_, LN_)                                                                                                    \
@@ -491,12 +491,12 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
         KS = K / SK_KC;
         // algorithmic bytes: the weight matrix once (+ x per slice, + partials)
         ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + 4.0 * KS * 32.0 * N, s);
-        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(cdiv(N, 32), 4), KS), dim3(256), 0, s, x, wT, M, N, K, scratch);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(cdiv(N, 32), 4), KS), dim3(256), 0, s, x, wT, M, N, K, scratch + S16_MAX_TILES);
         R4D_CHECK_LAUNCH("gemm_skinny");
     }
     {
         ProfScope prof(PK_GEMM_SKINNY_EPI, 4.0 * KS * M * (double)N + 8.0 * M * N, s);
-        hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((unsigned)cdiv((long long)M * N, 256)), dim3(256), 0, s, scratch,
+        hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((unsigned)cdiv((long long)M * N, 256)), dim3(256), 0, s, scratch + S16_MAX_TILES,
                            KS, M, N, bias, resid, epilogue, y);
         R4D_CHECK_LAUNCH("gemm_skinny_epilogue");
     }

@@ -140,7 +140,7 @@ def test_attention_oracle_shapes(dev, B, T, H, hd, attn_mode):
     assert rel_err(out.numpy(), ref.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("L,H,d", [(2, 2, 64), (2, 8, 768), (1, 2, 512)])
+@pytest.mark.parametrize("L,H,d", [(2, 2, 64), (2, 8, 768), (1, 2, 512), (1, 8, 1024), (2, 2, 256)])
 def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
     """r4d_gpt2_decode_step_f32: ragged batch, prefill + 5 cached steps == the last row of a full forward over each
     extended sequence (oracle AND the library's own full forward); an out-of-cache position poisons its row only."""
@@ -180,7 +180,7 @@ def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
     assert torch.isnan(h2[2]).all() and not torch.isnan(h2[[0, 1, 3, 4]]).any()
 
 
-@pytest.mark.parametrize("L,H,d,B", [(2, 2, 64, 5), (2, 8, 768, 32), (1, 2, 512, 33)])
+@pytest.mark.parametrize("L,H,d,B", [(2, 2, 64, 5), (2, 8, 768, 32), (1, 2, 512, 33), (1, 8, 1024, 7), (2, 2, 256, 32), (1, 8, 1280, 4)])
 def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B):
     """GreedyDecoder (argmax + stop rules on the device; captured HIP graph and kernel-by-kernel) generates exactly what
     a host loop over decode_step / lm_logits / argmax generates: max-token, end-of-sequence and length stops, ragged
