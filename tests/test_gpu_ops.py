@@ -392,6 +392,29 @@ def test_normalize_and_score_topk_vs_oracle(dev):
         assert np.array_equal(perm, retrieval_ref.rank_full(S))
 
 
+@pytest.mark.parametrize("d", [32, 96, 128, 384, 1024, 2048])
+def test_score_topk_every_scan_variant(dev, d):
+    """Every contraction-split variant of the pool scan (d = 32 ... 1024), a width with no variant (96: GEMM route) and one past
+    the table (2048), at query counts on both sides of the 32-query block and of the scan / GEMM switch (64), pool sizes
+    below one tile and ragged: scores against the oracle, selection bit-exact on the device's own scores."""
+    from rag4dyg_amd import ops
+    from oracle import retrieval_ref
+    g = torch.Generator().manual_seed(d)
+    for Q, N, k in ((1, 31, 5), (32, 4097, 10), (33, 1000, 3), (64, 2500, 10), (65, 333, 7)):
+        q = torch.randn(Q, d, generator=g)
+        p = torch.randn(N, d, generator=g) + 0.2
+        p[N // 3] = p[1]
+        ref = retrieval_ref.score_batch(q, p).numpy()
+        qh, ph = ops.normalize_rows(q.to(dev)), ops.normalize_rows(p.to(dev))
+        vals, idx, S = ops.score_topk(qh, ph, k, index_offset=7, want_scores=True)
+        S = S.cpu().numpy()
+        assert rel_err(S, ref) < 1e-5 and elementwise_err(S, ref) < 1, (d, Q, N)
+        ev, ei = retrieval_ref.topk_stable(S, k)
+        assert np.array_equal(idx.cpu().numpy(), ei + 7) and np.array_equal(vals.cpu().numpy(), ev), (d, Q, N)
+        v2, i2, _ = ops.score_topk(qh, ph, k, index_offset=7, want_scores=False)        # the no-score-output form: same selection
+        assert np.array_equal(i2.cpu().numpy(), ei + 7) and np.array_equal(v2.cpu().numpy(), ev), (d, Q, N)
+
+
 def _rank_inputs(rows, n, seed, dtype):
     """Score rows full of ties and special values: quantised normals, duplicated columns, +-inf, -0.0, NaN."""
     rng = np.random.default_rng(seed)
