@@ -180,15 +180,16 @@ def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
     assert torch.isnan(h2[2]).all() and not torch.isnan(h2[[0, 1, 3, 4]]).any()
 
 
-@pytest.mark.parametrize("L,H,d,B", [(2, 2, 64, 5), (2, 8, 768, 32), (1, 2, 512, 33), (1, 8, 1024, 7), (2, 2, 256, 32), (1, 8, 1280, 4)])
-def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B):
+@pytest.mark.parametrize("L,H,d,B,V", [(2, 2, 64, 5, 90), (2, 8, 768, 32, 90), (1, 2, 512, 33, 90), (1, 8, 1024, 7, 90), (2, 2, 256, 32, 90),
+                                       (1, 8, 1280, 4, 90), (1, 8, 1024, 4, 5000), (1, 2, 512, 9, 11919)])
+def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B, V):
     """GreedyDecoder (argmax + stop rules on the device; captured HIP graph and kernel-by-kernel) generates exactly what
     a host loop over decode_step / lm_logits / argmax generates: max-token, end-of-sequence and length stops, ragged
     prompts, B <= 32 (skinny lm_head) and B > 32 (tiled), a decoder reused for a second batch."""
     from oracle import gpt2_ref
     from rag4dyg_amd import ops
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
-    V, P = 90, 128
+    P = 128                                                           # V = 5000 at d = 1024: lm_head split over k AND > 256 column tiles
     sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=L * 10 + H, random_affine=True)
     m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
     m.load_state_dict(sd, strict=False); m.tie_weights()
