@@ -598,6 +598,21 @@ def g8_training_step():
     _save("g8_training_step", **out)
 
 
+def g8b_lr_schedule():
+    """``adjust_learning_rate`` (train/train_retriever.py:120-130) sampled over warm-up and cosine epochs."""
+    _import_utils_model()
+    import train.train_retriever as tr
+    rows = []
+    for warm, epochs, ipe, base in ((0, 50, 150, 1e-5), (2, 10, 37, 3e-4), (1, 3, 5, 1.0)):
+        args = types.SimpleNamespace(warmup_steps=warm, num_train_epochs=epochs)
+        opt = types.SimpleNamespace(param_groups=[{"lr": None}])
+        for ep in range(epochs):
+            for i in sorted({0, 1, ipe // 2, ipe - 1}):
+                tr.adjust_learning_rate(args, opt, ep, base, i, ipe)
+                rows.append((warm, epochs, ipe, base, ep, i, opt.param_groups[0]["lr"]))
+    _save("g8b_lr_schedule", rows=np.array(rows, np.float64))
+
+
 def g9_query_times():
     """get_train_query_time.py (the training loop's ``resources/<ds>_train_query_time.pt``): the reference's own ``load_data`` /
     ``get_query_time`` run on the shipped event tables of all three datasets; committed: the event columns the functions
@@ -626,7 +641,7 @@ def g9_query_times():
 
 def main():
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
-              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g9": g9_query_times}
+              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g8b": g8b_lr_schedule, "g9": g9_query_times}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

@@ -662,3 +662,17 @@ def test_train_query_times_match_reference_on_all_shipped_datasets(tmp_path, mon
     assert got.dtype == torch.float32 and got.tolist() == [2.0, 1.0]
     with pytest.raises(ValueError):
         query_time.query_times([0], [1], [1.0], [9], [0], 5, 1)           # no event early enough
+
+
+def test_learning_rate_schedule_matches_reference():
+    """adjust_learning_rate (linear warm-up over --warmup_steps EPOCHS, then half a cosine) against the reference function's own
+    values (G8b): three (warm-up, epochs, iterations per epoch, base lr) settings, every epoch, four iterations each."""
+    from types import SimpleNamespace
+    from rag4dyg_amd import training
+    rows = load_golden("g8b_lr_schedule")["rows"]
+    assert len(rows) > 200
+    for warm, epochs, ipe, base, ep, i, want in rows:
+        args = SimpleNamespace(warmup_steps=int(warm), num_train_epochs=int(epochs))
+        opt = SimpleNamespace(lr=None)
+        training.adjust_learning_rate(args, opt, int(ep), float(base), int(i), int(ipe))
+        assert opt.lr == want, (warm, epochs, ipe, ep, i, opt.lr, want)
