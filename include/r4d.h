@@ -29,7 +29,7 @@ extern "C" {
 #define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
 #define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
 
-#define R4D_ABI_VERSION 2
+#define R4D_ABI_VERSION 3
 
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
@@ -214,6 +214,19 @@ int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int3
 int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d /* optional [N,K] copy or NULL */,
                    const float* bias_d, const float* residual_d,
                    int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
+/*
+ * The same Conv1D on the bf16 matrix cores AT FP32 ACCURACY ("bf16x3" split): every fp32 operand is the exact sum of three
+ * bf16 numbers (hi + mid + lo) and a product is evaluated as its six leading partial products
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- 2.67x fewer matrix-pipe cycles than the exact-f32 MFMA at an error
+ * against float64 that is no larger (shorter fp32 accumulation chains; acceptance table in profiles/).
+ * r4d_split3_planes_bf16: the STATIC operand, once per checkpoint: w_d fp32 [K,N] (reference Conv1D layout; transposed != 0:
+ * an [N,K] copy) -> planes_d bf16 [3][N][K] (hi, mid, lo planes, K contiguous; 6 * N * K bytes).
+ * r4d_conv1d_s3_f32: y = epilogue(x[M,K] @ W + bias) with W given as those planes; x stays fp32 and is split on the fly.
+ * K % 32 == 0; epilogue as r4d_conv1d_f32.
+ */
+int r4d_split3_planes_bf16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream);
+int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d,
+                      int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
 /* Causal multi-head attention on packed c_attn output qkv_d [B,T,3d] -> a_d [B,T,d] (heads merged).
  * Attention._attn + split/merge_heads, modeling_gpt2.py:140-175; scale = division by sqrt(hd) (:143).
  * scores_ws_d: device scratch of r4d_attention_workspace_bytes(B,H,T). */

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: tools/ A/B tuning only
 
-R4D_ABI_VERSION = 2
+R4D_ABI_VERSION = 3
 
 
 class R4DError(RuntimeError):
@@ -79,6 +79,8 @@ PROTOTYPES = {
     "r4d_lm_logits_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_layernorm_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),
     "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_split3_planes_bf16": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_conv1d_s3_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_attention_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_attention_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_normalize_rows_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),

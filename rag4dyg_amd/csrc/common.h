@@ -41,7 +41,7 @@ int dbgflag_kc(); int dbgflag_att(); int dbgflag_sk(); int dbgflag_jac(); int db
 // ------------------------------------------------------------------ launch profiler (profile.hip)
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
-    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
+    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_S3_128x256, PK_GEMM_S3_128x128, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
     PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN, PK_GREEDY_ADVANCE,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };
@@ -91,6 +91,18 @@ void* gemm_skinny_counters(float* scratch, size_t* bytes);
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
                        const float* ln_b = nullptr, float ln_eps = 0.f, bool counters_zeroed = false);
+
+// gemm_s3.hip: C = epilogue(A . W^T + bias) on the bf16 matrix cores at fp32 accuracy (A fp32, split on the fly into three
+// bf16 terms; W given as three pre-split bf16 planes [3][N][K]); K % 32 == 0
+struct S3Args {
+    const float* A; const unsigned short* planes; float* C;
+    const float* bias; const float* resid;
+    int M, N, K, lda, ldc, ldr, epilogue;
+};
+bool gemm_s3_supported(int M, int K, int N);
+int launch_gemm_s3(const S3Args& a, hipStream_t stream);
+// w element (n, k) at w[k * ld_k + n * ld_n] -> planes [3][N][K] bf16 (hi, mid, lo)
+int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s);
 
 // ------------------------------------------------------------------ train_ops.hip
 struct DropKey { unsigned seed_lo, seed_hi, step_lo, step_hi; };      // Philox key (seed) and counter words 2-3 (step)

@@ -1,0 +1,415 @@
+// "bf16x3" GEMM: C[M,N] = epilogue(A[M,K] . W^T + bias) computed on the bf16 matrix cores at fp32 accuracy.
+//
+// Every fp32 operand is written as the EXACT sum of three bf16 numbers, x = hi + mid + lo (round-to-nearest at each step;
+// 3 x 8 significant bits cover the 24 of an fp32), and a product a.b is evaluated as the six partial products whose
+// weight is >= 2^-16 of it: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi -- each a v_mfma_f32_32x32x16_bf16 with an fp32
+// accumulator (bf16 x bf16 is exact in fp32; the dropped terms mid.lo, lo.mid, lo.lo are <= 2^-23 |a.b|).  One fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, 64 cycles for k = 2) becomes six bf16 MFMAs of 32 cycles for k = 16: 2.67x fewer matrix-pipe
+// cycles per flop, and -- measured against float64 on the encoder's dominant shape (profiles/r03_s3_accuracy)
+// -- a SMALLER error than the exact-f32 instruction, because the fp32 accumulation chains are 8x shorter (one rounding
+// per 16 products and plane pair instead of one per product).
+//
+// Operands: A is the fp32 activation [M,K] as every other kernel leaves it -- it is split on the fly while its tile is
+// staged (11 VALU instructions per two elements, done once per element and workgroup: 8 % of the MFMA cycles at
+// BN = 256); W is a STATIC weight, split once per checkpoint into three k-contiguous bf16 planes [3][N][K]
+// (r4d_split3_planes_bf16), so its staging is a plain copy.
+//
+// Tile structure (BK = 32, 8 wavefronts): LDS holds per stage three bf16 planes of the A tile and three of the W tile,
+// rows of 64 bytes with the 16-byte chunk index XOR-ed with (row >> 2) & 3, which makes every ds_read_b128 of a fragment
+// (lane = row, half-wave = k chunk) and every ds_write_b128 of the staging conflict-free without padding; a lane's six
+// fragments of a k-step are 16 bytes each = the 8 consecutive k the bf16 MFMA wants.  Global loads are buffer loads with
+// a loop-invariant lane offset and the k-tile (and the plane) in the scalar offset; out-of-range rows are clamped, K % 32
+// == 0 is a precondition; register-staged pipeline with NBUF LDS stages and one barrier per k-tile.
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace r4d {
+
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: low half = bf16(a), RNE
+    const f32x2s v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2s));
+}
+// two fp32 -> packed (hi, hi), (mid, mid), (lo, lo)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+__device__ __forceinline__ f32x2s gelu_new_s3(f32x2s x) {            // the epilogue of gemm_f32_kc.hip, same instructions
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    const f32x2s a = x * x * k1 + k0;
+    const f32x2s w = x * a;
+    f32x2s e;
+    e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);
+    e = e + 1.0f;
+    f32x2s r;
+    r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y);
+    return x * r;
+}
+__device__ __forceinline__ float gelu_new_s3_1(float x) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+}
+
+struct S3Shape {
+    int M, N, K, lda, ldc, ldr;
+    int plane_bytes;          // N * K * 2: distance between the bf16 planes of W
+};
+
+// ---------------------------------------------------------------------------------------------- weight planes
+// w element (n, k) at w[k * ld_k + n * ld_n]  (reference Conv1D layout [K,N]: ld_k = N, ld_n = 1; a [N,K] copy: 1, K)
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ w, int N, int K, long long ld_k,
+                                                            long long ld_n, unsigned short* __restrict__ planes) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 rows of 32 per pass
+    const bool n_fast = ld_n == 1;                                    // read along the unit stride
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n_fast ? n0 + tx : n0 + r, k = n_fast ? k0 + r : k0 + tx;
+        const float v = (n < N && k < K) ? w[(long long)k * ld_k + (long long)n * ld_n] : 0.f;
+        if (n_fast) tile[tx][r] = v; else tile[r][tx] = v;            // tile[n][k]
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {                                // write along k
+        const int n = n0 + r, k = k0 + tx;
+        if (n >= N || k >= K) continue;
+        const float x = tile[r][tx];
+        unsigned h, m, l;
+        split3_pair(x, 0.f, h, m, l);
+        const size_t o = (size_t)n * K + k, P = (size_t)N * K;
+        planes[o] = (unsigned short)(h & 0xffffu);
+        planes[P + o] = (unsigned short)(m & 0xffffu);
+        planes[2 * P + o] = (unsigned short)(l & 0xffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the GEMM
+template <int BM, int BN, int WGM, int WGN, int NBUF, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kernel(
+    const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
+    const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
+    constexpr int BK = 32;
+    constexpr int NTHREADS = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int NIA = BM * 4 / NTHREADS, NIB = BN * 4 / NTHREADS;   // (row, 8-k chunk) items per thread
+    constexpr int A_PLANE = BM * 4, B_PLANE = BN * 4;                 // uint4 units (a row = 4 chunks of 16 bytes)
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+    constexpr int D = NBUF - 1;                                       // k-tiles between the LDS store and its use
+    static_assert(NIA >= 1 && NIB >= 1 && NIA <= 2 && NIB <= 2 && TM >= 1 && TN >= 1 && (NBUF == 2 || NBUF == 3), "tile");
+    __shared__ u32x4s lds[NBUF * STAGE];
+
+    // XCD-aware grouped tile order (gemm_f32_kc.hip)
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = g.K / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging coordinates: item idx = tid + i * NTHREADS -> row = idx >> 2, chunk = idx & 3
+    int a_off[NIA], b_off[NIB], a_dst[NIA], b_dst[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
+        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + c * 8) * 4;
+        a_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
+        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * 2;
+        b_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
+
+    u32x4s ra[NIA][2], rb[NIB][3];                                    // staging registers (fully unrolled indices only)
+#define S3_LOAD(KT)                                                                                \
+    {                                                                                              \
+        const int kt_ = min((KT), nkt - 1);                                                        \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
+            ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
+            ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                          \
+                rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+    }
+#define S3_STORE(STG)                                                                              \
+    {                                                                                              \
+        u32x4s* sa_ = lds + (STG) * STAGE;                                                         \
+        u32x4s* sb_ = sa_ + 3 * A_PLANE;                                                           \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
+            u32x4s h_, m_, l_;                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+                /* (cast the WHOLE vector: __builtin_bit_cast on an ext-vector element reads element 0) */ \
+                const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[i][q >> 1]);                     \
+                const float x0_ = src_[(q & 1) * 2], x1_ = src_[(q & 1) * 2 + 1];                  \
+                unsigned hh_, mm_, ll_;                                                            \
+                split3_pair(x0_, x1_, hh_, mm_, ll_);                                              \
+                h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                             \
+            }                                                                                      \
+            sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = m_; sa_[2 * A_PLANE + a_dst[i]] = l_;    \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[i][p];  \
+    }
+
+    // fragment addresses: lane (li, lh), k-step s -> chunk 2s + lh of row li (+ 32 per tile)
+    const int fq = (li >> 2) & 3;
+    const int f_off0 = li * 4 + ((0 + lh) ^ fq), f_off1 = li * 4 + ((2 + lh) ^ fq);
+    const int fa_base = wm * WM * 4, fb_base = 3 * A_PLANE + wn * WN * 4;
+
+    f32x16s acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define S3_MFMA(A_, B_, I_, J_) \
+    acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
+#define S3_COMPUTE(STG)                                                                            \
+    {                                                                                              \
+        const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
+            const int fo_ = s ? f_off1 : f_off0;                                                   \
+            u32x4s fa_[TM][3], fb_[TN][3];                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) fa_[i][p] = st_[fa_base + p * A_PLANE + i * 128 + fo_]; \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) fb_[j][p] = st_[fb_base + p * B_PLANE + j * 128 + fo_]; \
+            /* smallest partial products first; consecutive MFMAs go to different accumulators */  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][2], fb_[j][0], i, j); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][2], i, j); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][1], fb_[j][1], i, j); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][1], fb_[j][0], i, j); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][1], i, j); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][0], i, j); \
+        }                                                                                          \
+    }
+
+    // prologue: k-tiles 0 .. D-1 into their stages, k-tile D into the staging registers
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+        S3_LOAD(t)
+        S3_STORE(t)
+    }
+    S3_LOAD(D)
+    __syncthreads();
+
+    // iteration kt: registers (k-tile kt+D) -> stage (kt+D) % NBUF [last read in iteration kt-1, all waves are past
+    // its barrier]; loads of k-tile kt+D+1 (in flight for a whole iteration); MFMAs on stage kt % NBUF; barrier.
+#define S3_ITER(CUR, WR)                                                                           \
+    {                                                                                              \
+        S3_STORE(WR)                                                                               \
+        S3_LOAD(kt + D + 1)                                                                        \
+        S3_COMPUTE(CUR)                                                                            \
+        __syncthreads();                                                                           \
+    }
+    int kt = 0;
+    if constexpr (NBUF == 2) {
+        for (; kt + 1 < nkt; kt += 2) {
+            S3_ITER(0, 1)
+            { ++kt; S3_ITER(1, 0) }
+            --kt;
+        }
+        if (kt < nkt) S3_ITER(0, 1)
+    } else {
+        for (; kt + 2 < nkt; kt += 3) {                               // compile-time stages
+            S3_ITER(0, 2)
+            { ++kt; S3_ITER(1, 0) }
+            { ++kt; S3_ITER(2, 1) }
+            kt -= 2;
+        }
+        int cur = 0, wr = 2;                                          // kt is a multiple of 3 here: 0..2 k-tiles left
+        for (; kt < nkt; ++kt) {
+            S3_ITER(cur, wr)
+            cur = cur == 2 ? 0 : cur + 1;
+            wr = wr == 2 ? 0 : wr + 1;
+        }
+    }
+#undef S3_ITER
+#undef S3_COMPUTE
+#undef S3_MFMA
+#undef S3_STORE
+#undef S3_LOAD
+
+    // epilogue: the one of gemm_f32_kc.hip (C/D layout is dtype-independent: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    float* __restrict__ C = Cg;
+    const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
+    if (interior) {
+        const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
+        const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float res[16];
+                if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
+                }
+#pragma unroll
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
+                    if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
+                    else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = r2 + h2;
+                        const float v = h2 ? v2.y : v2.x;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
+                                                              ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                                   // edge tiles: clamped reads, guarded stores
+        const int col = n0 + wn * WN + j * 32 + li;
+        const bool col_ok = col < g.N;
+        const int colc = min(col, g.N - 1);
+        const float bias = biasg ? biasg[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float res[16];
+            if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    res[r] = residg[(long long)row * g.ldr + colc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias;
+                if (EPI == EPI_GELU) v = gelu_new_s3_1(v);
+                else if (EPI == EPI_RESIDUAL) v += res[r];
+                if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct S3Tile { int bm, bn, cls; double eff; };
+static const S3Tile kS3[] = {
+    {128, 256, PK_GEMM_S3_128x256, 1.0},
+    {128, 128, PK_GEMM_S3_128x128, 0.9},
+};
+constexpr int kNumS3 = 2;
+
+template <int BM, int BN, int WGM, int WGN, int NBUF>
+static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
+    S3Shape sh;
+    sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
+#define S3_LAUNCH_(E)                                                                              \
+    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WGM, WGN, NBUF, E>), dim3(tiles), dim3(64 * WGM * WGN), 0, stream, a.A, \
+                       a.planes, a.C, a.bias, a.resid, sh)
+    switch (a.epilogue) {
+        case EPI_NONE: S3_LAUNCH_(EPI_NONE); break;
+        case EPI_GELU: S3_LAUNCH_(EPI_GELU); break;
+        case EPI_RESIDUAL: S3_LAUNCH_(EPI_RESIDUAL); break;
+        default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
+    }
+#undef S3_LAUNCH_
+    R4D_CHECK_LAUNCH("gemm_s3");
+    return R4D_OK;
+}
+
+static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
+    switch (t) {
+        case 0: return launch_s3<128, 256, 2, 4, 2>(a, kS3[0].cls, stream);
+        default: return launch_s3<128, 128, 2, 4, 3>(a, kS3[1].cls, stream);
+    }
+}
+
+bool gemm_s3_supported(int M, int K, int N) {
+    return M >= 1 && K >= 32 && K % 32 == 0 && N >= 1 && (long long)N * K * 6 < (1ll << 31) && (long long)M * K < (1ll << 29) &&
+           128ll * N < (1ll << 29);
+}
+
+int launch_gemm_s3(const S3Args& a, hipStream_t stream) {
+    R4D_REQUIRE(a.A && a.planes && a.C, "gemm_s3: null pointer");
+    R4D_REQUIRE(gemm_s3_supported(a.M, a.K, a.N), "gemm_s3: unsupported shape M=%d K=%d N=%d (K %% 32 == 0 wanted)", a.M, a.K, a.N);
+    R4D_REQUIRE(a.lda % 4 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_s3: alignment");
+    R4D_REQUIRE(a.epilogue != EPI_RESIDUAL || a.resid, "gemm_s3: residual epilogue needs the residual");
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("R4D_GEMM_S3_TILE"); forced = e ? atoi(e) : -1; }
+    if (forced >= 0 && forced < kNumS3) return s3_launch_tile(a, forced, stream);
+    int best = 0;
+    double best_cost = 1e300;
+    for (int t = 0; t < kNumS3; ++t) {
+        const long long blocks = (long long)cdiv(a.M, kS3[t].bm) * cdiv(a.N, kS3[t].bn);
+        const double cost = (double)((blocks + 255) / 256) * kS3[t].bm * kS3[t].bn / kS3[t].eff;
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return s3_launch_tile(a, best, stream);
+}
+
+int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s) {
+    R4D_REQUIRE(w && planes && N >= 1 && K >= 1, "split3_planes: bad arguments");
+    R4D_REQUIRE(ld_n == 1 || ld_k == 1, "split3_planes: one of the two strides must be 1");
+    hipLaunchKernelGGL(split3_planes_kernel, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(256), 0, s, w, N, K, ld_k, ld_n, planes);
+    R4D_CHECK_LAUNCH("split3_planes");
+    return R4D_OK;
+}
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" {
+
+int r4d_split3_planes_bf16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream) {
+    // transposed == 0: w_d is the reference Conv1D layout [K,N] (in, out); != 0: w_d is [N,K]
+    return launch_split3_planes(w_d, N, K, transposed ? 1 : N, transposed ? K : 1, planes_d, (hipStream_t)stream);
+}
+
+int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d, int32_t M,
+                      int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream) {
+    R4D_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv1d_s3: epilogue %d not in {0,1,2}", epilogue);
+    S3Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = x_d; a.planes = planes_d; a.C = y_d; a.bias = bias_d; a.resid = residual_d;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
+    return launch_gemm_s3(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

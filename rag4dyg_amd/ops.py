@@ -59,6 +59,33 @@ def conv1d(x, w, bias, epilogue="none", residual=None, w_t=None):
     return y
 
 
+def split3_planes(w, transposed=False):
+    """Static Conv1D weight [K,N] (``transposed``: an [N,K] copy) -> its three k-contiguous bf16 planes (hi, mid, lo),
+    a uint16 tensor [3,N,K] (torch's bfloat16 bit patterns): the operand format of :func:`conv1d_s3`."""
+    if transposed:
+        N, K = w.shape
+    else:
+        K, N = w.shape
+    planes = torch.empty(3, N, K, dtype=torch.int16, device=w.device)
+    check(_lib.load().r4d_split3_planes_bf16(_dev(w, torch.float32, "w"), K, N, int(bool(transposed)), planes.data_ptr(),
+                                             _stream()), "split3_planes")
+    return planes
+
+
+def conv1d_s3(x, planes, bias, epilogue="none", residual=None):
+    """:func:`conv1d` on the bf16 matrix cores at fp32 accuracy (three-way bf16 split of both operands, six partial
+    products, fp32 accumulation); ``planes`` from :func:`split3_planes`."""
+    _, N, K = planes.shape
+    M = x.numel() // K
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
+    rp = _dev(residual, torch.float32, "residual") if residual is not None else None
+    bp = _dev(bias, torch.float32, "bias") if bias is not None else None
+    check(_lib.load().r4d_conv1d_s3_f32(_dev(x, torch.float32, "x"), _dev(planes, torch.int16, "planes"), bp, rp, M, K, N, epi,
+                                        y.data_ptr(), _stream()), "conv1d_s3")
+    return y
+
+
 def set_attention_fused(mode):
     """-1 / None: auto by head_dim (default); True: fused flash-style kernel; False: three-launch GEMM form."""
     _lib.load().r4d_set_attention_fused(-1 if mode is None or mode == -1 else (2 if mode == 2 else int(bool(mode))))
