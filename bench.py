@@ -37,6 +37,9 @@ from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG    # noqa: E402
 from rag4dyg_amd.retrieval import PoolIndex, encode_batches, right_pad_batches   # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: dense bf16 matrix peak (the 2:1-sparsity figure is not used)
+# the bf16x3 GEMM spends SIX bf16 products per fp32 product: its ceiling in fp32-equivalent flop is the bf16 peak / 6
+PEAK_S3_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 PEAK_HBM_GBS = 8000.0
 QB = 32                          # per_gpu_eval_batch_size, utils/args_parser_retriever.py:225
 
@@ -46,6 +49,10 @@ def build_model(shape, device):
     cfg = GPT2Config(vocab_size=shape.vocab, n_positions=1024, n_ctx=1024, n_embd=shape.n_embd,
                      n_layer=shape.n_layer, n_head=shape.n_head)
     return GPT2LMHeadModelRAG(cfg).to(device).eval()
+
+
+def mfma_peak(kernel):
+    return PEAK_S3_TFLOPS if kernel.startswith("gemm_s3") else PEAK_F32_MFMA_TFLOPS
 
 
 def f_enc(shape, B, T):
@@ -78,20 +85,22 @@ def host_cores():
     return n
 
 
-def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
+def cpu_baseline(model, shape, query_seqs, pool_emb, k, first_batches=(), budget_s=12.0):
     """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample.  Like the reference
     (train_retriever.py:419: ``_, h = model(input_ids)`` computes lm_logits and throws them away) the forward INCLUDES
-    the lm_head GEMM; the rate without it is reported beside it."""
+    the lm_head GEMM; the rate without it is reported beside it.  ``first_batches``: indices of the query batches to take
+    first (the LAST timed step's): their oracle scores and stable top-k are returned for the in-run verification."""
     from oracle import gpt2_ref, retrieval_ref
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
     pool = pool_emb.cpu()
     torch.set_num_threads(host_cores())
+    nqb = len(query_seqs) // QB
+    order = list(first_batches) + [b for b in range(nqb) if b not in set(first_batches)]
     done, t0 = 0, time.perf_counter()
     nb, t_head = 0, 0.0
-    while True:
-        chunk = query_seqs[nb * QB:(nb + 1) * QB]
-        if not chunk:
-            break
+    kept = {}
+    for bi in order:
+        chunk = query_seqs[bi * QB:(bi + 1) * QB]
         b = retrieval_ref.right_pad_batches(chunk, QB, shape.pad_id)
         embs = []
         for ids in b:                                               # retrieval_ref.encode_batches + the discarded lm_head
@@ -102,17 +111,49 @@ def cpu_baseline(model, shape, query_seqs, pool_emb, k, budget_s=12.0):
                 t_head += time.perf_counter() - th
             embs.append(out["hidden"].mean(dim=1))
         S = retrieval_ref.score_batch(torch.cat(embs), pool).numpy()
-        retrieval_ref.topk_stable(S, k)
+        top = retrieval_ref.topk_stable(S, k)
+        if bi in first_batches:
+            kept[bi] = (S, top[1])
         done += len(chunk)
         nb += 1
-        if time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t0 > budget_s and nb >= len(first_batches):
             break
     el = time.perf_counter() - t0
     return {"value": round(done / el, 2), "unit": "query-seqs/s", "cores": torch.get_num_threads(), "kind": "port",
             "value_without_lm_head": round(done / (el - t_head), 2),
             "sample": f"{nb} query batches of {QB} (same synthetic {shape.name}-shape inputs, same resident pool of "
                       f"{pool.shape[0]} rows), oracle torch-CPU fp32 encode INCLUDING the lm_head GEMM the reference computes "
-                      f"and discards + score + stable top-{k}, {el:.1f} s"}
+                      f"and discards + score + stable top-{k}, {el:.1f} s"}, kept
+
+
+def verify_one_gpu(kept, first_batches, last_out, model, q_batches, index, k):
+    """N = 1, after the timed region: the LAST timed step's ranked top-k against the oracle's stable top-k of the same
+    queries (the CPU baseline computes them anyway): fraction of rows whose whole list is identical and the largest ORACLE
+    score gap at any mismatching position (tests/conftest.rank_mismatch_report semantics; pass = gap <= 2e-6); plus the two
+    device scoring paths against each other: the HBM-bound scan (32 queries per call) and the MFMA-bound GEMM (256 per call)."""
+    S = np.concatenate([kept[b][0] for b in first_batches]).astype(np.float64)
+    ref_idx = np.concatenate([np.asarray(kept[b][1]) for b in first_batches]).astype(np.int64)
+    got_idx = last_out[1].cpu().numpy()
+    got_val = last_out[0].cpu().numpy().astype(np.float64)
+    same = ref_idx == got_idx
+    gap = 0.0
+    for r, c in zip(*np.nonzero(~same)):
+        gap = max(gap, abs(S[r, ref_idx[r, c]] - S[r, got_idx[r, c]]))
+    ref_val = np.take_along_axis(S, ref_idx, axis=1)
+    emb = model.encode_groups_meanpool([q_batches[b] for b in first_batches])
+    q_hat = ops.normalize_rows(emb)
+    v_gemm, i_gemm, _ = ops.score_topk(q_hat, index.pool_hat, k, index.index_offset)
+    parts = [ops.score_topk(q_hat[j:j + QB], index.pool_hat, k, index.index_offset) for j in range(0, q_hat.shape[0], QB)]
+    i_scan = torch.cat([p_[1] for p_ in parts])
+    v_scan = torch.cat([p_[0] for p_ in parts])
+    scan_gap = float((v_scan - v_gemm).abs().max())
+    return {"queries": int(ref_idx.shape[0]), "pool_rows": int(S.shape[1]), "topk": k,
+            "rows_identical_to_oracle": round(float(same.all(axis=1).mean()), 4),
+            "max_oracle_score_gap_at_mismatch": gap, "pass": bool(gap <= 2e-6),
+            "max_abs_score_err_vs_oracle": float(np.abs(got_val - ref_val).max()),
+            "timed_step_equals_recomputation": bool(torch.equal(i_gemm, last_out[1]) and torch.equal(v_gemm, last_out[0])),
+            "scan_path_rows_identical_to_gemm_path": round(float((i_scan == i_gemm).all(dim=1).float().mean()), 4),
+            "scan_vs_gemm_max_abs_score_diff": scan_gap}
 
 
 def verify_sharded(world, rank, device, index, last_out, model, q_batches, args, G, k, gather, elapsed_local):
@@ -145,7 +186,29 @@ def verify_sharded(world, rank, device, index, last_out, model, q_batches, args,
         print(f"[bench] VERIFY FAILED: sharded top-k differs from the one-GPU recomputation on ranks {[r for r, o in enumerate(oks) if not o]}",
               file=sys.stderr)
     ms = [1e3 * t_ / args.steps for t_ in times]
-    return {"world_size": world, "devices": sorted({d[1] for d in dev_ids}), "device_names": sorted({d[2] for d in dev_ids}),
+    # the step's two collectives on their own, HIP-event timed on this rank (embeddings: Q*d*4 B per rank; candidates: Q*k*12 B)
+    coll = {}
+    try:
+        cand_v = torch.zeros(q_all.shape[0], k, dtype=torch.float32, device=device)
+        cand_i = torch.zeros(q_all.shape[0], k, dtype=torch.int64, device=device)
+        q_loc = q_all[:q_all.shape[0] // world].contiguous()
+        for name, fn in (("all_gather_embeddings_us", lambda: gather(q_loc)),
+                         ("all_gather_candidates_us", lambda: (gather(cand_v), gather(cand_i)))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            coll[name] = round(e0.elapsed_time(e1) * 1e3 / 20, 1)
+        coll["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        coll["backend"] = dist.get_backend()
+    except Exception as e:                                           # noqa: BLE001
+        coll["error"] = f"{type(e).__name__}: {e}"
+    return {"world_size": world, "collectives": coll, "devices": sorted({d[1] for d in dev_ids}), "device_names": sorted({d[2] for d in dev_ids}),
             "sharded_topk_equals_one_gpu": ok, "pool_rows_checked": int(sum(all_rows)),
             "per_rank_ms_per_step": [round(x, 3) for x in ms],
             "rank_spread": round((max(ms) - min(ms)) / max(ms), 4)}
@@ -181,18 +244,26 @@ def scan_q32(index, shape, k, device, reps=50):
     prof = read_profile()
     lib.r4d_profile_enable(0)
     sc, tk = prof["pool_scan"], prof.get("topk", {"ms": 0.0, "launches": 1})
-    gbs = sc["work"] / (sc["ms"] * 1e-3) / 1e9
+    n_rows = int(index.pool_hat.shape[0])
+    scan_s, topk_s = sc["ms"] * 1e-3 / sc["launches"], tk["ms"] * 1e-3 / sc["launches"]
+    b_survey = 4.0 * n_rows * shape.n_embd + 4.0 * QB * shape.n_embd + 8.0 * QB * k       # B_score
+    b_moved = sc["work"] / sc["launches"]                                                 # + the [Q,N] score rows the kernel writes
+    gbs = b_moved / scan_s / 1e9
     traffic = None                                    # PMC bytes of a separate rocprofv3 pass on the same sources and size, else null
     tf = os.path.join(REPO, "profiles", "pmc_scan.json")
     if os.path.exists(tf):
         pmc = json.load(open(tf))
         if pmc.get("_workload", {}).get("source_sha") == source_sha():
-            traffic = pmc.get(f"{int(index.pool_hat.shape[0])}x{shape.n_embd}", {}).get("hbm_bytes_per_launch")
-    return {"pool_rows": int(index.pool_hat.shape[0]), "d": shape.n_embd, "queries": QB, "topk": k,
-            "scan_kernel_us": round(1e3 * sc["ms"] / sc["launches"], 2), "topk_kernel_us": round(1e3 * tk["ms"] / sc["launches"], 2),
-            "host_loop_wall_us": round(wall * 1e6, 1), "algorithmic_bytes": sc["work"] / sc["launches"],
-            "roofline": {"kernel": "pool_scan", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic}}
+            traffic = pmc.get(f"{n_rows}x{shape.n_embd}", {}).get("hbm_bytes_per_launch")
+    return {"pool_rows": n_rows, "d": shape.n_embd, "queries": QB, "topk": k,
+            "scan_kernel_us": round(scan_s * 1e6, 2), "topk_kernel_us": round(topk_s * 1e6, 2),
+            "host_loop_wall_us": round(wall * 1e6, 1), "algorithmic_bytes": b_survey, "bytes_moved": b_moved,
+            "roofline": {"kernel": "pool_scan", "bound": "hbm", "achieved": round(b_survey / scan_s / 1e9, 1), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(b_survey / scan_s / 1e9 / PEAK_HBM_GBS, 4),
+                         "frac_survey": round(b_survey / scan_s / 1e9 / PEAK_HBM_GBS, 4),       # SURVEY's B_score / scan kernel time
+                         "frac_moved": round(gbs / PEAK_HBM_GBS, 4),                            # incl. the score rows written
+                         "frac_scan_plus_topk": round(b_survey / (scan_s + topk_s) / 1e9 / PEAK_HBM_GBS, 4),
+                         "traffic": traffic}}
 
 
 def main():
@@ -210,14 +281,27 @@ def main():
                          "as one fused launch sequence")
     ap.add_argument("--query-batches", type=int, default=256,
                     help="distinct synthetic query batches cycled over the steps (256 x 32 = the 8192 queries of SURVEY 8d)")
+    ap.add_argument("--gemm", default="split3", choices=["split3", "f32"],
+                    help="split3 (default): the encoder GEMMs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, six "
+                         "products, fp32 accumulate; acceptance table: profiles/r03_s3_acceptance.md); f32: the exact-f32 MFMA kernels")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (the metric's form): every rank encodes --batches-per-step batches per step; strong: the SAME "
+                         "64 batches (2048 queries) per step split over the ranks, so total work is fixed as N grows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-pool", action="store_true",
                     help="profiling aid: fill the resident pool shard with N(0,1) embeddings instead of encoding the "
                          "synthetic pool, so that a rocprofv3 trace holds the timed-step kernels only")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-bucketed", action="store_true", help="skip the length-bucketed second run (extras.length_bucketed)")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the second timed run on the exact-f32 MFMA kernels (extras.exact_f32)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling aid: warm-up + timed steps and nothing else, so that a rocprofv3 --kernel-trace --stats of this "
+                         "command averages the headline launches only")
     ap.add_argument("--no-verify", action="store_true",
                     help="N > 1: skip the post-run check that the sharded top-k equals a one-GPU recomputation on rank 0")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_roofline = args.no_bucketed = args.no_exact_f32 = args.no_cpu_baseline = args.no_verify = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +320,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     _lib.load()
+    ops.set_gemm_split3(args.gemm == "split3")
 
     shape = synth.SHAPES[args.shape]
     model = build_model(shape, device)
@@ -273,6 +358,10 @@ def main():
     q_batches = right_pad_batches(q_seqs, QB, shape.pad_id, device)
 
     G = args.batches_per_step
+    if args.scaling == "strong":
+        if 64 % world:
+            raise SystemExit("--scaling strong splits 64 batches per step over the ranks: N must divide 64")
+        G = 64 // world
     nqb = len(q_batches)
 
     if world > 1 and backend != "nccl":
@@ -332,28 +421,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    tail = drain()                                                   # the last two steps' results: inside the timed region
-    if tail:
-        out = tail[-1]
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed_local = elapsed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert out[1].shape == (QB * G * world, k)
+    def timed_run():
+        for i in range(args.warmup):
+            step(i)
+        drain()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out_ = step(i)
+        tail = drain()                                               # the last two steps' results: inside the timed region
+        if tail:
+            out_ = tail[-1]
+        sync()
+        el = time.perf_counter() - t0
+        el_local = el
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert out_[1].shape == (QB * G * world, k)
+        return out_, el, el_local
 
-    # --- roofline: the same K steps again with per-launch HIP events on the launch stream
-    roofline, kernels = None, {}
-    if not args.no_roofline:
+    def roofline_run():
+        """The same K steps again with per-launch HIP events on the launch stream (r4d_profile hooks)."""
         lib = _lib.load()
         lib.r4d_profile_enable(1)
         for i in range(args.steps):
@@ -362,16 +452,17 @@ def main():
         torch.cuda.synchronize()
         prof = read_profile()
         lib.r4d_profile_enable(0)
+        kernels_ = {}
         tot_ms = sum(v["ms"] for v in prof.values())
         for name, v in prof.items():
             is_mfma = name.startswith(("gemm", "attn"))
             rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
-            kernels[name] = {"share": round(v["ms"] / tot_ms, 4), "launches": v["launches"],
-                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
-                             ("TFLOP/s" if is_mfma else "GB/s"): round(rate / (1e12 if is_mfma else 1e9), 2)}
+            kernels_[name] = {"share": round(v["ms"] / tot_ms, 4), "launches": v["launches"],
+                              "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                              ("TFLOP/s" if is_mfma else "GB/s"): round(rate / (1e12 if is_mfma else 1e9), 2)}
         dom = max(prof, key=lambda n: prof[n]["ms"])
         v = prof[dom]
-        traffic = None
+        traffic, util = None, None
         tf = os.path.join(REPO, "profiles", f"pmc_traffic_{args.shape}.json")
         if not os.path.exists(tf):
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -379,20 +470,51 @@ def main():
             pmc = json.load(open(tf))       # it was profiled on only -- otherwise null
             meta = pmc.get("_workload", {})
             if (meta.get("shape") == args.shape and meta.get("batches_per_step") == G and meta.get("n_gpus", 1) == world
-                    and meta.get("pool_rows_per_gpu") == P and meta.get("source_sha") == source_sha()):
+                    and meta.get("pool_rows_per_gpu") == P and meta.get("source_sha") == source_sha()
+                    and meta.get("gemm", "f32") == ("split3" if ops.gemm_split3_enabled() else "f32")):
                 traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+                util = pmc.get(dom, {}).get("mfma_pipe_util")
         if dom.startswith(("gemm", "attn")):
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                        "flop_per_launch": v["work"] / v["launches"]}
+            peak = mfma_peak(dom)
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                    "flop_per_launch": v["work"] / v["launches"]}
+            if dom.startswith("gemm_s3"):
+                roof["peak_note"] = ("fp32-equivalent flop; bf16x3: six v_mfma_f32_32x32x16_bf16 products per fp32 product, "
+                                     "so the ceiling is the dense bf16 MFMA peak (2500 TFLOP/s) / 6")
+                roof["x_exact_f32_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
+            if util is not None:
+                roof["mfma_pipe_busy_pmc"] = round(util, 4)
         else:
             ach = v["work"] / (v["ms"] * 1e-3) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                        "bytes_per_launch": v["work"] / v["launches"]}
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                    "bytes_per_launch": v["work"] / v["launches"]}
+        return roof, kernels_
+
+    out, elapsed, elapsed_local = timed_run()
+
+    roofline, kernels = None, {}
+    if not args.no_roofline:
+        roofline, kernels = roofline_run()
+
+    # --- N = 1: the same timed region once more on the exact-f32 MFMA kernels (the line the bf16x3 headline is read against)
+    exact = None
+    if world == 1 and args.gemm == "split3" and not args.no_exact_f32:
+        ops.set_gemm_split3(False)
+        model.transformer.__dict__.pop("_w3_cache", None)
+        out_f, el_f, _ = timed_run()
+        roof_f, kern_f = roofline_run() if not args.no_roofline else (None, {})
+        same = (out_f[1] == out[1]).all(dim=1).float().mean()
+        exact = {"dtype": "f32", "value": round(QB * G * args.steps / el_f, 2), "unit": "query-seqs/s",
+                 "ms_per_step": round(1e3 * el_f / args.steps, 4), "roofline": roof_f,
+                 "dominant_kernel_share": kern_f.get(roof_f["kernel"], {}).get("share") if roof_f else None,
+                 "top10_rows_identical_to_split3": round(float(same), 4),
+                 "max_abs_score_diff_vs_split3": float((out_f[0] - out[0]).abs().max())}
+        ops.set_gemm_split3(True)
 
     # --- N > 1: correctness bit + load spread, outside the timed region (never allowed to lose the run)
     verify = None
@@ -408,7 +530,7 @@ def main():
     # batches of 32, so a batch pads to similar lengths.  NOT parity-comparable with the reference (an embedding is a mean
     # over its batch's padded positions) and never the headline value: it shows what the reference's file-order batching costs.
     bucketed = None
-    if world == 1 and rank == 0 and not args.no_roofline:
+    if world == 1 and rank == 0 and not args.no_roofline and not args.no_bucketed:
         order = sorted(range(len(q_seqs)), key=lambda j: len(q_seqs[j]))
         b_batches = right_pad_batches([q_seqs[j] for j in order], QB, shape.pad_id, device)
         nb = len(b_batches)
@@ -432,7 +554,16 @@ def main():
                             "batches (mean over padded positions), reported beside the headline value only"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(model, shape, [s.tolist() for s in q_seqs], pool_emb, k)
+        last = [((args.steps - 1) * G + j) % nqb for j in range(G)]     # the query batches of the last timed step
+        first = last if not args.no_verify and len(set(last)) == G else []
+        cpu, kept = cpu_baseline(model, shape, [s.tolist() for s in q_seqs], pool_emb, k, first_batches=first)
+        if first:
+            try:
+                verify = verify_one_gpu(kept, first, out, model, q_batches, index, k)
+                if not verify["pass"]:
+                    print(f"[bench] VERIFY FAILED: top-{k} differs from the oracle beyond fp32 noise: {verify}", file=sys.stderr)
+            except Exception as e:                                   # noqa: BLE001 -- never lose the run to the check
+                verify = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         Ts = [int(b.shape[1]) for b in q_batches]
@@ -444,10 +575,10 @@ def main():
             "unit": "query-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32 (bf16x3 operands, f32 accumulate)" if args.gemm == "split3" else "f32", "data": "synthetic",
             "config": {"workload": f"{shape.name}-shape synthetic sequences, SimpleDyG GPT-2 L{shape.n_layer} H{shape.n_head} "
-                                   f"d{shape.n_embd} V{shape.vocab} random-init fp32; per rank and step {G} reference query batches of {QB} "
+                                   f"d{shape.n_embd} V{shape.vocab} random-init fp32 weights and activations; per rank and step {G} reference query batches of {QB} "
                                    f"(each padded to its own batch max, mean T={np.mean(Ts):.0f}; one fused launch sequence) "
                                    f"encode+mean-pool+normalise, cosine scan of a "
                                    f"resident {P}-row shard of the {pool_total}-row pool, top-{k}; N>1: RCCL all-gather of embeddings "
@@ -459,7 +590,8 @@ def main():
                                        "async, consumed one step later (3-stage pipeline)" if pipe is not None else "synchronous")},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "extras": {"source_sha": source_sha(), "scan_q32": scan, "verify": verify, "length_bucketed": bucketed,
+            "extras": {"source_sha": source_sha(), "gemm": args.gemm, "exact_f32": exact, "scan_q32": scan, "verify": verify,
+                       "length_bucketed": bucketed,
                        "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),
                        "kernels": kernels},

@@ -34,7 +34,7 @@ extern "C" {
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
 /* 0 for a product build.  Non-zero when the library was compiled with one of the kernel-ablation macros of
- * tools/kc_ablate.sh (bit 0 KC_DBG, bit 1 ATT_DBG, bit 2 SK_DBG, bit 3 JAC_DBG, bit 4 SCAN_DBG): such a build
+ * tools/kc_ablate.sh (bit 0 KC_DBG, bit 1 ATT_DBG, bit 2 SK_DBG, bit 3 JAC_DBG, bit 4 SCAN_DBG, bit 5 S3_DBG): such a build
  * computes WRONG results by construction and the Python binding refuses to load it outside tools/. */
 int r4d_build_flags(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -68,6 +68,12 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * k-contiguous and the faster b128-LDS kernel runs (same values up to fp32 summation order). */
     const float* c_attn_wT;   const float* attn_proj_wT;  /* [3d,d], [d,d]  */
     const float* c_fc_wT;     const float* mlp_proj_wT;   /* [4d,d], [d,4d] */
+    /* OPTIONAL bf16x3 planes of the same four weights (r4d_split3_planes_bf16: uint16 [3][out][in], hi / mid / lo), made
+     * once per checkpoint; NULL = not provided.  With them (and r4d_set_gemm_split3 != 0, the default) the four Conv1D
+     * GEMMs of a block run on the bf16 matrix cores at fp32 accuracy (r4d_conv1d_s3_f32) in the encoder calls (the cached
+     * decode step keeps its weight-stream kernels); everything else about the call is unchanged. */
+    const uint16_t* c_attn_w3;  const uint16_t* attn_proj_w3;
+    const uint16_t* c_fc_w3;    const uint16_t* mlp_proj_w3;
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
@@ -227,6 +233,10 @@ int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d /* opt
 int r4d_split3_planes_bf16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream);
 int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d,
                       int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
+/* 1 (default): the encoder / training-forward GEMMs use the bf16x3 kernel where a layer carries its planes; 0: exact-f32 MFMA
+ * kernels everywhere (the planes are ignored).  Process-wide, not thread-safe against concurrent calls. */
+int r4d_set_gemm_split3(int32_t mode);
+int r4d_get_gemm_split3(void);
 /* Causal multi-head attention on packed c_attn output qkv_d [B,T,3d] -> a_d [B,T,d] (heads merged).
  * Attention._attn + split/merge_heads, modeling_gpt2.py:140-175; scale = division by sqrt(hd) (:143).
  * scores_ws_d: device scratch of r4d_attention_workspace_bytes(B,H,T). */

@@ -24,7 +24,8 @@ class GPT2ConfigC(Structure):
 class GPT2LayerC(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_1_w", "ln_1_b", "c_attn_w", "c_attn_b", "attn_proj_w", "attn_proj_b",
                                          "ln_2_w", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b",
-                                         "c_attn_wT", "attn_proj_wT", "c_fc_wT", "mlp_proj_wT")]
+                                         "c_attn_wT", "attn_proj_wT", "c_fc_wT", "mlp_proj_wT",
+                                         "c_attn_w3", "attn_proj_w3", "c_fc_w3", "mlp_proj_w3")]
 
 
 class GreedyStateC(Structure):
@@ -81,6 +82,8 @@ PROTOTYPES = {
     "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_split3_planes_bf16": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_conv1d_s3_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_set_gemm_split3": (c_int32, [c_int32]),
+    "r4d_get_gemm_split3": (c_int32, []),
     "r4d_attention_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_attention_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_normalize_rows_f32": (c_int32, [_P, c_int32, c_int32, _P, _P]),

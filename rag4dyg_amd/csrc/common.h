@@ -10,7 +10,7 @@ namespace r4d {
 
 void set_error(const char* fmt, ...);
 // 1 when the translation unit was built with its kernel-ablation macro set (tools/kc_ablate.sh): r4d_build_flags()
-int dbgflag_kc(); int dbgflag_att(); int dbgflag_sk(); int dbgflag_jac(); int dbgflag_scan();
+int dbgflag_kc(); int dbgflag_att(); int dbgflag_sk(); int dbgflag_jac(); int dbgflag_scan(); int dbgflag_s3();
 
 #define R4D_REQUIRE(cond, ...)                     \
     do {                                           \
@@ -102,6 +102,12 @@ struct S3Args {
 bool gemm_s3_supported(int M, int K, int N);
 int launch_gemm_s3(const S3Args& a, hipStream_t stream);
 // w element (n, k) at w[k * ld_k + n * ld_n] -> planes [3][N][K] bf16 (hi, mid, lo)
+extern int g_gemm_split3;             // 1: layers that carry bf16x3 planes use them (r4d_set_gemm_split3)
+// Conv1D dispatch shared by the encoder and the training forward (encoder.hip): skinny weight stream (decode), bf16x3 planes,
+// k-contiguous copy, reference layout -- in that order of preference
+int conv1d(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K, int N,
+           int epilogue, float* y, hipStream_t s, float* skinny_scratch = nullptr, bool sk_counters_zeroed = false,
+           const unsigned short* w3 = nullptr);
 int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s);
 
 // ------------------------------------------------------------------ train_ops.hip

@@ -24,6 +24,10 @@
 #include <string.h>
 #include "common.h"
 
+#ifndef S3_DBG
+#define S3_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 4 only the split arithmetic
+#endif
+
 namespace r4d {
 
 typedef float f32x16s __attribute__((ext_vector_type(16)));
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
                 const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[i][q >> 1]);                     \
                 const float x0_ = src_[(q & 1) * 2], x1_ = src_[(q & 1) * 2 + 1];                  \
                 unsigned hh_, mm_, ll_;                                                            \
-                split3_pair(x0_, x1_, hh_, mm_, ll_);                                              \
+                if (S3_DBG & 16) { hh_ = __builtin_bit_cast(unsigned, x0_); mm_ = __builtin_bit_cast(unsigned, x1_); ll_ = hh_ ^ mm_; } \
+                else split3_pair(x0_, x1_, hh_, mm_, ll_);                                         \
                 h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                             \
             }                                                                                      \
             sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = m_; sa_[2 * A_PLANE + a_dst[i]] = l_;    \
@@ -191,26 +196,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 
 #define S3_MFMA(A_, B_, I_, J_) \
     acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
-#define S3_COMPUTE(STG)                                                                            \
+    // fragment registers, two sets: the reads of k-step s+1 travel under the MFMAs of k-step s
+    u32x4s fa[2][TM][3], fb[2][TN][3];
+#define S3_FRAGS(SET, STG, S)                                                                      \
     {                                                                                              \
         const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
-            const int fo_ = s ? f_off1 : f_off0;                                                   \
-            u32x4s fa_[TM][3], fb_[TN][3];                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) fa_[i][p] = st_[fa_base + p * A_PLANE + i * 128 + fo_]; \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) fb_[j][p] = st_[fb_base + p * B_PLANE + j * 128 + fo_]; \
-            /* smallest partial products first; consecutive MFMAs go to different accumulators */  \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][2], fb_[j][0], i, j); \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][2], i, j); \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][1], fb_[j][1], i, j); \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][1], fb_[j][0], i, j); \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][1], i, j); \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa_[i][0], fb_[j][0], i, j); \
-        }                                                                                          \
+        const int fo_ = (S) ? f_off1 : f_off0;                                                     \
+        /* in the order the MFMAs want them: lo(A) . hi(B) first */                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][2] = (S3_DBG & 1) ? dbg_frag : st_[fa_base + 2 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = (S3_DBG & 1) ? dbg_frag : st_[fb_base + 0 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = (S3_DBG & 1) ? dbg_frag : st_[fa_base + 0 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][2] = (S3_DBG & 1) ? dbg_frag : st_[fb_base + 2 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = (S3_DBG & 1) ? dbg_frag : st_[fa_base + 1 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = (S3_DBG & 1) ? dbg_frag : st_[fb_base + 1 * B_PLANE + j * 128 + fo_]; \
+    }
+    /* smallest partial products first; consecutive MFMAs go to different accumulators */
+#define S3_MFMAS(SET)                                                                              \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][2], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][0], fb[SET][j][2], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][1], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][1], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][0], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][0], fb[SET][j][0], i, j); \
     }
 
+    u32x4s dbg_frag = {(unsigned)tid, 0x3f803f80u, 0x3f803f80u, (unsigned)lane};   // (ablation builds only)
+    if (S3_DBG & 1) asm volatile("" : "+v"(dbg_frag));
     // prologue: k-tiles 0 .. D-1 into their stages, k-tile D into the staging registers
 #pragma unroll
     for (int t = 0; t < D; ++t) {
@@ -220,14 +232,38 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     S3_LOAD(D)
     __syncthreads();
 
-    // iteration kt: registers (k-tile kt+D) -> stage (kt+D) % NBUF [last read in iteration kt-1, all waves are past
-    // its barrier]; loads of k-tile kt+D+1 (in flight for a whole iteration); MFMAs on stage kt % NBUF; barrier.
+    // iteration kt (the staging registers hold k-tile kt+D, requested during iteration kt-1):
+    //   [after the barrier] the 3(TM+TN) fragment reads of k-step 0 of stage kt % NBUF;
+    //   k-step 0: its 6 TM TN MFMAs with, between them, the reads of k-step 1, the split of the staged A elements and the
+    //             LDS stores of k-tile kt+D into stage (kt+D) % NBUF (last read in iteration kt-1: every wave is past that barrier);
+    //   k-step 1: its MFMAs with the global loads of k-tile kt+D+1 between them (in flight until the middle of iteration kt+1);
+    //   barrier.
+    // sched_group_barrier pins that interleaving: left alone, the scheduler reads each fragment group right in front of
+    // its MFMAs (exposed LDS latency) and sinks the loads to the end of the iteration (half an iteration of flight time).
+    constexpr int NMF = 6 * TM * TN, NFR = 3 * (TM + TN), NDW = 3 * (NIA + NIB), NVM = 2 * NIA + 3 * NIB;
 #define S3_ITER(CUR, WR)                                                                           \
     {                                                                                              \
-        S3_STORE(WR)                                                                               \
-        S3_LOAD(kt + D + 1)                                                                        \
-        S3_COMPUTE(CUR)                                                                            \
-        __syncthreads();                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        S3_FRAGS(0, CUR, 0)                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(S3_DBG & 2)) S3_STORE(WR)                                                            \
+        S3_FRAGS(1, CUR, 1)                                                                        \
+        S3_MFMAS(0)                                                                                \
+        _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
+            if (m_ >= NMF - 2 * NDW && ((NMF - 1 - m_) & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(S3_DBG & 8)) S3_LOAD(kt + D + 1)                                                     \
+        S3_MFMAS(1)                                                                                \
+        _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(S3_DBG & 4)) __syncthreads();                                                        \
     }
     int kt = 0;
     if constexpr (NBUF == 2) {
@@ -252,7 +288,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         }
     }
 #undef S3_ITER
-#undef S3_COMPUTE
+#undef S3_FRAGS
+#undef S3_MFMAS
 #undef S3_MFMA
 #undef S3_STORE
 #undef S3_LOAD
@@ -390,6 +427,8 @@ int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long
     R4D_CHECK_LAUNCH("split3_planes");
     return R4D_OK;
 }
+
+int dbgflag_s3() { return S3_DBG != 0; }
 
 }  // namespace r4d
 

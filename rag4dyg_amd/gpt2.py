@@ -205,6 +205,19 @@ class GPT2Model(_PreTrained):
             cache[key] = ent
         return ent[1].data_ptr()
 
+    def _w3(self, w):
+        """bf16x3 planes [3,out,in] of a static Conv1D weight (``ops.split3_planes``), cached like ``_wt``; None when the
+        split GEMM is switched off (``ops.set_gemm_split3(False)`` / ``R4D_GEMM_SPLIT3=0``) or the shape has no kernel."""
+        if not ops.gemm_split3_enabled() or w.shape[0] % 32 != 0:
+            return None
+        cache = self.__dict__.setdefault("_w3_cache", {})
+        key = id(w)
+        ent = cache.get(key)
+        if ent is None or ent[0] != (w.data_ptr(), w._version):
+            ent = ((w.data_ptr(), w._version), ops.split3_planes(w.detach()))
+            cache[key] = ent
+        return ent[1].data_ptr()
+
     def _c_structs(self):
         cfg = self.config
         c = _lib.GPT2ConfigC(cfg.n_layer, cfg.n_head, cfg.n_embd, self.wte.num_embeddings, self.wpe.num_embeddings,
@@ -222,7 +235,9 @@ class GPT2Model(_PreTrained):
                                         p(blk.ln_2.weight), p(blk.ln_2.bias), p(blk.mlp.c_fc.weight),
                                         p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias),
                                         self._wt(blk.attn.c_attn.weight), self._wt(blk.attn.c_proj.weight),
-                                        self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight))
+                                        self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight),
+                                        self._w3(blk.attn.c_attn.weight), self._w3(blk.attn.c_proj.weight),
+                                        self._w3(blk.mlp.c_fc.weight), self._w3(blk.mlp.c_proj.weight))
         head = self.__dict__.get("_lm_head_weight")              # set by an LM-head model whose lm_head is NOT tied to wte
         head = head() if head is not None else None
         w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers,

@@ -59,6 +59,25 @@ def conv1d(x, w, bias, epilogue="none", residual=None, w_t=None):
     return y
 
 
+_SPLIT3 = None
+
+
+def gemm_split3_enabled():
+    """True when the encoder GEMMs run on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, DESIGN.md 4);
+    default on, ``R4D_GEMM_SPLIT3=0`` or :func:`set_gemm_split3` select the exact-f32 MFMA kernels."""
+    global _SPLIT3
+    if _SPLIT3 is None:
+        import os
+        set_gemm_split3(os.environ.get("R4D_GEMM_SPLIT3", "1") != "0")
+    return _SPLIT3
+
+
+def set_gemm_split3(on):
+    global _SPLIT3
+    _SPLIT3 = bool(on)
+    check(_lib.load().r4d_set_gemm_split3(int(_SPLIT3)), "set_gemm_split3")
+
+
 def split3_planes(w, transposed=False):
     """Static Conv1D weight [K,N] (``transposed``: an [N,K] copy) -> its three k-contiguous bf16 planes (hi, mid, lo),
     a uint16 tensor [3,N,K] (torch's bfloat16 bit patterns): the operand format of :func:`conv1d_s3`."""

@@ -520,11 +520,22 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["dtype"].startswith("f32 (bf16x3") and d["extras"]["gemm"] == "split3"
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["roofline"]["kernel"].startswith("gemm_s3") and d["roofline"]["peak"] == 416.7     # bf16 dense peak / 6 products
+    ex = d["extras"]["exact_f32"]                                        # the same timed region on the exact-f32 MFMA kernels
+    assert ex["dtype"] == "f32" and ex["value"] > 0 and ex["roofline"]["peak"] == 157.3 and 0 < ex["roofline"]["frac"] <= 1
+    assert ex["top10_rows_identical_to_split3"] >= 0.99 and ex["max_abs_score_diff_vs_split3"] < 2e-6
+    v1 = d["extras"]["verify"]                                           # N = 1: last timed step against the oracle, in the run
+    assert v1.get("error") is None and v1["pass"] is True and v1["queries"] == 256 and v1["rows_identical_to_oracle"] >= 0.98, v1
+    assert v1["max_oracle_score_gap_at_mismatch"] <= 2e-6 and v1["timed_step_equals_recomputation"] is True
+    assert v1["scan_path_rows_identical_to_gemm_path"] >= 0.98 and v1["scan_vs_gemm_max_abs_score_diff"] < 1e-6
     assert "lm_head" in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["value_without_lm_head"] >= d["cpu_baseline"]["value"]
     sq = d["extras"]["scan_q32"]                                         # the north-star kernel on its own (HBM) roofline
     assert sq["queries"] == 32 and sq["pool_rows"] == 2048 and sq["roofline"]["bound"] == "hbm" and 0 < sq["roofline"]["frac"] <= 1
+    assert sq["roofline"]["frac"] == sq["roofline"]["frac_survey"] <= sq["roofline"]["frac_moved"]      # SURVEY's B_score vs bytes moved
+    assert sq["algorithmic_bytes"] == 4 * 2048 * 512 + 4 * 32 * 512 + 8 * 32 * 10 and 0 < sq["roofline"]["frac_scan_plus_topk"] < sq["roofline"]["frac"]
     assert d["roofline"]["traffic"] is None                              # PMC figure belongs to another workload / pool size
     assert len(d["extras"]["source_sha"]) == 16 and d["config"]["pool_rows_total"] == 2048
     lb = d["extras"]["length_bucketed"]                                  # SURVEY 8d's second run, never the headline
@@ -541,4 +552,5 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     v = d2["extras"]["verify"]                                           # post-run check: sharded == one-GPU recomputation
     assert v.get("error") is None and v["world_size"] == 2 and v["sharded_topk_equals_one_gpu"] is True, v
     assert v["pool_rows_checked"] == 4096 and len(v["per_rank_ms_per_step"]) == 2
+    assert v["collectives"].get("error") is None and v["collectives"]["all_gather_embeddings_us"] > 0, v["collectives"]
     assert "pipeline" in d2["config"]["collectives"] and "unavailable" not in p.stderr

@@ -22,7 +22,7 @@ stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --shape {os.environ.get('R4D_PROFILE_SHAPE', 'UCI_13')} "
-            "--steps 32 --warmup 16 --random-pool --no-cpu-baseline\n")
+            f"--gemm {os.environ.get('R4D_PROFILE_GEMM', 'split3')} --steps 32 --warmup 16 --random-pool --headline-only\n")
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in rows:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
@@ -69,6 +69,9 @@ def bench_class(k):
     m = re.match(r"gemm_f32_kc_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+(?:, \d+)?>", k)       # (+ epilogue kind)
     if m:
         return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
+    m = re.match(r"gemm_s3_kernel<(\d+), (\d+), ", k)
+    if m:
+        return f"gemm_s3_{m.group(1)}x{m.group(2)}x32"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
@@ -105,12 +108,28 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "a") as f:
     for c, (n, tot) in sorted(_class_rows().items(), key=lambda kv: -kv[1][1]):
         if not c.startswith(("at::", "__amd")):
             f.write(f"\"{c}\",{n},{tot:.0f},{tot / max(n, 1):.0f}\n")
+# the dominant class, recomputable by a reader: algorithmic flop per launch (bench.py's own HIP-event pass over the same steps)
+# over the rocprofv3 average duration of that class in THIS trace
+try:
+    line = json.loads([ln for ln in open(out + ".line.json") if ln.startswith("{")][-1])
+    roof = line["roofline"]
+    cls = _class_rows()
+    n, tot = cls[roof["kernel"]]
+    avg_ns = tot / max(n, 1)
+    tf = roof["flop_per_launch"] / avg_ns / 1e3
+    with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "a") as f:
+        f.write(f"# dominant class {roof['kernel']}: flop_per_launch {roof['flop_per_launch']:.6g} (bench.py, same steps) / rocprofv3 avg "
+                f"{avg_ns:.0f} ns = {tf:.1f} TFLOP/s = {tf / roof['peak']:.3f} of the {roof['peak']} TFLOP/s peak "
+                f"(bench.py HIP events on the launch stream: {roof['avg_launch_us']} us, {roof['achieved']} TFLOP/s, frac {roof['frac']})\n")
+except Exception as e:                                                        # noqa: BLE001
+    print("no bench line beside the trace:", e)
 sys.path.insert(0, repo)
 from bench import source_sha                                                   # noqa: E402
 shape = os.environ.get("R4D_PROFILE_SHAPE", "UCI_13")
-traffic["_workload"] = {"shape": shape, "batches_per_step": 8, "n_gpus": 1, "pool_rows_per_gpu": 100000,
+gemm = os.environ.get("R4D_PROFILE_GEMM", "split3")
+traffic["_workload"] = {"shape": shape, "batches_per_step": 8, "n_gpus": 1, "pool_rows_per_gpu": 100000, "gemm": gemm,
                         "source_sha": source_sha(),
-                        "command": f"bench.py --shape {shape} --steps 32 --warmup 16 --random-pool --no-cpu-baseline"}
+                        "command": f"bench.py --shape {shape} --gemm {gemm} --steps 32 --warmup 16 --random-pool --headline-only"}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1)[:3000])

@@ -35,6 +35,22 @@ def child():
         r = torch.randn(M, N, device=dev, generator=g) if epi == "residual" else None
         wt = w.t().contiguous()
         planes = ops.split3_planes(w)
+        if os.environ.get("S3_TIME_ONLY"):                     # ablated builds (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): timing only
+            fn = lambda: ops.conv1d_s3(x, planes, b, epi, r)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20 if M * K * N < 2e11 else 5
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            print(json.dumps({"lib": os.path.basename(os.environ.get("R4D_LIB_PATH", "product")), "tile": tile, "M": M, "K": K, "N": N,
+                              "epi": epi, "s3_us": round(ms * 1e3, 1), "s3_TF": round(2.0 * M * K * N / ms / 1e9, 1)}), flush=True)
+            continue
         rows = min(M, 4096)                                    # float64 reference on a slice (all columns)
         ref = x[:rows].double() @ w.double() + b.double()
         if epi == "gelu":
