@@ -41,7 +41,7 @@ int dbgflag_kc(); int dbgflag_att(); int dbgflag_sk(); int dbgflag_jac(); int db
 // ------------------------------------------------------------------ launch profiler (profile.hip)
 enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
-    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_S3_128x256, PK_GEMM_S3_128x128, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
+    PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_S3_128x256, PK_GEMM_S3_128x128, PK_GEMM_S3_W4_128x128, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
     PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN, PK_GREEDY_ADVANCE,
     PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
 };

@@ -24,6 +24,9 @@
 #include <string.h>
 #include "common.h"
 
+#ifndef S3_NRS
+#define S3_NRS 1   // register stages of the 128 x 256 tile; 2 measured no faster (K = 512: 157-166 vs 163-168 TFLOP/s, 240 vs 206 VGPRs): the k-tile loads are not latency-bound
+#endif
 #ifndef S3_DBG
 #define S3_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 4 only the split arithmetic
 #endif
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- the GEMM
-template <int BM, int BN, int WGM, int WGN, int NBUF, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kernel(
     const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
     const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
     constexpr int D = NBUF - 1;                                       // k-tiles between the LDS store and its use
     static_assert(NIA >= 1 && NIB >= 1 && NIA <= 2 && NIB <= 2 && TM >= 1 && TN >= 1 && (NBUF == 2 || NBUF == 3), "tile");
+    static_assert(NRS == 1 || (NRS == 2 && NBUF == 2), "two register stages: with the two-stage LDS ring only");
     __shared__ u32x4s lds[NBUF * STAGE];
 
     // XCD-aware grouped tile order (gemm_f32_kc.hip)
@@ -148,19 +152,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
 
-    u32x4s ra[NIA][2], rb[NIB][3];                                    // staging registers (fully unrolled indices only)
-#define S3_LOAD(KT)                                                                                \
+    // staging registers (fully unrolled indices only).  NRS = 2: two register stages -- a k-tile's loads are requested TWO
+    // iterations before they are split and stored (at K = 512 the A rows of a tile come from beyond the XCD's L2, one
+    // iteration of flight time does not cover that latency)
+    u32x4s ra[NRS][NIA][2], rb[NRS][NIB][3];
+#define S3_LOAD(RS, KT)                                                                            \
     {                                                                                              \
         const int kt_ = min((KT), nkt - 1);                                                        \
         _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
-            ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
-            ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
+            ra[RS][i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
+            ra[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
             _Pragma("unroll") for (int p = 0; p < 3; ++p)                                          \
-                rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+                rb[RS][i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
     }
-#define S3_STORE(STG)                                                                              \
+#define S3_STORE(RS, STG)                                                                          \
     {                                                                                              \
         u32x4s* sa_ = lds + (STG) * STAGE;                                                         \
         u32x4s* sb_ = sa_ + 3 * A_PLANE;                                                           \
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             u32x4s h_, m_, l_;                                                                     \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
                 /* (cast the WHOLE vector: __builtin_bit_cast on an ext-vector element reads element 0) */ \
-                const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[i][q >> 1]);                     \
+                const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[RS][i][q >> 1]);                 \
                 const float x0_ = src_[(q & 1) * 2], x1_ = src_[(q & 1) * 2 + 1];                  \
                 unsigned hh_, mm_, ll_;                                                            \
                 if (S3_DBG & 16) { hh_ = __builtin_bit_cast(unsigned, x0_); mm_ = __builtin_bit_cast(unsigned, x1_); ll_ = hh_ ^ mm_; } \
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = m_; sa_[2 * A_PLANE + a_dst[i]] = l_;    \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[i][p];  \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[RS][i][p]; \
     }
 
     // fragment addresses: lane (li, lh), k-step s -> chunk 2s + lh of row li (+ 32 per tile)
@@ -223,13 +230,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 
     u32x4s dbg_frag = {(unsigned)tid, 0x3f803f80u, 0x3f803f80u, (unsigned)lane};   // (ablation builds only)
     if (S3_DBG & 1) asm volatile("" : "+v"(dbg_frag));
-    // prologue: k-tiles 0 .. D-1 into their stages, k-tile D into the staging registers
+    // prologue: k-tiles 0 .. D-1 into their stages, k-tile D (and D+1 with two register stages) into the staging registers
+    if constexpr (NRS == 2) {
+        S3_LOAD(0, 0)
+        S3_LOAD(1, 1)                                                 // k-tiles 0 and 1 travel together: one exposed latency
+        S3_STORE(0, 0)
+        S3_LOAD(0, 2)
+    } else {
 #pragma unroll
-    for (int t = 0; t < D; ++t) {
-        S3_LOAD(t)
-        S3_STORE(t)
+        for (int t = 0; t < D; ++t) {
+            S3_LOAD(0, t)
+            S3_STORE(0, t)
+        }
+        S3_LOAD(0, D)
     }
-    S3_LOAD(D)
     __syncthreads();
 
     // iteration kt (the staging registers hold k-tile kt+D, requested during iteration kt-1):
@@ -241,12 +255,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     // sched_group_barrier pins that interleaving: left alone, the scheduler reads each fragment group right in front of
     // its MFMAs (exposed LDS latency) and sinks the loads to the end of the iteration (half an iteration of flight time).
     constexpr int NMF = 6 * TM * TN, NFR = 3 * (TM + TN), NDW = 3 * (NIA + NIB), NVM = 2 * NIA + 3 * NIB;
+    // (two register stages: the set that holds k-tile kt+1 has the parity of its LDS stage WR; it is refilled with k-tile kt+3)
 #define S3_ITER(CUR, WR)                                                                           \
     {                                                                                              \
+        const int RS_ = NRS == 2 ? ((WR) & 1) : 0;                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         S3_FRAGS(0, CUR, 0)                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (!(S3_DBG & 2)) S3_STORE(WR)                                                            \
+        if (!(S3_DBG & 2)) S3_STORE(RS_, WR)                                                       \
         S3_FRAGS(1, CUR, 1)                                                                        \
         S3_MFMAS(0)                                                                                \
         _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             if (m_ >= NMF - 2 * NDW && ((NMF - 1 - m_) & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (!(S3_DBG & 8)) S3_LOAD(kt + D + 1)                                                     \
+        if (!(S3_DBG & 8)) S3_LOAD(RS_, kt + D + NRS)                                              \
         S3_MFMAS(1)                                                                                \
         _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
@@ -294,6 +310,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #undef S3_STORE
 #undef S3_LOAD
 
+#if S3_DBG & 32
+    {   // ablation: no epilogue at all (one conditional store keeps the accumulators alive)
+        float ssum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ssum += acc[i][j][r];
+        if (ssum == 12345.678f) Cg[0] = ssum;
+        return;
+    }
+#endif
     // epilogue: the one of gemm_f32_kc.hip (C/D layout is dtype-independent: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
@@ -362,22 +391,232 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 4-wave form, two workgroups per CU
+// 128 x 128 tile, BK = 16, four wavefronts (2 x 2, wave tile 64 x 64), THREE LDS stages of 24 KB (72 KB: two workgroups
+// per CU = two waves per SIMD that belong to DIFFERENT tiles, so one tile's prologue, barrier waits and epilogue sit under
+// the other's MFMAs -- at K = 512 a tile is only 32 k-tiles long and the 8-wave kernel above, alone on its CU, exposes all
+// of that), two register stages (a k-tile's global loads are requested two iterations before they are split and stored).
+// LDS rows are 32 bytes (2 chunks of 8 k), chunk index XOR-ed with (row >> 3) & 1: conflict-free b128 reads and writes.
+// Iteration kt:  MFMAs of k-tile kt (fragment set kt & 1, read during iteration kt-1 -- legal before that iteration's
+// barrier: stage kt % 3 was stored in iteration kt-2);  between them the reads of k-tile kt+1 into the other fragment
+// set, the split + LDS stores of k-tile kt+2 (register set kt & 1) into stage (kt+2) % 3 [last read in iteration kt-1],
+// and the global loads of k-tile kt+4 into the same register set;  one barrier.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_s3w4_kernel(
+    const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
+    const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2, WM = 64, WN = 64;
+    constexpr int A_PLANE = BM * 2, B_PLANE = BN * 2;                 // uint4 units (a row = 2 chunks of 16 bytes)
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);                    // 1536 uint4 = 24 KB
+    __shared__ u32x4s lds[3 * STAGE];
+
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = g.K / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging: thread -> (row = tid >> 1, chunk = tid & 1) of the A tile AND of the W tile (three planes)
+    const int st_row = tid >> 1, st_c = tid & 1;
+    const int a_off = (min(m0 + st_row, g.M - 1) * g.lda + st_c * 8) * 4;
+    const int b_off = (min(n0 + st_row, g.N - 1) * g.K + st_c * 8) * 2;
+    const int st_dst = st_row * 2 + (st_c ^ ((st_row >> 3) & 1));
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
+
+    u32x4s ra[2][2], rb[2][3];                                        // two register stages
+#define W4_LOAD(RS, KT)                                                                            \
+    {                                                                                              \
+        const int kt_ = min((KT), nkt - 1);                                                        \
+        ra[RS][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off, kt_ * (BK * 4), 0);       \
+        ra[RS][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off + 16, kt_ * (BK * 4), 0);  \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                              \
+            rb[RS][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off, kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+    }
+#define W4_STORE(RS, STG)                                                                          \
+    {                                                                                              \
+        u32x4s* sa_ = lds + (STG) * STAGE + st_dst;                                                \
+        u32x4s h_, m_, l_;                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+            const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[RS][q >> 1]);                        \
+            unsigned hh_, mm_, ll_;                                                                \
+            split3_pair(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, mm_, ll_);                  \
+            h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                                 \
+        }                                                                                          \
+        sa_[0] = h_; sa_[A_PLANE] = m_; sa_[2 * A_PLANE] = l_;                                     \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) sa_[3 * A_PLANE + p * B_PLANE] = rb[RS][p];  \
+    }
+    const int f_off = li * 2 + (lh ^ ((li >> 3) & 1));
+    const int fa_base = wm * WM * 2 + f_off, fb_base = 3 * A_PLANE + wn * WN * 2 + f_off;
+    u32x4s fa[2][TM][3], fb[2][TN][3];
+#define W4_FRAGS(SET, STG)                                                                         \
+    {                                                                                              \
+        const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][2] = st_[fa_base + 2 * A_PLANE + i * 64]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = st_[fb_base + 0 * B_PLANE + j * 64]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = st_[fa_base + 0 * A_PLANE + i * 64]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][2] = st_[fb_base + 2 * B_PLANE + j * 64]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = st_[fa_base + 1 * A_PLANE + i * 64]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = st_[fb_base + 1 * B_PLANE + j * 64]; \
+    }
+    f32x16s acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define W4_MFMA(A_, B_, I_, J_) \
+    acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
+#define W4_MFMAS(SET)                                                                              \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][2], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][2], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][1], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][1], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][0], i, j); \
+    }
+
+    // prologue: k-tiles 0 and 1 into stages 0 and 1, k-tiles 2 and 3 into the two register stages, fragments of k-tile 0
+    W4_LOAD(0, 0)
+    W4_LOAD(1, 1)
+    W4_STORE(0, 0)
+    W4_LOAD(0, 2)
+    W4_STORE(1, 1)
+    W4_LOAD(1, 3)
+    __syncthreads();
+    W4_FRAGS(0, 0)
+
+    // one k-tile; SET = kt & 1 (compile time: the loop is unrolled by two), stages rotate at run time
+#define W4_ITER(SET)                                                                               \
+    {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        W4_STORE(SET, wr)                                                                          \
+        W4_LOAD(SET, kt + 4)                                                                       \
+        W4_FRAGS((SET) ^ 1, nxt)                                                                   \
+        W4_MFMAS(SET)                                                                              \
+        _Pragma("unroll") for (int m_ = 0; m_ < 24; ++m_) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
+            if (m_ >= 12 && m_ < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            \
+            if (m_ >= 18 && m_ < 23) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        __syncthreads();                                                                           \
+        const int t_ = cur; cur = nxt; nxt = wr; wr = t_;                                          \
+    }
+    int cur = 0, nxt = 1, wr = 2;
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        W4_ITER(0)
+        { ++kt; W4_ITER(1) }
+        --kt;
+    }
+    if (kt < nkt) W4_ITER(0)
+#undef W4_ITER
+#undef W4_MFMAS
+#undef W4_MFMA
+#undef W4_FRAGS
+#undef W4_STORE
+#undef W4_LOAD
+
+    float* __restrict__ C = Cg;
+    const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);
+    if (interior) {
+        const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
+        const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float res[16];
+                if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
+                }
+#pragma unroll
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
+                    if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
+                    else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = r2 + h2;
+                        const float v = h2 ? v2.y : v2.x;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
+                                                              ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + li;
+        const bool col_ok = col < g.N;
+        const int colc = min(col, g.N - 1);
+        const float bias = biasg ? biasg[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float res[16];
+            if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    res[r] = residg[(long long)row * g.ldr + colc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias;
+                if (EPI == EPI_GELU) v = gelu_new_s3_1(v);
+                else if (EPI == EPI_RESIDUAL) v += res[r];
+                if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 struct S3Tile { int bm, bn, cls; double eff; };
 static const S3Tile kS3[] = {
     {128, 256, PK_GEMM_S3_128x256, 1.0},
     {128, 128, PK_GEMM_S3_128x128, 0.9},
+    {128, 128, PK_GEMM_S3_W4_128x128, 0.0},          // 4 waves, two workgroups per CU (eff 0: via R4D_GEMM_S3_TILE=2 until measured)
 };
-constexpr int kNumS3 = 2;
+constexpr int kNumS3 = 3;
 
-template <int BM, int BN, int WGM, int WGN, int NBUF>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS>
 static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
     const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
     ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
     S3Shape sh;
     sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
 #define S3_LAUNCH_(E)                                                                              \
-    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WGM, WGN, NBUF, E>), dim3(tiles), dim3(64 * WGM * WGN), 0, stream, a.A, \
+    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WGM, WGN, NBUF, NRS, E>), dim3(tiles), dim3(64 * WGM * WGN), 0, stream, a.A, \
                        a.planes, a.C, a.bias, a.resid, sh)
     switch (a.epilogue) {
         case EPI_NONE: S3_LAUNCH_(EPI_NONE); break;
@@ -390,10 +629,28 @@ static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
     return R4D_OK;
 }
 
+static int launch_s3w4(const S3Args& a, hipStream_t stream) {
+    const int tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
+    ProfScope prof(PK_GEMM_S3_W4_128x128, 2.0 * (double)a.M * a.N * a.K, stream);
+    S3Shape sh;
+    sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
+#define W4_LAUNCH_(E) hipLaunchKernelGGL((gemm_s3w4_kernel<E>), dim3(tiles), dim3(256), 0, stream, a.A, a.planes, a.C, a.bias, a.resid, sh)
+    switch (a.epilogue) {
+        case EPI_NONE: W4_LAUNCH_(EPI_NONE); break;
+        case EPI_GELU: W4_LAUNCH_(EPI_GELU); break;
+        case EPI_RESIDUAL: W4_LAUNCH_(EPI_RESIDUAL); break;
+        default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
+    }
+#undef W4_LAUNCH_
+    R4D_CHECK_LAUNCH("gemm_s3w4");
+    return R4D_OK;
+}
+
 static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
     switch (t) {
-        case 0: return launch_s3<128, 256, 2, 4, 2>(a, kS3[0].cls, stream);
-        default: return launch_s3<128, 128, 2, 4, 3>(a, kS3[1].cls, stream);
+        case 0: return launch_s3<128, 256, 2, 4, 2, S3_NRS>(a, kS3[0].cls, stream);
+        case 1: return launch_s3<128, 128, 2, 4, 3, 1>(a, kS3[1].cls, stream);
+        default: return launch_s3w4(a, stream);
     }
 }
 
@@ -413,6 +670,7 @@ int launch_gemm_s3(const S3Args& a, hipStream_t stream) {
     int best = 0;
     double best_cost = 1e300;
     for (int t = 0; t < kNumS3; ++t) {
+        if (kS3[t].eff <= 0.0) continue;
         const long long blocks = (long long)cdiv(a.M, kS3[t].bm) * cdiv(a.N, kS3[t].bn);
         const double cost = (double)((blocks + 255) / 256) * kS3[t].bm * kS3[t].bn / kS3[t].eff;
         if (cost < best_cost) { best_cost = cost; best = t; }
