@@ -9,6 +9,7 @@ unchanged and the reference call sites (``train/train_retriever.py:419,430``,
 only (CPU tensors raise: there is no fallback).
 """
 import ctypes
+import weakref
 import json
 import os
 
@@ -194,6 +195,14 @@ class GPT2Model(_PreTrained):
         return new
 
     # ------------------------------------------------------------------ kernel hand-off
+    # per-object caches and the back-link to an owning LM-head model: never copied or pickled (copy.deepcopy(model) -- the
+    # reference's `best_model = copy.deepcopy(model)` -- and torch.save(model) go through __getstate__); an owner re-links
+    # its own copy in _LMHeadBase.__setstate__
+    _TRANSIENT = ("_wt_cache", "_w3_cache", "_greedy_decoders", "_lm_head_weight")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
     def _wt(self, w):
         """Contiguous transposed copy [out,in] of a static Conv1D weight, cached until the weight changes
         (keyed by storage pointer and in-place version counter)."""
@@ -593,12 +602,28 @@ class _LMHeadBase(_PreTrained):
     def lm_head_is_tied(self):
         return self.lm_head.weight is self.transformer.wte.weight
 
+    def _link_transformer(self):
+        """The decode kernels read lm_head through the transformer's weight struct: the transformer gets a getter that
+        follows whatever Parameter THIS model's lm_head.weight currently is (tied, untied, re-tied).  Held through a weak
+        reference (no cycle) and rebuilt for every copy / unpickled model (``__setstate__``): a deep copy must resolve its
+        OWN lm_head, not the original's."""
+        tr = self._modules.get("transformer")
+        if isinstance(tr, GPT2Model):
+            ref = weakref.ref(self)
+
+            def head():
+                owner = ref()
+                return owner.lm_head.weight if owner is not None and "lm_head" in owner._modules else None
+            tr.__dict__["_lm_head_weight"] = head
+
     def __setattr__(self, name, value):
         super().__setattr__(name, value)
         if name == "transformer" and isinstance(value, GPT2Model):
-            # the decode kernels read lm_head through the transformer's weight struct; a weakref-free closure over `self`
-            # keeps following whatever Parameter lm_head.weight currently is (tied, untied, re-tied)
-            value.__dict__["_lm_head_weight"] = lambda: self.lm_head.weight if "lm_head" in self._modules else None
+            self._link_transformer()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._link_transformer()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """``nn.Module.load_state_dict`` with the reference's UNTIED checkpoints handled.  The reference unties lm_head from

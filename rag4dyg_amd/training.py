@@ -403,7 +403,10 @@ def adjust_learning_rate(args, optimizer, epoch, base_lr, i, iteration_per_epoch
 
 def save_checkpoint(model, optimizer, tokenizer, args, global_step):
     """``utils/model.py:56-69`` layout: ``<output_dir>/checkpoint-<n>/{config.json, pytorch_model.bin, tokenizer files,
-    training_args.bin, optimizer.pt, scheduler.pt}`` (+ rotation by ``--save_total_limit``, :41-53)."""
+    training_args.bin}`` (+ rotation by ``--save_total_limit``, :41-53).  The optimizer / schedule state goes to
+    ``r4d_optimizer.pt`` / ``r4d_scheduler.pt`` in this build's own layout -- NOT under the reference's ``optimizer.pt`` /
+    ``scheduler.pt`` names, which ``get_optimizer_scheduler`` (utils/model.py:96-102) would try to ``load_state_dict`` as a
+    ``transformers.AdamW`` / ``LambdaLR`` state when pointed at this directory."""
     import glob
     import re
     import shutil
@@ -424,8 +427,8 @@ def save_checkpoint(model, optimizer, tokenizer, args, global_step):
             shutil.rmtree(path)
     torch.save({"format": "rag4dyg_amd.AdamW", "t": optimizer.t, "lr": optimizer.lr,
                 "m": {k: v.cpu() for k, v in optimizer.m.items()}, "v": {k: v.cpu() for k, v in optimizer.v.items()}},
-               os.path.join(out, "optimizer.pt"))
-    torch.save({"last_epoch": optimizer.t}, os.path.join(out, "scheduler.pt"))
+               os.path.join(out, "r4d_optimizer.pt"))
+    torch.save({"last_epoch": optimizer.t}, os.path.join(out, "r4d_scheduler.pt"))
 
 
 def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args, mask_nce):
@@ -502,7 +505,8 @@ def train(args, train_dataset, model, tokenizer):
         print('==> Training Epoch: ', epoch)
         global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step,
                                                    args, mask_nce)
-        tr_loss += ep_loss
+        tr_loss = ep_loss            # the reference resets tr_loss every epoch (train_retriever.py:158): its logged / returned
+                                     # "train_loss" is the LAST epoch's summed loss over the cumulative step count (:303, :354)
         val_metrics, val_loss = test(epoch, args, model, tokenizer, evaluate=True)
         score = val_metrics['hit@3']
         print(f"epoch {epoch}: train_loss {tr_loss / max(global_step, 1):.5f} (cl {cl:.4f} aug {au:.4f}) val_loss {float(val_loss):.5f} "

@@ -282,7 +282,7 @@ def test_main_retriever_do_train_end_to_end(dev, tmp_path, monkeypatch):
     losses = [float(x) for x in re.findall(r"epoch \d+: train_loss ([0-9.]+)", log)]
     assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     for ck in ("checkpoint-0", "checkpoint-1"):
-        for f in ("config.json", "pytorch_model.bin", "tokenizer.json", "training_args.bin", "optimizer.pt", "scheduler.pt"):
+        for f in ("config.json", "pytorch_model.bin", "tokenizer.json", "training_args.bin", "r4d_optimizer.pt", "r4d_scheduler.pt"):
             assert (out / ck / f).exists(), (ck, f)
     sd = torch.load(out / "checkpoint-1" / "pytorch_model.bin", map_location="cpu", weights_only=True)
     assert "transformer.h.1.mlp.c_proj.weight" in sd and "lm_head.weight" in sd and all(torch.isfinite(v).all() for v in sd.values())
@@ -439,7 +439,7 @@ def test_main_retriever_do_train_two_ranks(dev, tmp_path):
     import re
     per_rank = [[float(x) for x in re.findall(r"val_hit@3 ([0-9.eE+-]+)", o)] for o, _ in done]
     assert len(per_rank[0]) == 3 and per_rank[0] == per_rank[1]                # same weights on both ranks -> same validation
-    assert (out / "checkpoint-1" / "pytorch_model.bin").exists() and (out / "checkpoint-1" / "optimizer.pt").exists()
+    assert (out / "checkpoint-1" / "pytorch_model.bin").exists() and (out / "checkpoint-1" / "r4d_optimizer.pt").exists()
     assert all("test_metrics last epoch" in o for o, _ in done)
 
 

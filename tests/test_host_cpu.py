@@ -43,6 +43,30 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.r4d_argsort_workspace_bytes(4, 100000, 8) >= 4 * 49 * 2048 * 12
 
 
+def test_deepcopy_and_pickle_follow_their_own_lm_head():
+    """`best_model = copy.deepcopy(model)` (the reference's training loops) must give a copy whose decode path
+    resolves ITS OWN lm_head (tied or untied), never the original's; per-object kernel caches are not copied; torch.save works."""
+    import copy
+    import io
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=20, n_positions=16, n_ctx=16, n_embd=64, n_layer=1, n_head=2))
+    m.transformer.__dict__["_wt_cache"] = {"stale": 1}
+    head = lambda model: model.transformer.__dict__["_lm_head_weight"]()
+    assert head(m) is m.lm_head.weight
+    m2 = copy.deepcopy(m)
+    assert head(m2) is m2.lm_head.weight and head(m2) is not m.lm_head.weight
+    assert m2.lm_head.weight is m2.transformer.wte.weight and "_wt_cache" not in m2.transformer.__dict__      # tie kept, caches dropped
+    m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight.detach().clone() + 1.0)      # untie the original
+    m3 = copy.deepcopy(m)
+    assert head(m3) is m3.lm_head.weight and m3.lm_head.weight is not m3.transformer.wte.weight
+    assert torch.equal(m3.lm_head.weight, m.lm_head.weight) and head(m2) is m2.transformer.wte.weight      # earlier copy untouched
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m4 = torch.load(buf, weights_only=False)
+    assert head(m4) is m4.lm_head.weight and torch.equal(m4.lm_head.weight, m.lm_head.weight)
+
+
 def test_product_path_has_no_cpu_fallback():
     from rag4dyg_amd import ops
     from rag4dyg_amd._lib import R4DError
