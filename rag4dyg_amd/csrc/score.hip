@@ -7,7 +7,7 @@
 #include "common.h"
 
 #ifndef SCAN_DBG
-#define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs, bit 1 the score stores, bit 2 the cross-wave reduction
+#define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs, bit 1 the score stores, bit 2 the cross-wave reduction, bit 3 writes s_memrealtime stamps (100 MHz) of workgroup phases over the score rows of queries >= 16 (tools/scan_timeline.py)
 #endif
 
 namespace r4d {
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 // the raw rows (6 % of the pool bytes) stay cache-resident.
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
-template <int KW, int NG>                               // d == 32 * KW * NG
+template <int KW, int NG, bool TWO>                     // d == 32 * KW * NG; TWO: two tiles of a workgroup in flight
 __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_scan_ks_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
-                                                              int Q, int N, float* __restrict__ scores,
+                                                              int Q, int N, int rpw, float* __restrict__ scores,
                                                               unsigned* __restrict__ zero_d, int nzero) {
     constexpr int D = 32 * KW * NG;
     constexpr int R = 16 / KW;                          // accumulator registers a wave finishes
@@ -69,9 +69,21 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
     const int q0 = blockIdx.y * 32;
     if (blockIdx.x == 0 && blockIdx.y == 0)             // ticket counters of the top-k launch that follows on this stream
         for (int i = tid; i < nzero; i += 64 * KW) zero_d[i] = 0u;
-    const int ntiles = (N + 31) / 32;
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
+    // rpw > 0: workgroup b owns the CONTIGUOUS rows [b rpw, (b+1) rpw) of the shard, walked in 32-row tiles (the last one
+    // partial): rows, i.e. bytes, are dealt evenly -- a 12,500-row shard is 49 rows (100 KB) per CU instead of 391 whole
+    // tiles over 256 CUs (two tiles on half of them, one on the rest).  rpw == 0 (long shards): the 32-row tiles are dealt
+    // round-robin (tile b, b + G, ...), so that at any moment the workgroups read ADJACENT lines (DRAM page locality:
+    // contiguous ranges measured 48.9 us against 43-45 us at 100k x 512).
+    const int G = (int)gridDim.x;
+    const int r0 = rpw > 0 ? blockIdx.x * rpw : blockIdx.x * 32;
+    const int r1 = rpw > 0 ? min(N, r0 + rpw) : N;
+    const int tstep = rpw > 0 ? 32 : 32 * G;                 // rows between consecutive tiles of this workgroup
+    if (r0 >= N) return;
+#if SCAN_DBG & 8
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(scores + (long long)16 * N) + blockIdx.x * 16;
+    if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[5] = __builtin_amdgcn_s_memtime(); }
+#endif
+    const int ntiles = rpw > 0 ? (r1 - r0 + 31) / 32 : ((N + 31) / 32 - (int)blockIdx.x + G - 1) / G;
     // k order: load u of lane half h of row j is the 16-byte piece 2u + h of the wave's 128-byte line g, so ONE load
     // instruction touches a whole 32-byte sector of each of its 32 rows; component c of that load is
     // k = 32 (g KW + w) + 8 u + 4 h + c on BOTH operands.
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
                 qf[g][u] = v;
             }
     }
-    auto tile_ptr = [&](int tt) {
-        return reinterpret_cast<const float4*>(pool + (long long)min(tt * 32 + li, N - 1) * D) + lh + 8 * w;   // clamped: always valid
+    auto tile_ptr = [&](int tt) {                       // rows past the shard are clamped (always valid); rows past r1 belong to the
+        return reinterpret_cast<const float4*>(pool + (long long)min(r0 + tt * tstep + li, N - 1) * D) + lh + 8 * w;   // next workgroup: computed, not stored
     };
     int buf = 0;
     // one tile: MFMAs over the staged rows `bb`, each group's registers refilled with tile `trefill` (< 0: none) right after
@@ -118,6 +130,9 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
                 for (int u = 0; u < 4; ++u) bb[g][u] = pn[8 * KW * g + 2 * u];
             }
         }
+#if SCAN_DBG & 8
+        if (tcur < 2) { asm volatile("" :: "v"(acc[0]), "v"(acc[15])); if (tid == 0) stamps[8 + 4 * tcur] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         float fin[R];
         if (KW > 1 && !(SCAN_DBG & 4)) {
             // red[buf][src wave][dst wave][lane][R]: lane-contiguous vectors, conflict-free on both sides
@@ -138,13 +153,16 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
 #pragma unroll
             for (int i = 0; i < R; ++i) fin[i] = acc[w * R + i];
         }
-        const int row = tcur * 32 + li;
-        if (row < N && !(SCAN_DBG & 2)) {
+#if SCAN_DBG & 8
+        if (tcur < 2) { asm volatile("" :: "v"(fin[0])); if (tid == 0) stamps[9 + 4 * tcur] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        const int row = r0 + tcur * tstep + li;
+        if (row < r1 && !(SCAN_DBG & 2)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int r = w * R + i;
                 const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (q < Q) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+                if (q < Q && (!(SCAN_DBG & 8) || q < 16)) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
             }
         }
     };
@@ -155,10 +173,90 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
 #pragma unroll
             for (int u = 0; u < 4; ++u) bb[g][u] = p[8 * KW * g + 2 * u];
     };
-    const int G = (int)gridDim.x;
     float4 b0[NG][4];
-    load_tile(b0, t);
-    for (; t < ntiles; t += G) do_tile(b0, t, t + G < ntiles ? t + G : -1);
+    load_tile(b0, 0);
+#if SCAN_DBG & 8
+    if (tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();              // all loads issued
+    {   // wait for the first tile and the queries
+        float sink = qf[0][0].x + b0[NG - 1][3].w;
+        asm volatile("" :: "v"(sink));
+        if (tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();          // first tile landed
+    }
+#endif
+    if constexpr (TWO) {
+        // short ranges (a shard of a few ten thousand rows: 2-3 tiles per workgroup): the second tile's loads go out together
+        // with the first's -- ONE memory latency in front of the MFMAs instead of one per tile -- and the two tiles share ONE
+        // cross-wave reduction (timeline of the one-tile-at-a-time form, tools/scan_timeline.py: the barrier of the first
+        // tile's reduction waits 1.8 us for the wave whose loads landed last, while the matrix pipe idles)
+        float4 b1[NG][4];
+        load_tile(b1, min(1, ntiles - 1));
+        for (int t = 0; t < ntiles; t += 2) {
+            const bool has2 = t + 1 < ntiles;                             // workgroup-uniform
+            f32x16s acc2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 (&bb)[NG][4] = h ? b1 : b0;
+                const int tn = t + 2 + h;
+                const float4* __restrict__ pn = tile_ptr(tn < ntiles ? tn : 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[h][r] = 0.f;
+                if (h == 0 || has2) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].x, bb[g][u].x, acc2[h], 0, 0, 0);
+                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].y, bb[g][u].y, acc2[h], 0, 0, 0);
+                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].z, bb[g][u].z, acc2[h], 0, 0, 0);
+                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].w, bb[g][u].w, acc2[h], 0, 0, 0);
+                        }
+                        if (tn < ntiles) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) bb[g][u] = pn[8 * KW * g + 2 * u];
+                        }
+                    }
+                }
+            }
+            // red[tile h][src wave][dst wave][lane][R]; same fixed summation order as the one-tile form: identical bits
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float* base = red + h * (KW * KW * 64 * R);
+#pragma unroll
+                for (int wd = 0; wd < KW; ++wd)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) base[((w * KW + wd) * 64 + lane) * R + i] = acc2[h][wd * R + i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* base = red + h * (KW * KW * 64 * R);
+                float fin[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) fin[i] = 0.f;
+#pragma unroll
+                for (int p = 0; p < KW; ++p)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) fin[i] += base[((p * KW + w) * 64 + lane) * R + i];
+                const int row = r0 + (t + h) * tstep + li;
+                if (row < r1 && (h == 0 || has2)) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int r = w * R + i;
+                        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (q < Q) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+                    }
+                }
+            }
+            if (t + 2 < ntiles) __syncthreads();                          // the LDS buffers are reused by the next pair
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) do_tile(b0, t, t + 1 < ntiles ? t + 1 : -1);
+    }
+#if SCAN_DBG & 8
+    if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();              // all stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { stamps[3] = __builtin_amdgcn_s_memrealtime(); stamps[6] = __builtin_amdgcn_s_memtime(); stamps[4] = (unsigned long long)__builtin_amdgcn_s_getreg(6164); }   // end; XCC id
+#endif
 }
 
 template <int KW, int NG>
@@ -167,16 +265,26 @@ static int launch_scan_variant(const float* qhat, const float* pool, int Q, int 
     static int wgs_per_cu = 0;
     if (wgs_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ks_kernel<KW, NG>, 64 * KW, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ks_kernel<KW, NG, false>, 64 * KW, 0) != hipSuccess || nb < 1) nb = 1;
         wgs_per_cu = nb;
     }
-    static int force = -1;
+    static int force = -1, two = -1;
     if (force < 0) { const char* e = getenv("R4D_SCAN_WGS_PER_CU"); force = e ? atoi(e) : 0; }     // tuning aid
+    if (two < 0) { const char* e = getenv("R4D_SCAN_TWO"); two = e ? atoi(e) : 1; }                // tuning aid: 0 = never two tiles in flight
     const int per_cu = force > 0 ? force : wgs_per_cu;
     const int ntiles = cdiv(N, 32);
-    const int gx = max(1, min(ntiles, 256 * per_cu));
-    hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat, pool, Q, N, scores,
-                       zero_d, nzero);
+    // short shards (<= 3 tiles per CU): ONE workgroup per CU owning an equal, contiguous share of the rows, two tiles in
+    // flight and one joint reduction; long ones: round-robin tiles over the occupancy-sized grid
+    const bool shortr = two && KW * NG >= 8 && ntiles > 256 && ntiles <= 3 * 256;
+    if (shortr) {
+        const int rpw = cdiv(N, 256);
+        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, (KW * NG >= 8)>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat,
+                           pool, Q, N, rpw, scores, zero_d, nzero);
+    } else {
+        const int gx = max(1, min(ntiles, 256 * per_cu));
+        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, false>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat, pool, Q, N, 0,
+                           scores, zero_d, nzero);
+    }
     R4D_CHECK_LAUNCH("pool_scan");
     return R4D_OK;
 }
