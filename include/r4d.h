@@ -74,6 +74,11 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * decode step keeps its weight-stream kernels); everything else about the call is unchanged. */
     const uint16_t* c_attn_w3;  const uint16_t* attn_proj_w3;
     const uint16_t* c_fc_w3;    const uint16_t* mlp_proj_w3;
+    /* TRAINING only, optional: the planes of the same weights as the operand of the data-gradient GEMMs dx = dy . W^T
+     * (r4d_split3_planes_bf16(w, K = out, N = in, transposed = 1): uint16 [3][in][out]); NULL = exact-f32 kernel.  Like the
+     * wT copies, every plane set must be refreshed by the caller after each optimizer step. */
+    const uint16_t* c_attn_w3t; const uint16_t* attn_proj_w3t;
+    const uint16_t* c_fc_w3t;   const uint16_t* mlp_proj_w3t;
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
@@ -409,6 +414,14 @@ int r4d_profile_num_classes(void);
 const char* r4d_profile_class_name(int32_t cls);
 /* Synchronises the recorded events; total_ms / launches / work summed over the launches of `cls`. */
 int r4d_profile_read(int32_t cls, double* total_ms, int64_t* launches, double* work);
+
+/* Dispatcher-branch coverage: every host-side decision that selects a kernel variant (tile shape, template instantiation,
+ * split-K form, fallback) counts its launches under a name.  Tests enumerate the table and assert that each branch ran
+ * (names starting with "tuning:" are reachable through environment switches only). */
+int r4d_dispatch_num_branches(void);
+const char* r4d_dispatch_branch_name(int32_t i);
+int64_t r4d_dispatch_branch_hits(int32_t i);      /* launches through branch i since load / the last reset */
+int r4d_dispatch_reset(void);
 
 #ifdef __cplusplus
 }

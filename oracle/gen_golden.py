@@ -81,7 +81,7 @@ def _ref_model(flavour, n_layer, n_head, n_embd, vocab, n_positions, sd, output_
     m = cls(cfg).eval()
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
-    assert all(k.endswith("attn.bias") for k in missing), missing   # causal buffers only
+    assert all(k.endswith(".attn.bias") or k.endswith(".attn.masked_bias") for k in missing), missing   # causal buffers only (NOT c_attn.bias)
     return m
 
 
@@ -579,6 +579,10 @@ def g8_training_step():
                     tag + "_grad_lnf_w": model.transformer.ln_f.weight.grad.numpy().copy(),
                     tag + "_grad_cattn_b0": model.transformer.h[0].attn.c_attn.bias.grad.numpy().copy(),
                     tag + "_grad_wte_rows": model.transformer.wte.weight.grad[:8].numpy().copy()})
+        if tag == "ts_tiny":        # EVERY parameter gradient of the small step (wpe: the rows a 64-position batch can touch)
+            for n in names:
+                gr = model.get_parameter(n).grad
+                out[tag + "_grad_all:" + n] = (gr[:64] if n.endswith("wpe.weight") else gr).numpy().copy()
 
     step("ts_tiny", 2, 2, 64, 80, 78, 4, [9, 12, 17, 23], 410, 0.2, 0.5, 0.1)
     step("ts_cfg2", 4, 2, 512, 1801, 1799, 8, [12, 20, 37, 60], 420, 0.2, 0.5, 0.1)
@@ -639,7 +643,91 @@ def g9_query_times():
     _save("g9_query_times", **out)
 
 
+# --------------------------------------------------------------------------- G10
+def g10_trained(tag="small", weights=None, device_npz=None):
+    """TRAINED weights (every other vector uses N(0, 0.02) + random affine).  The checkpoint comes from THIS build's
+    own trainer on the real UCI_13/12 data (GPU box: ``python tools/g10_trained.py <tag> L H d epochs lr`` -> gpurun_out/g10/
+    <tag>_weights.npz, the reference script's recipe for the full-size run); here the SAME tensors are loaded into the
+    reference model on CPU and the hot path is run with the reference's own modules (as g4 does).
+      tag == "small" (L2 H2 d128, 2.8 MB): weights + reference outputs are committed as tests/golden/g10_trained_small.npz;
+      any other tag (the full-size L4 H2 d512 checkpoint, 56 MB: not committed): the reference outputs are compared with the
+      device outputs the GPU run dumped next to the weights and a report goes to profiles/r03_trained_parity_<tag>.json."""
+    print(f"G10 trained weights [{tag}]")
+    import json
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    weights = weights or os.path.join(here, "gpurun_out", "g10", f"{tag}_weights.npz")
+    device_npz = device_npz or os.path.join(here, "gpurun_out", "g10", f"{tag}_device.npz")
+    w = np.load(weights)
+    sd = {k: torch.from_numpy(w[k]) for k in w.files}
+    d = sd["transformer.wte.weight"].shape[1]
+    V = sd["transformer.wte.weight"].shape[0]
+    L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer.h."))
+    H = 2
+    n_pos = sd["transformer.wpe.weight"].shape[0]
+    if "lm_head.weight" not in sd:
+        sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    m = _ref_model("rag", L, H, d, V, n_pos, sd)
+    g6 = np.load(os.path.join(GOLD, "g6_uci_tokens.npz"))
+    pad = int(g6["pad_id"])
+
+    def seqs(flat, off):
+        return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    pool, test = seqs(g6["pool_flat"], g6["pool_off"]), seqs(g6["test_flat"], g6["test_off"])
+    NP = 256                                                         # pool rows used: the first 8 reference batches
+
+    def batches(examples):          # dataloader/retriever.py:153-166 around the reference model (as g4)
+        for s in range(0, len(examples), 32):
+            ch = [torch.tensor(e, dtype=torch.long) for e in examples[s:s + 32]]
+            yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=pad)
+    with torch.no_grad():
+        pe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool[:NP])], dim=0)
+        qe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(test)], dim=0)
+        qn = qe / qe.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
+        pn = pe / pe.norm(dim=1, keepdim=True)
+        S = ((torch.matmul(qn, pn.t()) + 1) / 2).numpy()
+    top10 = np.argsort(-S, axis=1, kind="stable")[:, :10].astype(np.int32)
+    stats = {"max_abs_weight": float(max(v.abs().max() for v in sd.values())),
+             "ln_gain_range": [float(min(v.min() for k, v in sd.items() if "ln_" in k and k.endswith("weight"))),
+                               float(max(v.max() for k, v in sd.items() if "ln_" in k and k.endswith("weight")))],
+             "query_emb_absmax": float(qe.abs().max())}
+    if tag == "small":
+        _save("g10_trained_small", n_layer=np.array(L), n_head=np.array(H), pool_rows=np.array(NP),
+              pool_emb=pe.numpy(), query_emb=qe.numpy(), scores=S, top10_stable=top10,
+              **{"w:" + k: v.numpy() for k, v in sd.items() if k != "lm_head.weight"})
+        print("   ", stats)
+        return
+    dv = np.load(device_npz)
+    rep = {"checkpoint": f"tools/g10_trained.py {tag}: {L} layers, {H} heads, d {d}, vocab {V}; the reference recipe "
+                         "(scripts/train_retriever/train_retriever_UCI_13.sh) on UCI_13/12 with this build's trainer", "weights": stats,
+           "compared": f"{qe.shape[0]} test queries x first {NP} pool rows, reference modules on CPU vs the HIP path on MI355X"}
+    for mode in ("split3", "f32"):
+        q_d, p_d, S_d = dv[f"{mode}_query_emb"], dv[f"{mode}_pool_emb_head"][:NP], dv[f"{mode}_scores"][:, :NP]
+        # device top-10 restricted to the first NP pool rows, canonical order, from the DEVICE scores
+        top_d = np.argsort(-S_d.astype(np.float64), axis=1, kind="stable")[:, :10]
+        same = top_d == top10
+        gap = 0.0
+        for r, c in zip(*np.nonzero(~same)):
+            gap = max(gap, abs(float(S[r, top10[r, c]]) - float(S[r, top_d[r, c]])))
+
+        def ew(got, ref):
+            got, ref = got.astype(np.float64), ref.astype(np.float64)
+            return float((np.abs(got - ref) / (1e-4 * np.abs(ref) + 1e-5 * np.abs(ref).max())).max())
+        rep[mode] = {"query_emb_maxnorm_err": float(np.abs(q_d - qe.numpy()).max() / np.abs(qe.numpy()).max()),
+                     "query_emb_elementwise_ratio": ew(q_d, qe.numpy()), "pool_emb_elementwise_ratio": ew(p_d, pe.numpy()),
+                     "scores_max_abs_err": float(np.abs(S_d - S).max()), "top10_rows_identical": float(same.all(axis=1).mean()),
+                     "max_reference_score_gap_at_mismatch": gap}
+    out = os.path.join(here, "profiles", f"r03_trained_parity_{tag}.json")
+    json.dump(rep, open(out, "w"), indent=1)
+    print(json.dumps(rep, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":                   # g10 <tag> [weights.npz] [device.npz]
+        torch.set_num_threads(os.cpu_count() or 1)
+        _install_stubs()
+        _scratch_cwd()
+        g10_trained(*sys.argv[2:5])
+        return
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
               "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g8b": g8b_lr_schedule, "g9": g9_query_times}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)

@@ -25,7 +25,8 @@ class GPT2LayerC(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_1_w", "ln_1_b", "c_attn_w", "c_attn_b", "attn_proj_w", "attn_proj_b",
                                          "ln_2_w", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b",
                                          "c_attn_wT", "attn_proj_wT", "c_fc_wT", "mlp_proj_wT",
-                                         "c_attn_w3", "attn_proj_w3", "c_fc_w3", "mlp_proj_w3")]
+                                         "c_attn_w3", "attn_proj_w3", "c_fc_w3", "mlp_proj_w3",
+                                         "c_attn_w3t", "attn_proj_w3t", "c_fc_w3t", "mlp_proj_w3t")]
 
 
 class GreedyStateC(Structure):
@@ -116,6 +117,10 @@ PROTOTYPES = {
     "r4d_causal_softmax_bwd_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_float, _P]),
     "r4d_sumsq_accumulate_f32": (c_int32, [_P, c_int64, _P, _P]),
     "r4d_adamw_step_f32": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int32, _P, c_float, _P]),
+    "r4d_dispatch_num_branches": (c_int32, []),
+    "r4d_dispatch_branch_name": (c_char_p, [c_int32]),
+    "r4d_dispatch_branch_hits": (c_int64, [c_int32]),
+    "r4d_dispatch_reset": (c_int32, []),
     "r4d_profile_enable": (c_int32, [c_int32]),
     "r4d_profile_num_classes": (c_int32, []),
     "r4d_profile_class_name": (c_char_p, [c_int32]),

@@ -573,6 +573,14 @@ int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const 
     for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
     R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
     switch (hd) {
+        case 32: R4D_BRANCH(ATT_KS32); break;
+        case 64: R4D_BRANCH(ATT_KS64); break;
+        case 96: if (g_attention_variant == 1) R4D_BRANCH(ATT_KS_FORCED); else R4D_BRANCH(ATT_CS96); break;
+        case 128: if (g_attention_variant == 1) R4D_BRANCH(ATT_KS_FORCED); else R4D_BRANCH(ATT_CS128); break;
+        case 256: if (g_attention_variant == 1) R4D_BRANCH(ATT_KS_FORCED); else R4D_BRANCH(ATT_CS256); break;
+        default: break;
+    }
+    switch (hd) {
         case 32: return launch_hd<32>(qkv, G, Tmax, flop, H, d, out, s);
         case 64: return launch_hd<64>(qkv, G, Tmax, flop, H, d, out, s);
         case 96: return g_attention_variant == 1 ? launch_hd<96>(qkv, G, Tmax, flop, H, d, out, s)

@@ -54,6 +54,42 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end_impl(s); }
 };
 
+// ------------------------------------------------------------------ dispatcher-branch coverage (profile.hip)
+// Every host-side decision that selects a kernel VARIANT (tile shape, template instantiation, split-K form, fallback) counts
+// its launches under a name; r4d_dispatch_* enumerates the table so that a test can assert that each branch was exercised
+// (tests/test_gpu_ops.py::test_every_dispatcher_branch_is_exercised -- a shape list keyed by config names missed the
+// d = 256 decode path once: commit 2e9f5d4).  Names that start with "tuning:" are reachable through environment switches only.
+#define R4D_BRANCH_LIST(X)                                                                                              \
+    X(KC_128x128x16, "gemm_kc:128x128x16") X(KC_128x64x16, "gemm_kc:128x64x16") X(KC_64x64x32, "gemm_kc:64x64x32")       \
+    X(KC_128x128x32, "tuning:gemm_kc:128x128x32") X(KC_ROWSPLIT, "gemm_kc:row-split (two launches)")                      \
+    X(S3_128x256, "gemm_s3:128x256x32") X(S3_128x128, "gemm_s3:128x128x32") X(S3_W4, "tuning:gemm_s3:w4_128x128x16")      \
+    X(F32_128x128, "gemm_f32:128x128") X(F32_128x64, "gemm_f32:128x64") X(F32_64x64, "gemm_f32:64x64")                   \
+    X(F32_NT, "gemm_f32:B as [N,K]") X(F32_NN, "gemm_f32:B as [K,N]") X(TN_SPLITK, "gemm_tn:split-K") X(TN_SINGLE, "gemm_tn:one slice") \
+    X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
+    X(SK16_SPLITK, "skinny16:split-K last-arriver") X(SK8_NG2, "skinny8:ng2") X(SK8_NG3, "skinny8:ng3")                    \
+    X(SK8_LN, "tuning:skinny8:+layernorm") X(SK8_SPLITK, "skinny8:split-K + epilogue launch") X(SK_PLAIN, "skinny:plain + epilogue launch") \
+    X(ATT_KS32, "attention:key-split hd32") X(ATT_KS64, "attention:key-split hd64") X(ATT_CS96, "attention:column-split hd96") \
+    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256")                              \
+    X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
+    X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
+    X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \
+    X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)")  \
+    X(TOPK_ONE_WG, "topk:one workgroup per row") X(TOPK_TICKET, "topk:cross-workgroup ticket merge")                      \
+    X(TOPK_MULTI, "topk:second launch over candidates") X(TOPK_F64, "topk:f64 rows")                                      \
+    X(LN4_2, "layernorm:ln4<2>") X(LN4_4, "layernorm:ln4<4>") X(LN4_8, "layernorm:ln4<8>") X(LN_GENERIC, "layernorm:generic") \
+    X(LNF_8, "lnf_meanpool:<8>") X(LNF_16, "lnf_meanpool:<16>") X(LNF_32, "lnf_meanpool:<32>")                             \
+    X(DEC_ATT_32, "decode_attention:<32>") X(DEC_ATT_64, "decode_attention:<64>")                                         \
+    X(JAC_LDS, "jaccard:LDS table") X(JAC_MERGE, "jaccard:merge walk (vocab too large for LDS)")                          \
+    X(ARGSORT_ONE, "argsort:one chunk") X(ARGSORT_MULTI, "argsort:chunk sort + rank scatter")
+enum DispatchBranch {
+#define X(id, name) BR_##id,
+    R4D_BRANCH_LIST(X)
+#undef X
+    BR_COUNT
+};
+extern unsigned long long g_branch_hits[BR_COUNT];
+#define R4D_BRANCH(id) (++r4d::g_branch_hits[r4d::BR_##id])
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

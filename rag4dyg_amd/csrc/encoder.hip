@@ -61,6 +61,7 @@ static int attention(const float* qkv, int B, int T, int H, int d, float* a_out,
         const int rc_f = launch_attention_fused(qkv, B, T, H, d, a_out, s);
         if (rc_f <= 0) return rc_f;                      // +1: no fused instantiation for this head_dim
     }
+    R4D_BRANCH(ATT_3LAUNCH);
     const int hd = d / H, ld = tpad(T);
     GemmArgs g;
     memset(&g, 0, sizeof(g));

@@ -90,6 +90,7 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
     if (rows <= 0) return R4D_OK;
     ProfScope prof(PK_LAYERNORM, 8.0 * rows * d, s);            // bytes: read x + write y
     const bool vec = d % 256 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
+    if (vec && d <= 512) R4D_BRANCH(LN4_2); else if (vec && d <= 1024) R4D_BRANCH(LN4_4); else if (vec) R4D_BRANCH(LN4_8); else R4D_BRANCH(LN_GENERIC);
     if (vec && d <= 512) hipLaunchKernelGGL(ln4_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
     else if (vec && d <= 1024) hipLaunchKernelGGL(ln4_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
     else if (vec) hipLaunchKernelGGL(ln4_kernel<8>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y);
@@ -343,6 +344,7 @@ int launch_decode_attention(const float* qkv_new, float* kv_layer, const int32_t
     // algorithmic bytes: the cached K and V rows of every head (upper bound t_cap/2 on average is unknown here: count
     // the new row only; callers that profile use the HIP-event time)
     ProfScope prof(PK_DECODE_ATTN, 16.0 * B * d, s);
+    if (hd <= 128) R4D_BRANCH(DEC_ATT_32); else R4D_BRANCH(DEC_ATT_64);
     if (hd <= 128) hipLaunchKernelGGL(decode_attn_kernel<32>, dim3(H, B), dim3(512), 0, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
     else hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(H, B), dim3(512), 0, s, qkv_new, kv_layer, pos, t_cap, H, d, out);
     R4D_CHECK_LAUNCH("decode_attention");
@@ -569,6 +571,7 @@ int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* 
         ProfScope prof(PK_LNF_MEANPOOL, 4.0 * rows * d * (hidden_out ? 2 : 1) + 4.0 * parts * d, s);
         const dim3 grid(cdiv(Tmax, LNF_ROWS_PER_CHUNK), nseq);
         float* part = pool_out ? scratch : nullptr;
+        if (d <= 512) R4D_BRANCH(LNF_8); else if (d <= 1024) R4D_BRANCH(LNF_16); else R4D_BRANCH(LNF_32);
         if (d <= 512) hipLaunchKernelGGL(lnf_partial_kernel<8>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
         else if (d <= 1024) hipLaunchKernelGGL(lnf_partial_kernel<16>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
         else hipLaunchKernelGGL(lnf_partial_kernel<32>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);

@@ -348,6 +348,8 @@ static int launch_variant(const GemmArgs& g, int cls, hipStream_t stream) {
     sh.b_rows = g.b_rows; sh.a_cols = g.a_cols; sh.nb1 = g.nb1; sh.epilogue = g.epilogue; sh.causal = g.causal;
     sh.sA0 = g.sA0; sh.sA1 = g.sA1; sh.sB0 = g.sB0; sh.sB1 = g.sB1; sh.sC0 = g.sC0; sh.sC1 = g.sC1;
     sh.scale_div = g.scale_div; sh.k_total = 0;
+    if (BM == 128 && BN == 128) R4D_BRANCH(F32_128x128); else if (BM == 128) R4D_BRANCH(F32_128x64); else R4D_BRANCH(F32_64x64);
+    if (g.b_trans) R4D_BRANCH(F32_NT); else R4D_BRANCH(F32_NN);
     if (g.b_trans)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WGM, WGN, true>), grid, dim3(NTHREADS), 0, stream, g.A, g.B, g.C, g.bias,
                            g.resid, sh);
@@ -413,6 +415,7 @@ int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, i
     sh.M = M; sh.N = N; sh.K = Sx > 1 ? kper : Kt; sh.lda = lda; sh.ldb = ldb; sh.ldc = N; sh.ldr = N;
     sh.b_rows = Kt; sh.a_cols = Kt; sh.nb1 = 1; sh.epilogue = EPI_NONE; sh.causal = CAUSAL_NONE; sh.k_total = Kt;
     sh.sA0 = (long long)kper * lda; sh.sB0 = (long long)kper * ldb; sh.sC0 = (long long)M * N; sh.scale_div = 1.f;
+    if (Sx > 1) R4D_BRANCH(TN_SPLITK); else R4D_BRANCH(TN_SINGLE);
     {
         ProfScope prof(PK_GEMM_128x128_NN, 2.0 * M * N * Kt, stream);
         // (tried: 2 x 2 waves with 64 x 64 wave tiles -- twice the MFMAs per LDS read, half the waves: no change, 48.4 vs 48.1 ms backward)

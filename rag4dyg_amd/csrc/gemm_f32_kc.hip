@@ -437,6 +437,7 @@ static int kc_best_tile(const GemmArgs& g, int rows, double* cost_out) {
 }
 
 static int kc_launch_tile(const GemmArgs& g, int t, hipStream_t stream) {
+    switch (t) { case 0: R4D_BRANCH(KC_128x128x32); break; case 1: R4D_BRANCH(KC_128x128x16); break; case 2: R4D_BRANCH(KC_128x64x16); break; default: R4D_BRANCH(KC_64x64x32); }
     switch (t) {
         case 0: return launch_kc<128, 128, 32, 4, 2, 2>(g, kKc[0].cls, stream);
         case 1: return launch_kc<128, 128, 16, 4, 2, 4>(g, kKc[1].cls, stream);
@@ -486,6 +487,7 @@ int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream) {
             if (total < best_cost) { best_cost = total; best_t1 = t1; best_t2 = t2; best_m1 = m1; }
         }
         if (best_t1 >= 0 && best_cost < 0.97 * single_cost) {
+            R4D_BRANCH(KC_ROWSPLIT);
             GemmArgs a = g, b = g;
             a.M = best_m1;
             b.M = g.M - best_m1;

@@ -647,6 +647,7 @@ static int launch_s3w4(const S3Args& a, hipStream_t stream) {
 }
 
 static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
+    switch (t) { case 0: R4D_BRANCH(S3_128x256); break; case 1: R4D_BRANCH(S3_128x128); break; default: R4D_BRANCH(S3_W4); }
     switch (t) {
         case 0: return launch_s3<128, 256, 2, 4, 2, S3_NRS>(a, kS3[0].cls, stream);
         case 1: return launch_s3<128, 128, 2, 4, 3, 1>(a, kS3[1].cls, stream);

@@ -467,6 +467,9 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
 #define SK16_(NG_, LN_)                                                                                                    \
     hipLaunchKernelGGL((gemm_skinny16_kernel<NG_, LN_>), grid, block, 0, s, x, wT, M, N, K, bias, resid, epilogue, y, partial, \
                        counters, ln_w, ln_b, ln_eps)
+        if (ng == 3) { if (ln_w) R4D_BRANCH(SK16_NG3_LN); else R4D_BRANCH(SK16_NG3); }
+        else         { if (ln_w) R4D_BRANCH(SK16_NG2_LN); else R4D_BRANCH(SK16_NG2); }
+        if (KS > 1) R4D_BRANCH(SK16_SPLITK);
         if (ng == 3) { if (ln_w) SK16_(3, true); else SK16_(3, false); }
         else         { if (ln_w) SK16_(2, true); else SK16_(2, false); }
 #undef SK16_
@@ -482,6 +485,9 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
 #define SK8_(NG_, LN_)                                                                                                    \
     hipLaunchKernelGGL((gemm_skinny8_kernel<NG_, LN_>), grid, block, 0, s, x, wT, M, N, K, bias, resid, epilogue, y, partial, \
                        ln_w, ln_b, ln_eps)
+        if (ng == 3) R4D_BRANCH(SK8_NG3); else R4D_BRANCH(SK8_NG2);
+        if (ln_w) R4D_BRANCH(SK8_LN);
+        if (KS > 1) R4D_BRANCH(SK8_SPLITK);
         if (ng == 3) { if (ln_w) SK8_(3, true); else SK8_(3, false); }
         else         { if (ln_w) SK8_(2, true); else SK8_(2, false); }
 #undef SK8_
@@ -491,6 +497,7 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
         KS = K / SK_KC;
         // algorithmic bytes: the weight matrix once (+ x per slice, + partials)
         ProfScope prof(PK_GEMM_SKINNY, 4.0 * K * (double)N + 4.0 * M * K + 4.0 * KS * 32.0 * N, s);
+        R4D_BRANCH(SK_PLAIN);
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3(cdiv(cdiv(N, 32), 4), KS), dim3(256), 0, s, x, wT, M, N, K, scratch + S16_MAX_TILES);
         R4D_CHECK_LAUNCH("gemm_skinny");
     }

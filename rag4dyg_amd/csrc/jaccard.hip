@@ -275,10 +275,12 @@ extern "C" int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_
         }
         // a big table leaves room for one workgroup per CU only: give it 16 wavefronts instead of 4
         const int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
+        R4D_BRANCH(JAC_LDS);
         hipLaunchKernelGGL(jaccard_lds_kernel, dim3(col_tiles, chunks), dim3(threads), lds, s, a_ptr_d, a_idx_d, na, a_nnz,
                            b_ptr_d, b_idx_d, nb, vocab, zero_diag, rows_per_block, a_order_d, a_dense_d, b_dense_d, out_d);
         R4D_CHECK_LAUNCH("jaccard_lds");
     } else {
+        R4D_BRANCH(JAC_MERGE);
         hipLaunchKernelGGL(jaccard_merge_kernel, dim3((unsigned)((long long)cdiv(nb, 256) * na)), dim3(256), 0, s, a_ptr_d, a_idx_d, na, b_ptr_d,
                            b_idx_d, nb, zero_diag, a_dense_d, b_dense_d, out_d);
         R4D_CHECK_LAUNCH("jaccard_merge");

@@ -30,11 +30,23 @@ static const char* kNames[PK_COUNT] = {
     "gemm_f32_kc_128x64x16", "gemm_f32_kc_64x64x32", "gemm_s3_128x256x32", "gemm_s3_128x128x32", "gemm_s3_w4_128x128x16", "gemm_skinny", "gemm_skinny_epilogue", "embed_layernorm",
     "layernorm", "causal_softmax", "decode_attention", "greedy_advance", "attn_fused", "lnf_partial", "meanpool_reduce", "normalize_rows", "pool_scan", "topk", "merge_topk", "argsort", "jaccard"};
 
+unsigned long long g_branch_hits[BR_COUNT];
+static const char* kBranchNames[BR_COUNT] = {
+#define X(id, name) name,
+    R4D_BRANCH_LIST(X)
+#undef X
+};
+
 }  // namespace r4d
 
 using namespace r4d;
 
 extern "C" {
+
+int r4d_dispatch_num_branches(void) { return BR_COUNT; }
+const char* r4d_dispatch_branch_name(int32_t i) { return (i >= 0 && i < BR_COUNT) ? kBranchNames[i] : ""; }
+int64_t r4d_dispatch_branch_hits(int32_t i) { return (i >= 0 && i < BR_COUNT) ? (int64_t)g_branch_hits[i] : -1; }
+int r4d_dispatch_reset(void) { for (int i = 0; i < BR_COUNT; ++i) g_branch_hits[i] = 0; return R4D_OK; }
 
 int r4d_profile_enable(int32_t on) {
     for (auto& r : g_recs) g_free.push_back(r);

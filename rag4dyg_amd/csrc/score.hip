@@ -277,6 +277,7 @@ static int launch_scan_variant(const float* qhat, const float* pool, int Q, int 
     // flight and one joint reduction; long ones: round-robin tiles over the occupancy-sized grid
     const bool shortr = two && KW * NG >= 8 && ntiles > 256 && ntiles <= 3 * 256;
     if (shortr) {
+        R4D_BRANCH(SCAN_SHORT);
         const int rpw = cdiv(N, 256);
         hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, (KW * NG >= 8)>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat,
                            pool, Q, N, rpw, scores, zero_d, nzero);
@@ -298,15 +299,15 @@ static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, 
     // algorithmic bytes (SURVEY 8d B_score): pool read once per 32 queries + queries + score rows out
     ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
     switch (d) {
-        case 32:   return launch_scan_variant<1, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 64:   return launch_scan_variant<2, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 128:  return launch_scan_variant<4, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 256:  return launch_scan_variant<4, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 384:  return launch_scan_variant<4, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 512:  return kw8 ? launch_scan_variant<8, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s)       // default
-                              : launch_scan_variant<4, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 768:  return launch_scan_variant<8, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
-        case 1024: return launch_scan_variant<8, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 32:   R4D_BRANCH(SCAN_1_1); return launch_scan_variant<1, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 64:   R4D_BRANCH(SCAN_2_1); return launch_scan_variant<2, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 128:  R4D_BRANCH(SCAN_4_1); return launch_scan_variant<4, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 256:  R4D_BRANCH(SCAN_4_2); return launch_scan_variant<4, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 384:  R4D_BRANCH(SCAN_4_3); return launch_scan_variant<4, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 512:  if (kw8) { R4D_BRANCH(SCAN_8_2); return launch_scan_variant<8, 2>(qhat, pool, Q, N, scores, zero_d, nzero, s); }   // default
+                   R4D_BRANCH(SCAN_4_4); return launch_scan_variant<4, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 768:  R4D_BRANCH(SCAN_8_3); return launch_scan_variant<8, 3>(qhat, pool, Q, N, scores, zero_d, nzero, s);
+        case 1024: R4D_BRANCH(SCAN_8_4); return launch_scan_variant<8, 4>(qhat, pool, Q, N, scores, zero_d, nzero, s);
         default:   return 1;
     }
 }
@@ -352,6 +353,7 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
         zeroed = rc == R4D_OK;
     }
     if (rc > 0) {                                                                // MFMA-bound regime / other d: tiled GEMM
+        R4D_BRANCH(SCAN_GEMM);
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = q_hat_d; g.B = pool_hat_d; g.C = scores;

@@ -400,6 +400,8 @@ int topk_rows(const T* vals, const long long* idx_in, int rows, int n, long long
                 R4D_HIP(hipMemsetAsync(counters, 0, align_up((size_t)rows * sizeof(unsigned), 16), s));
             counters_zeroed = false;
         }
+        if (nchunks == 1) R4D_BRANCH(TOPK_ONE_WG); else if (finish) R4D_BRANCH(TOPK_TICKET); else R4D_BRANCH(TOPK_MULTI);
+        if (sizeof(T) == 8) R4D_BRANCH(TOPK_F64);
         {
             ProfScope prof(PK_TOPK, (double)rows * cur * (sizeof(T) + (ci ? 8 : 0)), s);
             hipLaunchKernelGGL((topk_chunk_kernel<T>), dim3(nchunks, rows), dim3(64 * nw), 0, s, cv, ci, (int)cur, cld, k,
@@ -606,6 +608,7 @@ static int argsort_desc(const T* scores, int rows, int n, int32_t* perm, void* w
         ws_k = (K*)ws;
         ws_i = (uint32_t*)((char*)ws + align_up((size_t)rows * nchunks * SORT_CHUNK * sizeof(K), 256));
     }
+    if (nchunks > 1) R4D_BRANCH(ARGSORT_MULTI); else R4D_BRANCH(ARGSORT_ONE);
     ProfScope prof(PK_RANK_COUNT, (double)rows * n * (sizeof(T) + 4), s);
     hipLaunchKernelGGL((sort_chunks_kernel<T>), dim3(nchunks, rows), dim3(1024), 0, s, scores, n, nchunks, ws_k, ws_i, perm);
     R4D_CHECK_LAUNCH("sort_chunks");

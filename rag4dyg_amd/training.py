@@ -197,13 +197,33 @@ class EncoderTrainer:
                 for f in ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w"):
                     w = self.params[f"transformer.h.{i}.{dict(_LAYER_PARAMS)[f]}"]
                     self._wt[(i, f)] = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev)
+        # bf16x3 planes of the same weights: [3,out,in] for the forward GEMMs, [3,in,out] for the data gradients dx = dy . W^T
+        # (ops.split3_planes; the bf16 matrix cores at fp32 accuracy); refreshed with the copies above
+        self.use_s3 = ops.gemm_split3_enabled() and os.environ.get("R4D_TRAIN_SPLIT3", "1") != "0"
+        self._w3, self._w3t = {}, {}
+        if self.use_wt or self.use_s3:
             self.refresh_transposed()
 
     @torch.no_grad()
     def refresh_transposed(self):
-        """Bring the [out,in] weight copies up to date (call after every optimizer step / load_state_dict)."""
+        """Bring the [out,in] weight copies and the bf16x3 planes up to date (call after every optimizer step / load_state_dict)."""
         for (i, f), wt in self._wt.items():
             wt.copy_(self.params[f"transformer.h.{i}.{dict(_LAYER_PARAMS)[f]}"].t())
+        if self.use_s3:
+            lib = _lib.load()
+            stream = torch.cuda.current_stream().cuda_stream
+            for i in range(len(self.model.transformer.h)):
+                for f in ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w"):
+                    w = self.params[f"transformer.h.{i}.{dict(_LAYER_PARAMS)[f]}"]
+                    K, N = w.shape
+                    if K % 32 or N % 32:
+                        continue
+                    if (i, f) not in self._w3:
+                        self._w3[(i, f)] = torch.empty(3, N, K, dtype=torch.int16, device=w.device)
+                        self._w3t[(i, f)] = torch.empty(3, K, N, dtype=torch.int16, device=w.device)
+                    _lib.check(lib.r4d_split3_planes_bf16(w.data_ptr(), K, N, 0, self._w3[(i, f)].data_ptr(), stream), "split3_planes")
+                    # the data-gradient operand: W itself read as an [N' = K rows, K' = N contiguous] matrix
+                    _lib.check(lib.r4d_split3_planes_bf16(w.data_ptr(), N, K, 1, self._w3t[(i, f)].data_ptr(), stream), "split3_planes")
 
     def _structs(self):
         tr = self.model.transformer
@@ -215,7 +235,10 @@ class EncoderTrainer:
         for i in range(cfg.n_layer):
             vals = [self.params[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS]
             wts = [self._wt[(i, f)].data_ptr() if self.use_wt else None for f in ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w")]
-            layers[i] = _lib.GPT2LayerC(*vals, *wts)                                         # wT copies kept current by refresh_transposed
+            fs = ("c_attn_w", "attn_proj_w", "c_fc_w", "mlp_proj_w")
+            w3 = [self._w3[(i, f)].data_ptr() if (i, f) in self._w3 else None for f in fs]
+            w3t = [self._w3t[(i, f)].data_ptr() if (i, f) in self._w3t else None for f in fs]
+            layers[i] = _lib.GPT2LayerC(*vals, *wts, *w3, *w3t)                               # copies / planes kept current by refresh_transposed
             glayers[i] = _lib.GPT2LayerGradsC(*[self.grads[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS])
         w = _lib.GPT2WeightsC(tr.wte.weight.data_ptr(), tr.wpe.weight.data_ptr(), tr.ln_f.weight.data_ptr(),
                               tr.ln_f.bias.data_ptr(), layers, None)

@@ -63,6 +63,38 @@ def test_uci13_real_ids_match_reference_embeddings_scores_ranks(dev):
     assert retrieval_ref.topk_matches_modulo_ties(g["scores"], idx.cpu().numpy(), 10, 2e-6)
 
 
+@pytest.mark.parametrize("split3", [True, False])
+def test_trained_checkpoint_matches_reference_g10(dev, split3):
+    """TRAINED weights: a checkpoint this build's trainer produced on the real UCI_13/12 data (L2 H2 d128,
+    30 epochs, lr 1e-4; tools/g10_trained.py), loaded into the REFERENCE model on CPU by oracle/gen_golden.py g10 -- the 110 test
+    queries and the first 256 pool histories through both: embeddings element-wise at 1e-4, scores, stable top-10 with a
+    reference-score gap <= 2e-6 at any mismatching rank.  Both GEMM paths (bf16x3 split and exact-f32 MFMA).  The full-size
+    (L4 H2 d512, 50 epochs) comparison is a one-off report: profiles/r03_trained_parity_full.json."""
+    from rag4dyg_amd import ops
+    from rag4dyg_amd.retrieval import PoolIndex, encode_batches, right_pad_batches
+    g, k = load_golden("g10_trained_small"), load_golden("g6_uci_tokens")
+    sd = {n[2:]: torch.from_numpy(g[n]) for n in g.files if n.startswith("w:")}
+    d, V = sd["transformer.wte.weight"].shape[1], sd["transformer.wte.weight"].shape[0]
+    m = _model_from_sd(sd, int(g["n_layer"]), int(g["n_head"]), d, V, sd["transformer.wpe.weight"].shape[0], dev)
+    pad, NP = int(k["pad_id"]), int(g["pool_rows"])
+    was = ops.gemm_split3_enabled()
+    ops.set_gemm_split3(split3)
+    try:
+        pool = encode_batches(m, right_pad_batches(_unragged(k["pool_flat"], k["pool_off"])[:NP], 32, pad, dev))
+        q = encode_batches(m, right_pad_batches(_unragged(k["test_flat"], k["test_off"]), 32, pad, dev))
+        vals, idx, S = PoolIndex(pool).search(q, 10, want_scores=True)
+    finally:
+        ops.set_gemm_split3(was)
+        m.transformer.__dict__.pop("_w3_cache", None)
+    eq, ep = elementwise_err(q.cpu().numpy(), g["query_emb"]), elementwise_err(pool.cpu().numpy(), g["pool_emb"])
+    exact, gap = rank_mismatch_report(g["scores"], g["top10_stable"], idx.cpu().numpy())
+    print(f"G10 trained checkpoint ({'bf16x3' if split3 else 'exact f32'}): element-wise ratio queries {eq:.3f} pool {ep:.3f} (pass < 1); "
+          f"max |score - reference| {np.abs(S.cpu().numpy() - g['scores']).max():.2e}; top-10 lists identical {exact:.4f}, gap {gap:.2e}")
+    assert eq < 1 and ep < 1
+    assert rel_err(q.cpu().numpy(), g["query_emb"]) < TOL and elementwise_err(S.cpu().numpy(), g["scores"]) < 1
+    assert gap <= 2e-6, gap
+
+
 # ------------------------------------------------------------------------------------------- synthetic dataset
 def _write_dataset(root, ds="toy", t=4, v0=60, n_train=150, n_val=40, n_test=37, seed=0):
     rng = np.random.default_rng(seed)
