@@ -40,12 +40,48 @@ def _compile(src, force, hdr_m):
     return obj, True
 
 
+# Cross-workgroup hand-offs (topk.hip last-arriver merge, gemm_skinny.hip split-K combine) publish with RELAXED agent-scope
+# atomic stores and consume with relaxed agent-scope loads: correct on gfx950 because hipcc lowers those to write-through /
+# L1-bypassing `sc1` memory instructions (MI355X_MICROARCH.md, inter-workgroup visibility).  A toolchain that stopped emitting
+# sc1 would corrupt top-k results and decode projections silently, so the build fails instead.
+HANDOFF_KERNELS = {"topk.hip": ("topk_chunk_kernelIfE", "topk_chunk_kernelIdE"), "gemm_skinny.hip": ("gemm_skinny16_kernelILi2ELb0E", "gemm_skinny16_kernelILi3ELb0E")}
+
+
+def check_handoff_lowering(src):
+    import re
+    import tempfile
+    names = HANDOFF_KERNELS[os.path.basename(src)]
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "--offload-device-only", "-S", src, "-o", asm],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+        text = open(asm).read()
+    for name in names:
+        m = re.search(r"^(_ZN3r4d\d+" + re.escape(name) + r"[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+        if not m:
+            raise RuntimeError(f"hand-off check: kernel {name} not found in the assembly of {src}")
+        body = m.group(2)
+        stores = re.findall(r"global_store_dword(?:x2)? [^\n]*", body)
+        loads_sc1 = [ln for ln in re.findall(r"global_load_dword(?:x2)? [^\n]*", body) if " sc1" in ln]
+        stores_sc1 = [ln for ln in stores if " sc1" in ln]
+        ticket = re.findall(r"global_atomic_add[^\n]*", body)
+        if not ticket or len(stores_sc1) < 2 or len(loads_sc1) < 1:
+            raise RuntimeError(f"hand-off check FAILED for {name}: {len(stores_sc1)} sc1 stores, {len(loads_sc1)} sc1 loads, "
+                               f"{len(ticket)} ticket atomics -- the relaxed agent-scope publish / consume of {os.path.basename(src)} "
+                               "is no longer lowered to write-through / L1-bypassing instructions; use release / acquire there")
+
+
 def build_library(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = _deps_mtime()
     with ThreadPoolExecutor(max_workers=4) as ex:
         res = list(ex.map(lambda s: _compile(s, force, hdr_m), sources()))
     objs = [o for o, _ in res]
+    for src, (_o, compiled) in zip(sources(), res):
+        if compiled and os.path.basename(src) in HANDOFF_KERNELS:
+            check_handoff_lowering(src)
     if force or any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -424,6 +424,10 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
         s_last = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)KS - 1u;
     __syncthreads();
     if (!s_last) return;
+    // same hand-off as topk.hip (write-through sc1 partials, drained before the ticket behind a workgroup barrier, sc1 loads in
+    // the last arriver after a barrier it joined): compiler barrier so that no partial load is hoisted above the ticket;
+    // build.py checks the sc1 lowering
+    asm volatile("" ::: "memory");
     if (tid == 0) __hip_atomic_store(&counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (en < N && em < M) {
         float o = 0.f;

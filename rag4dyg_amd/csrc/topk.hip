@@ -321,6 +321,14 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES) void topk_chunk_kernel(
     if (lane == 0)
         last = __hip_atomic_fetch_add(&counters[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nchunks - 1u;
     if (!__builtin_amdgcn_readfirstlane(last)) return;          // wave-uniform: only wave 0 of the LAST workgroup goes on
+    // Ordering of this hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 table): every candidate is
+    // stored write-through (sc1) by the publishing wave, which drains its stores (vmcnt(0)) BEFORE its ticket add; the last
+    // arriver's add has returned (its value decided the branch above) before any of its candidate loads issue, and every such load
+    // is an sc1 load (L1 bypassed).  That is an ISA argument, not a C++ one: relaxed atomics on different addresses carry no
+    // order in the language, so the compiler barrier below pins the loads behind the branch (zero instructions; an agent-scope
+    // acquire fence here would cost one buffer_inv + wait, ~1.7 us on a 10 us kernel), and rag4dyg_amd/build.py refuses a build
+    // whose publish stores / consume loads are not lowered to sc1.
+    asm volatile("" ::: "memory");
     const int m = nchunks * k;                                  // <= 1024 (host guarantees it when finish is set)
     const T* cv = cand_v + (long long)row * m;
     for (int i = lane; i < m; i += 64) s_key[i] = KeyOf<T>::make(consume(cv + i));

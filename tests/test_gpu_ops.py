@@ -476,6 +476,48 @@ def test_topk_fuzz_random_shapes_heavy_ties(dev):
         assert np.array_equal(v.cpu().numpy(), ev), (trial, rows, n, k, levels)
 
 
+def test_cross_workgroup_handoffs_under_back_to_back_launches(dev):
+    """The last-arriver merges (topk_chunk_kernel's ticket, gemm_skinny16's split-K combine) publish with write-through
+    stores and consume with L1-bypassing loads.  Stress: 64 rows x 16 chunks of 16k columns,
+    200 launches back to back on one stream WITHOUT a host sync between them (the consumer's L1 is warm with the previous
+    launch's candidates -- the stale-read condition), every launch's result compared with the stable argsort afterwards; and
+    the split-K decode projection (K = 4d) 200 times back to back against its float64 product.  One pass, no retries."""
+    from rag4dyg_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    rows, n, k = 64, 16 * 16384, 10
+    xs = [torch.rand(rows, n, generator=g).to(dev) for _ in range(4)]
+    refs = [np.argsort(-x.cpu().numpy().astype(np.float64), axis=1, kind="stable")[:, :k] for x in xs]
+    outs = []
+    for it in range(200):
+        v, i = ops.topk_f32(xs[it % 4], k)                       # workspace (candidates + tickets) reused by every launch
+        outs.append(i.clone())
+    torch.cuda.synchronize()
+    bad = [it for it, i in enumerate(outs) if not np.array_equal(i.cpu().numpy(), refs[it % 4])]
+    assert not bad, f"stale / torn candidates in launches {bad[:10]}"
+    assert _lib.load().r4d_dispatch_branch_hits([j for j in range(_lib.load().r4d_dispatch_num_branches())
+                                                 if _lib.load().r4d_dispatch_branch_name(j) == b"topk:cross-workgroup ticket merge"][0]) >= 200
+    # skinny split-K: a decode step's mlp c_proj (M = 32 rows, K = 4d = 2048, N = 512) through the model API
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    sd = gpt2_ref.make_state_dict(1, 512, 60, n_positions=64, seed=3, random_affine=True)
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=60, n_positions=64, n_ctx=64, n_embd=512, n_layer=1, n_head=2))
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    m = m.to(dev).eval()
+    tr = m.transformer
+    ids = torch.randint(0, 59, (32, 9), generator=g).to(dev)
+    ref = tr.encode(ids, want_hidden=True)["hidden"][:, 8]
+    cache = tr.new_kv_cache(32, 16, dev)
+    pos = torch.full((32,), 8, dtype=torch.int32, device=dev)
+    hs = []
+    for it in range(200):
+        tr.prefill(cache, input_ids=ids[:, :8]) if it == 0 else None
+        hs.append(tr.decode_step(cache, pos, input_ids=ids[:, 8]).clone())    # rewrites cache row 8 with the same values
+    torch.cuda.synchronize()
+    worst = max(rel_err(h.cpu().numpy(), ref.cpu().numpy()) for h in hs)
+    assert worst < 2e-5 and all(torch.equal(h, hs[0]) for h in hs), worst      # deterministic slice order: identical bits every launch
+
+
 @pytest.mark.parametrize("rows,n", [(3, 1), (4, 2048), (3, 2049), (2, 3965), (5, 65537), (32, 100000), (1, 200001)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_argsort_desc_any_length_equals_numpy_stable(dev, rows, n, dtype):
