@@ -95,10 +95,12 @@ def main(argv=None):
             checkpoints = list(os.path.dirname(c) for c in
                                sorted(glob.glob(args.output_dir + "/**/" + WEIGHTS_NAME, recursive=True)))
         print("Evaluate the following checkpoints: {}".format(checkpoints))
+        from rag4dyg_amd.annotation import phase       # R4D_PHASE_TIMING=1: wall-clock breakdown (tools/annotation_e2e.py)
         for checkpoint in checkpoints:
-            state_dict = torch.load(os.path.join(checkpoint, WEIGHTS_NAME), map_location="cpu", weights_only=True)
-            model.load_state_dict(state_dict)          # strict, like main_retriever.py:152-153; no re-tie (as upstream)
-            model.to(args.device)
+            with phase("host: read checkpoint + load_state_dict + upload"):
+                state_dict = torch.load(os.path.join(checkpoint, WEIGHTS_NAME), map_location="cpu", weights_only=True)
+                model.load_state_dict(state_dict)      # strict, like main_retriever.py:152-153; no re-tie (as upstream)
+                model.to(args.device)
             test_metrics = test(0, args, model, tokenizer, evaluate=False, prefix="best")
             print('test_metrics: ', test_metrics)
 

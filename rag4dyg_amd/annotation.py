@@ -13,6 +13,32 @@ from . import ops
 
 ROW_CHUNK = 2048           # A-rows per device pass: bounds the f64 slab to ROW_CHUNK x N
 
+# ---- phase timing (R4D_PHASE_TIMING=1): where the wall clock of an annotation run goes -- parse, CSR pack + upload, device
+# work (Jaccard, rankings, selections), download, text formatting + file writes.  Off by default (the syncs it adds are the
+# only cost); tools/annotation_e2e.py prints the table next to the CPU oracle's time.
+import contextlib
+import time
+
+PHASES = {}
+_TIMING = os.environ.get("R4D_PHASE_TIMING") == "1"
+
+
+@contextlib.contextmanager
+def phase(name):
+    if not _TIMING:
+        yield
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        PHASES[name] = PHASES.get(name, 0.0) + time.perf_counter() - t0
+
+
 
 def get_input_seq(seq):
     """``retrieval_data_annotation.py:17-20`` -- keeps the ego id and the <|timeK|> tokens."""
@@ -84,11 +110,12 @@ def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CH
     lo, hi = (0, n) if rows is None else rows
     for r0 in range(lo, hi, chunk):
         r1 = min(hi, r0 + chunk)
-        p, ix = _slice_csr(target_csr[0], target_csr[1], r0, r1)
-        m = ops.jaccard(p, ix, source_csr[0], source_csr[1], vocab, False)
-        if zero_diag:
-            ar = torch.arange(r1 - r0, device=m.device)
-            m[ar, ar + r0] = 0.0
+        with phase("device: jaccard"):
+            p, ix = _slice_csr(target_csr[0], target_csr[1], r0, r1)
+            m = ops.jaccard(p, ix, source_csr[0], source_csr[1], vocab, False)
+            if zero_diag:
+                ar = torch.arange(r1 - r0, device=m.device)
+                m[ar, ar + r0] = 0.0
         yield r0, m
 
 
@@ -96,22 +123,30 @@ def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_
     """``retrieval_data_annotation.py:88-93``: full ranking (canonical stable order) + every score, as text."""
     with open(save_index_file, 'w') as f, open(save_score_file, 'w') as g:
         for _r0, m in iter_row_chunks(target_csr, source_csr, vocab, rows=rows):
-            indices = ops.argsort_desc(m).cpu().numpy()
-            mh = m.cpu().numpy()
-            for i in range(mh.shape[0]):
-                f.write(' '.join([str(x) for x in indices[i]]) + '\n')
-                g.write(' '.join([str(x) for x in mh[i]]) + '\n')
+            with phase("device: full-row argsort"):
+                perm = ops.argsort_desc(m)
+            with phase("download"):
+                indices = perm.cpu().numpy()
+                mh = m.cpu().numpy()
+            with phase("text: format + write"):
+                # python scalars format ~3x faster than numpy scalars and print the same shortest round-trip digits
+                for ind_row, sc_row in zip(indices.tolist(), mh.tolist()):
+                    f.write(' '.join(map(str, ind_row)) + '\n')
+                    g.write(' '.join(map(str, sc_row)) + '\n')
 
 
 def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk=10, rows=None):
     """``retrieval_data_annotation.py:97-103``: top-10 GT demonstrations of train x train (diag zeroed)."""
     with open(save_file_index, 'w') as f_index, open(save_file_score, 'w') as f_score:
         for _r0, m in iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True, rows=rows):
-            vals, idx = ops.topk_f64(m, min(topk, m.shape[1]))
-            vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
-            for i in range(idx.shape[0]):
-                f_index.write(' '.join(map(str, idx[i])) + '\n')
-                f_score.write(' '.join(map(str, vals[i])) + '\n')
+            with phase("device: top-10"):
+                vals, idx = ops.topk_f64(m, min(topk, m.shape[1]))
+            with phase("download"):
+                vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+            with phase("text: format + write"):
+                for ind_row, sc_row in zip(idx.tolist(), vals.tolist()):
+                    f_index.write(' '.join(map(str, ind_row)) + '\n')
+                    f_score.write(' '.join(map(str, sc_row)) + '\n')
 
 
 def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False, rows=None):
@@ -120,28 +155,31 @@ def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dial
     similarities (the reference's order is tie-dependent)."""
     gen_in = iter_row_chunks(in_csr, in_csr, vocab, zero_diag=True, rows=rows)
     for (r0, m_out), (_r0b, m_in) in zip(iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True, rows=rows), gen_in):
-        has_pos = (m_out > threshold).any(dim=1)
-        rows = torch.nonzero(has_pos).flatten()
-        if rows.numel() == 0:
-            continue
-        order = ops.argsort_desc(m_in[rows].contiguous()).cpu().numpy()
-        mo = m_out[rows].cpu().numpy()
+        with phase("device: positives + argsort of the input-set rows"):
+            has_pos = (m_out > threshold).any(dim=1)
+            rows = torch.nonzero(has_pos).flatten()
+            if rows.numel() == 0:
+                continue
+            order_d = ops.argsort_desc(m_in[rows].contiguous()).long()
+            # the five negative candidates of every anchor row at once (index glue on the device; was a python loop over the
+            # ranked pool per row: 0.8 s of a 1.2 s hepth run): walk the row's stable ranking of the input-set similarities,
+            # first the non-positive entries with an output score > 0, then -- only if fewer than neg_num -- those with score 0
+            ro = torch.gather(m_out[rows], 1, order_d)                       # output scores in ranking order
+            notpos = ~(ro > threshold)
+            cls = torch.where(notpos & (ro > 0), 0, torch.where(notpos & (ro == 0), 1, 2))
+            npool = ro.shape[1]
+            key = cls * npool + torch.arange(npool, device=ro.device)[None, :]
+            kk = min(neg_num, npool)
+            best = torch.topk(key, kk, dim=1, largest=False, sorted=True).values
+            neg_idx_d = torch.gather(order_d, 1, best % npool)
+            neg_cnt_d = (best < 2 * npool).sum(dim=1)
+        with phase("download"):
+            mo = m_out[rows].cpu().numpy()
+            neg_idx, neg_cnt = neg_idx_d.cpu().numpy(), neg_cnt_d.cpu().numpy()
         for r, i_local in enumerate(rows.tolist()):
             row = mo[r]
             pos = np.where(row > threshold)[0].tolist()
-            pos_set = set(pos)
-            negs = []
-            for idx in order[r]:
-                if idx not in pos_set and row[idx] > 0:
-                    negs.append(int(idx))
-                if len(negs) == neg_num:
-                    break
-            if len(negs) < neg_num:
-                for idx in order[r]:
-                    if idx not in pos_set and row[idx] == 0:
-                        negs.append(int(idx))
-                    if len(negs) == neg_num:
-                        break
+            negs = [int(x) for x in neg_idx[r, :int(neg_cnt[r])]]
             if dialog:
                 pos = pos[:4]
             yield r0 + i_local, pos, negs, row
@@ -211,6 +249,7 @@ def main(argv):
     save_path_gen = os.path.join('./resources/train_generator', dataset, str(timestamp), "train_gt_topk")
     os.makedirs(save_path_gen, exist_ok=True)
     base = os.path.join('resources', dataset, timestamp)
+    _t_parse = time.perf_counter()
     train_data = read_lines(os.path.join(base, 'train.link_prediction'))
     test_data = read_lines(os.path.join(base, 'test.link_prediction'))
     test_gt = read_lines(os.path.join(base, 'test_gt.link_prediction'))
@@ -219,11 +258,14 @@ def main(argv):
     train_in, train_out = get_inout_list(train_data, train_data)
     _, test_out = get_inout_list(test_data, test_gt)
     _, val_out = get_inout_list(val_data, val_gt)
+    if _TIMING:
+        PHASES["host: read + parse the five text files"] = time.perf_counter() - _t_parse
     table = SetTable()
-    tr_out = table.pack(train_out, device)
-    tr_in = table.pack(train_in, device)
-    te_out = table.pack(test_out, device)
-    va_out = table.pack(val_out, device)
+    with phase("host: token map + CSR pack + upload"):
+        tr_out = table.pack(train_out, device)
+        tr_in = table.pack(train_in, device)
+        te_out = table.pack(test_out, device)
+        va_out = table.pack(val_out, device)
     vocab = len(table.vocab)
     seed = [int(np.random.randint(0, 2 ** 31 - 1))]
     if world > 1:

@@ -19,6 +19,7 @@ from torch.utils.data import DataLoader
 from . import ops
 from .dataloader import LineByLineTextDatasetHistory, get_dataloader, load_and_cache_examples
 from .retrieval import PoolIndex, encode_batches
+from .annotation import PHASES, phase            # R4D_PHASE_TIMING=1: wall-clock breakdown (tools/annotation_e2e.py)
 
 
 def hit_rate_at_k(predictions, targets, k=1):
@@ -37,10 +38,11 @@ def save_index_score(index_rows, score_matrix, save_index_file, save_score_file,
     what ``read_matrix_rows`` (and through it this build's generator stage) loads when it is present and complete."""
     import json
     mode = 'w' if steps == 0 else 'a'
-    with open(save_index_file, mode) as f, open(save_score_file, mode) as g:
-        for i in range(score_matrix.shape[0]):
-            f.write(' '.join([str(x) for x in index_rows[i]]) + '\n')
-            g.write(' '.join([f"{x:.4f}" for x in score_matrix[i]]) + '\n')
+    with phase("text: format + write (*.gen, file-compatible)"):
+        with open(save_index_file, mode) as f, open(save_score_file, mode) as g:
+            for ind_row, sc_row in zip(np.asarray(index_rows).tolist(), np.asarray(score_matrix, dtype=np.float64).tolist()):
+                f.write(' '.join(map(str, ind_row)) + '\n')
+                g.write(' '.join([f"{x:.4f}" for x in sc_row]) + '\n')
     for path, arr, dt in ((save_index_file, index_rows, np.int32), (save_score_file, score_matrix, np.float32)):
         a = np.ascontiguousarray(arr, dtype=dt)
         meta_path = path + ".bin.json"
@@ -49,8 +51,9 @@ def save_index_score(index_rows, score_matrix, save_index_file, save_score_file,
             meta = json.load(open(meta_path))
             if meta["cols"] != a.shape[1] or meta["dtype"] != np.dtype(dt).name:
                 raise ValueError(f"{path}.bin: row layout changed between steps")
-        with open(path + ".bin", 'wb' if steps == 0 else 'ab') as h:
-            h.write(a.tobytes())
+        with phase("binary side-car write"):
+            with open(path + ".bin", 'wb' if steps == 0 else 'ab') as h:
+                h.write(a.tobytes())
         meta["rows"] += int(a.shape[0])
         with open(meta_path, "w") as h:
             json.dump(meta, h)
@@ -77,6 +80,8 @@ def _unwrap(model):
 @torch.no_grad()
 def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
     test_mode = False if evaluate else True
+    import time as _time
+    _t_host = _time.perf_counter()
     eval_dataset = load_and_cache_examples(args, tokenizer, evaluate=evaluate, test=test_mode)
     if args.local_rank in [-1, 0]:
         os.makedirs(args.output_dir, exist_ok=True)
@@ -99,6 +104,9 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
         rows = [line for line in f.read().splitlines() if (len(line) > 0 and not line.isspace())]
     scores = torch.Tensor([list(map(float, item.split())) for item in rows])      # float32, as the reference (:409-410)
     scores = DataLoader(scores, batch_size=args.eval_batch_size, shuffle=False, num_workers=0, drop_last=False)
+    if os.environ.get("R4D_PHASE_TIMING") == "1":
+        PHASES["host: tokenise pool + queries, read the ground-truth score rows"] = \
+            PHASES.get("host: tokenise pool + queries, read the ground-truth score rows", 0.0) + _time.perf_counter() - _t_host
 
     # HOT LOOP 1 (:414-422): pool embeddings, then one resident normalised index
     import torch.distributed as tdist
@@ -109,7 +117,8 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
         train_embeddings = encode_pool_sharded(lambda bs: encode_batches(model, [b.to(device) for b in bs]),
                                                list(train_dataloader))
     else:
-        train_embeddings = encode_batches(model, [batch.to(device) for batch in train_dataloader])    # fused groups
+        with phase("device: upload + encode the pool"):
+            train_embeddings = encode_batches(model, [batch.to(device) for batch in train_dataloader])    # fused groups
     print('size of train_embeddings: ', train_embeddings.size())
     index = PoolIndex(train_embeddings)
     n_pool = len(index)
@@ -123,22 +132,29 @@ def test(epoch, args, model, tokenizer, evaluate=True, prefix=""):
 
     # HOT LOOP 2 (:425-474).  The query batches are encoded up front in fused groups like the pool (every batch keeps
     # its own padding, so each row equals ``model.encode_meanpool(batch)`` of the reference's per-batch call).
-    eval_batches = [batch.to(device) for batch in eval_dataloader]
-    query_embeddings = encode_batches(model, eval_batches)
+    with phase("device: upload + encode the queries"):
+        eval_batches = [batch.to(device) for batch in eval_dataloader]
+        query_embeddings = encode_batches(model, eval_batches)
     row = 0
     for batch, score in zip(eval_batches, scores):
         h_egos = query_embeddings[row:row + batch.shape[0]]
         row += batch.shape[0]
-        score = score.to(device)
-        _vals, top_idx, dot_products = index.search(h_egos, topk, want_scores=True)
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(dot_products, score)      # metric only (:439-441)
-        eval_loss += loss
+        with phase("device: scan + top-k + BCE metric"):
+            score = score.to(device)
+            _vals, top_idx, dot_products = index.search(h_egos, topk, want_scores=True)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(dot_products, score)      # metric only (:439-441)
+            eval_loss += loss
         if prefix == "best" and rank0:
             if rank_output == "full":
-                index_rows = ops.argsort_desc(dot_products).cpu().numpy()
+                with phase("device: full-row argsort (file-compatible ranking)"):
+                    perm = ops.argsort_desc(dot_products)
+                with phase("download"):
+                    index_rows = perm.cpu().numpy()
             else:
                 index_rows = top_idx.cpu().numpy()
-            save_index_score(index_rows, dot_products.cpu().numpy(), save_index_file, save_score_file, nb_eval_steps)
+            with phase("download"):
+                dp_host = dot_products.cpu().numpy()
+            save_index_score(index_rows, dp_host, save_index_file, save_score_file, nb_eval_steps)
         # hit@1 / hit@3 against the top-3 of the float32 Jaccard rows (:458-474), canonical tie-break on both sides
         _, gt3 = ops.topk_f32(score.contiguous(), min(3, n_pool))
         gt3, pred = gt3.cpu().numpy(), top_idx.cpu().numpy()

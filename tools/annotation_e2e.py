@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""GPU box: END-TO-END wall clock of the two CLIs a user actually waits for, with a phase breakdown (VERDICT r2 missing 4):
+
+  annotation : ``retrieval_data_annotation.py hepth 11 0.8`` -- the reference's hepth/11 set families rebuilt as
+               .link_prediction text from the G5 fixture (same parsed sets: 3,965 training histories, 305 test, 240
+               validation; the reference tree does not exist on the GPU box), all eight output files; beside it the CPU
+               oracle's time for the four Jaccard matrices alone (single thread, python sets, as the reference computes them).
+  retriever  : ``main_retriever.py --do_eval`` on the real UCI_13/12 files rebuilt from the G6 / G5 fixtures (1,708-history
+               pool, 110 test queries), file-compatible text output and the binary side-car.
+
+    R4D_PHASE_TIMING=1 python tools/annotation_e2e.py [annotation] [retriever]     -> one JSON line per run
+"""
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+
+os.environ.setdefault("R4D_PHASE_TIMING", "1")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def hepth_workdir(root):
+    g = np.load(os.path.join(GOLD, "g5_jaccard_hepth.npz"))
+    tok = [str(t) for t in g["vocab_tokens"]]
+
+    def sets(ptr, idx):
+        return [[tok[j] for j in idx[ptr[i]:ptr[i + 1]]] for i in range(len(ptr) - 1)]
+    tr_in, tr_out = sets(g["tr_in_ptr"], g["tr_in_idx"]), sets(g["tr_out_ptr"], g["tr_out_idx"])
+    te_out, va_out = sets(g["te_out_ptr"], g["te_out_idx"]), sets(g["va_out_ptr"], g["va_out_idx"])
+    base = os.path.join(root, "resources", "hepth", "11")
+    os.makedirs(base)
+
+    def line(hist, pre):
+        return ("<|endoftext|> <|history|> " + " ".join(hist) + " <|endofhistory|> <|pre|> <|time11|> " + " ".join(pre) +
+                " <|endofpre|> <|endoftext|>")
+    open(os.path.join(base, "train.link_prediction"), "w").write("\n".join(line(a, b) for a, b in zip(tr_in, tr_out)) + "\n")
+    for name, outs in (("test", te_out), ("val", va_out)):
+        open(os.path.join(base, f"{name}.link_prediction"), "w").write("\n".join(line(["0"], []) for _ in outs) + "\n")
+        open(os.path.join(base, f"{name}_gt.link_prediction"), "w").write("\n".join(line(["0"], o) for o in outs) + "\n")
+    return tr_in, tr_out, te_out, va_out
+
+
+def run_annotation():
+    import torch
+    from oracle import jaccard_ref
+    from rag4dyg_amd import annotation
+    root = tempfile.mkdtemp(prefix="r4d_ann_")
+    tr_in, tr_out, te_out, va_out = hepth_workdir(root)
+    os.chdir(root)
+    np.random.seed(0)
+    annotation.main(["retrieval_data_annotation.py", "hepth", "11", "0.8"])          # warm-up: library load, first launches
+    annotation.PHASES.clear()
+    np.random.seed(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        annotation.main(["retrieval_data_annotation.py", "hepth", "11", "0.8"])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(root, "resources")) for f in fs
+                    if f.endswith((".retrieval", ".gen")))
+    t1 = time.perf_counter()                                                           # CPU oracle: the four matrices only
+    for tgt, src in ((tr_out, tr_out), (tr_in, tr_in), (te_out, tr_out), (va_out, tr_out)):
+        jaccard_ref.occurrence_matrix(tgt, src)
+    cpu = time.perf_counter() - t1
+    pairs = 2 * len(tr_out) ** 2 + (len(te_out) + len(va_out)) * len(tr_out)
+    print(json.dumps({"run": "retrieval_data_annotation.py hepth 11 0.8", "sets": {"train": len(tr_out), "test": len(te_out), "val": len(va_out)},
+                      "wall_s": round(wall, 3), "phases_s": {k: round(v, 4) for k, v in sorted(annotation.PHASES.items())},
+                      "unaccounted_s": round(wall - sum(annotation.PHASES.values()), 4), "output_bytes": out_bytes,
+                      "jaccard_pairs": pairs,
+                      "cpu_oracle_four_matrices_s": round(cpu, 2), "cpu_oracle_pairs_per_s": round(pairs / cpu, 0),
+                      "note": "train x train output sets are computed twice (annotation triples, top-10 file) as upstream does"}), flush=True)
+
+
+def run_retriever():
+    import torch
+    import train_uci13_demo as demo
+    from rag4dyg_amd import retriever
+    root = tempfile.mkdtemp(prefix="r4d_ret_")
+    base, ret = demo.build_workdir(root)
+    os.chdir(root)
+    import main_retriever
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    from rag4dyg_amd.tokenizer import get_model_tokenizer            # noqa: F401
+    # a checkpoint to evaluate: random-init UCI_13 configuration saved in the reference layout
+    out = os.path.join(root, "out")
+    argv = (f"--dataset UCI_13 --timestamp 12 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
+            f"--train_data_file {base}/train.link_prediction --eval_data_file {base}/val.link_prediction "
+            f"--eval_data_gt_file {ret}/val_score.retrieval --test_data_file {base}/test.link_prediction "
+            f"--test_data_gt_file {ret}/test_score.retrieval --n_layer 4 --n_head 2 --n_embed 512 --block_size 512 --seed 42 --topK 5 "
+            f"--train_pair_data_file {ret}/train_index.retrieval --num_train_epochs 1 --per_gpu_train_batch_size 64 --do_train --patience 50").split()
+    with redirect_stdout(io.StringIO()):
+        main_retriever.main(argv)                                                      # one training epoch -> checkpoints to evaluate
+    ev = [a for a in argv if a != "--do_train"] + ["--do_eval", "--eval_all_checkpoints"]
+    with redirect_stdout(io.StringIO()):
+        main_retriever.main(ev)                                                        # warm-up (library load, caches)
+    retriever.PHASES.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        main_retriever.main(ev)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({"run": "main_retriever.py --do_eval --eval_all_checkpoints (UCI_13/12 files: pool 1708, 146 val + 110 test queries, "
+                             "two checkpoints; file-compatible full rankings as text + binary side-car)",
+                      "wall_s": round(wall, 3), "phases_s": {k: round(v, 4) for k, v in sorted(retriever.PHASES.items())},
+                      "unaccounted_s": round(wall - sum(retriever.PHASES.values()), 4),
+                      "reference_cpu_s_for_one_checkpoint": "18.98 (pool encode) + 5.60 (110 queries) on this image's CPU cores, BASELINE.md"}), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["annotation"]
+    if "annotation" in what:
+        run_annotation()
+    if "retriever" in what:
+        run_retriever()
