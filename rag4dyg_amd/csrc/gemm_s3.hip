@@ -22,10 +22,14 @@
 // == 0 is a precondition; register-staged pipeline with NBUF LDS stages and one barrier per k-tile.
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "common.h"
 
 #ifndef S3_NRS
 #define S3_NRS 1   // register stages of the 128 x 256 tile; 2 measured no faster (K = 512: 157-166 vs 163-168 TFLOP/s, 240 vs 206 VGPRs): the k-tile loads are not latency-bound
+#endif
+#ifndef S3_EPI_LDS
+#define S3_EPI_LDS 0   // 1: interior tiles leave through LDS as whole rows (16 dwordx4 stores per lane instead of 64 dword stores). Measured: NO change (K = 512: 608 vs 607, 711 vs 708, 191 vs 194 us) -- the epilogue is not store-issue-bound; kept switchable
 #endif
 #ifndef S3_DBG
 #define S3_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 4 only the split arithmetic
@@ -326,6 +330,52 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     // epilogue: the one of gemm_f32_kc.hip (C/D layout is dtype-independent: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
+#if S3_EPI_LDS
+    if (interior && ((g.ldc | g.ldr) & 3) == 0 && ((uintptr_t)Cg & 15) == 0 && ((uintptr_t)residg & 15) == 0 && ((uintptr_t)biasg & 15) == 0) {
+        // Interior tiles: the wave's WM x WN accumulator block goes through ITS OWN region of the (now idle) LDS stages and comes
+        // back as whole rows, so that the tile leaves with 16-byte stores covering 256 contiguous bytes per row (64 dword stores
+        // per lane in the accumulator layout -> 16 dwordx4; the residual is read the same way).  No barrier: a wave reads only
+        // what it wrote, and LDS operations of one wave complete in order.  [WM][WN] floats, unpadded: conflict-free for the
+        // ds_write_b32 (32 consecutive columns per half-wave) and for the ds_read_b128 (16-lane groups cover 64 distinct banks).
+        static_assert(NBUF * STAGE * 16 >= WGM * WGN * WM * WN * 4, "epilogue staging fits the LDS stages");
+        float* reg = reinterpret_cast<float*>(lds) + wid * (WM * WN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    reg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + li] = acc[i][j][r];
+        constexpr int LPR = WN / 4, RPP = 64 / LPR, NPASS = WM / RPP;     // lanes per row, rows per pass, passes
+        const int er = lane / LPR, ec = 4 * (lane % LPR);
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (long long)(m0 + wm * WM) * g.ldc + n0 + wn * WN, 0, ((WM - 1) * g.ldc + WN) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)(m0 + wm * WM) * g.ldr + n0 + wn * WN : Ag), 0,
+            EPI == EPI_RESIDUAL ? ((WM - 1) * g.ldr + WN) * 4 : 0, 0x00020000);
+        const int lane_c = (er * g.ldc + ec) * 4, lane_r = (er * g.ldr + ec) * 4;
+        f32x4s bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (biasg) bias4 = *reinterpret_cast<const f32x4s*>(biasg + n0 + wn * WN + ec);
+        u32x4s res4[NPASS];
+        if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) res4[ps] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, lane_r, ps * RPP * g.ldr * 4, 0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            f32x4s v = *reinterpret_cast<const f32x4s*>(reg + (ps * RPP + er) * WN + ec);
+            v = v + bias4;
+            if (EPI == EPI_GELU) {
+                const f32x2s lo_ = gelu_new_s3(f32x2s{v[0], v[1]}), hi_ = gelu_new_s3(f32x2s{v[2], v[3]});
+                v = f32x4s{lo_[0], lo_[1], hi_[0], hi_[1]};
+            } else if (EPI == EPI_RESIDUAL) {
+                v = v + __builtin_bit_cast(f32x4s, res4[ps]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), c_rsrc, lane_c, ps * RPP * g.ldc * 4, 0);
+        }
+        return;
+    }
+#endif
     if (interior) {
         const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
         const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
@@ -389,6 +439,244 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- persistent form of the 128 x 256 tile
+// One workgroup per CU walks tiles v, v + G, v + 2G ... (G = grid size, a multiple of 8: the XCD of a tile sequence is fixed)
+// and the k-loop pipeline runs ACROSS tile boundaries: the last two iterations of a tile request and stage the first two
+// k-tiles of the NEXT tile, so a tile starts with its operands already in LDS / in flight instead of behind a workgroup
+// launch and two exposed memory latencies, and the epilogue's stores (younger than those loads in the in-order vmcnt queue)
+// drain under the next tile's first iterations.  At K = 512 a 128 x 256 tile is only 16 iterations long: launch, prologue
+// and epilogue were ~14 us of a 51 us tile (tools/s3_bench.py, S3_DBG ablations).  Requires an even number of k-tiles.
+// Tiles beyond the first one per workgroup are handed out DYNAMICALLY (a static stride loses the balancing a launch's own
+// dispatcher gives: measured 8-17 % slower at 4 tiles per CU): eight ticket counters, one per XCD class (blockIdx & 7), so a
+// workgroup keeps drawing tiles whose operands its XCD's L2 already holds; the ticket of the tile after next is requested a
+// whole tile ahead (one atomic per tile and workgroup, latency hidden).  The counters of a launch live in one of 64 slots
+// (host round-robin: launches on different streams do not share one); the last workgroup to leave resets its slot, so every
+// slot is zero whenever a launch starts -- no memset in the stream.
+__device__ unsigned g_s3p_slots[64][16];
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
+    const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
+    const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g, const int ntiles, const int slot) {
+    constexpr int BM = 128, BN = 256, BK = 32, WGN = 4, WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int NIB = 2;                                            // (row, chunk) items of the W tile per thread (A: one)
+    constexpr int A_PLANE = BM * 4, B_PLANE = BN * 4, STAGE = 3 * (A_PLANE + B_PLANE);
+    __shared__ u32x4s lds[2 * STAGE];
+    __shared__ int s_next;                                            // virtual index of the tile AFTER the current one
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nkt = g.K / BK;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    unsigned* const tickets = g_s3p_slots[slot];
+    const int cls = blockIdx.x & 7, G = (int)gridDim.x;
+    // XCD-aware grouped tile order over the VIRTUAL block index v (v & 7 == blockIdx.x & 7 for every tile of this workgroup)
+    auto origin = [&](int v, int& m0, int& n0) {
+        const int xq = ntiles >> 3, xr = ntiles & 7, xcd = v & 7;
+        const int bid = xcd * xq + min(xcd, xr) + (v >> 3);
+        constexpr int GROUP_M = 8;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = bid / per_group, first_m = grp * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM;
+        n0 = ((bid % per_group) / gsz) * BN;
+    };
+    const int st_row = tid >> 2, st_c = tid & 3;                      // staging item: row, 8-k chunk (A: rows 0..127; W: + 128)
+    const int st_dst = st_row * 4 + (st_c ^ ((st_row >> 2) & 3));
+    auto offsets = [&](int m0, int n0, int& ao, int (&bo)[NIB]) {
+        ao = (min(m0 + st_row, g.M - 1) * g.lda + st_c * 8) * 4;
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) bo[i] = (min(n0 + st_row + i * 128, g.N - 1) * g.K + st_c * 8) * 2;
+    };
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
+    u32x4s ra[2], rb[NIB][3];
+#define P_LOAD(AO, BO, KT)                                                                         \
+    {                                                                                              \
+        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, AO, (KT) * (BK * 4), 0);             \
+        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, AO + 16, (KT) * (BK * 4), 0);        \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                          \
+                rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, BO[i], (KT) * (BK * 2) + p * g.plane_bytes, 0); \
+    }
+#define P_STORE(STG)                                                                               \
+    {                                                                                              \
+        u32x4s* sa_ = lds + (STG) * STAGE + st_dst;                                                \
+        u32x4s h_, m_, l_;                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+            const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[q >> 1]);                            \
+            unsigned hh_, mm_, ll_;                                                                \
+            split3_pair(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, mm_, ll_);                  \
+            h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                                 \
+        }                                                                                          \
+        sa_[0] = h_; sa_[A_PLANE] = m_; sa_[2 * A_PLANE] = l_;                                     \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) sa_[3 * A_PLANE + p * B_PLANE + i * 512] = rb[i][p]; \
+    }
+    const int fq = (li >> 2) & 3;
+    const int f_off0 = li * 4 + ((0 + lh) ^ fq), f_off1 = li * 4 + ((2 + lh) ^ fq);
+    const int fa_base = wm * WM * 4, fb_base = 3 * A_PLANE + wn * WN * 4;
+    u32x4s fa[2][TM][3], fb[2][TN][3];
+    f32x16s acc[TM][TN];
+#define P_FRAGS(SET, STG, S)                                                                       \
+    {                                                                                              \
+        const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
+        const int fo_ = (S) ? f_off1 : f_off0;                                                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][2] = st_[fa_base + 2 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = st_[fb_base + 0 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = st_[fa_base + 0 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][2] = st_[fb_base + 2 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = st_[fa_base + 1 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = st_[fb_base + 1 * B_PLANE + j * 128 + fo_]; \
+    }
+#define P_MFMA(A_, B_, I_, J_) \
+    acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
+#define P_MFMAS(SET)                                                                               \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][2], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][0], fb[SET][j][2], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][1], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][1], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][0], fb[SET][j][1], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) P_MFMA(fa[SET][i][0], fb[SET][j][0], i, j); \
+    }
+    // same pinned interleaving as gemm_s3_kernel: k-step 0's MFMAs over the reads of k-step 1, the split and the LDS stores;
+    // k-step 1's MFMAs over the global loads
+#define P_ITER(CUR, WR, AO, BO, KTL)                                                               \
+    {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        P_FRAGS(0, CUR, 0)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        P_STORE(WR)                                                                                \
+        P_FRAGS(1, CUR, 1)                                                                         \
+        P_MFMAS(0)                                                                                 \
+        _Pragma("unroll") for (int m_ = 0; m_ < 24; ++m_) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
+            if (m_ >= 6 && ((23 - m_) & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        P_LOAD(AO, BO, KTL)                                                                        \
+        P_MFMAS(1)                                                                                 \
+        _Pragma("unroll") for (int m_ = 0; m_ < 24; ++m_) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        __syncthreads();                                                                           \
+    }
+
+    int m0, n0;
+    origin((int)blockIdx.x, m0, n0);
+    int ao, bo[NIB], aon, bon[NIB];
+    offsets(m0, n0, ao, bo);
+    P_LOAD(ao, bo, 0)
+    if (tid == 0) s_next = G + 8 * (int)__hip_atomic_fetch_add(&tickets[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + cls;
+    P_STORE(0)
+    P_LOAD(ao, bo, 1)
+    __syncthreads();
+    for (;;) {
+        const int vn = s_next;                                        // drawn one tile ago; every wave reads it before the tile's first barrier
+        const bool has_next = vn < ntiles;                            // workgroup-uniform
+        unsigned tk = 0;
+        if (tid == 0 && has_next) tk = __hip_atomic_fetch_add(&tickets[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int m0n, n0n;
+        origin(has_next ? vn : (int)blockIdx.x, m0n, n0n);
+        offsets(m0n, n0n, aon, bon);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        int kt = 0;
+        for (; kt + 2 < nkt; kt += 2) {
+            P_ITER(0, 1, ao, bo, kt + 2)
+            P_ITER(1, 0, ao, bo, kt + 3)
+        }
+        // the tile's last two iterations stage and request the NEXT tile's k-tiles 0 and 1 (its own again when there is none)
+        P_ITER(0, 1, aon, bon, 0)
+        if (tid == 0) s_next = has_next ? G + 8 * (int)tk + cls : ntiles;      // behind >= 1 barrier of this tile, published by the next
+        P_ITER(1, 0, aon, bon, 1)
+
+        // epilogue (accumulator layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) per 32 x 32 tile)
+        const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);
+        if (interior) {
+            const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
+            const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
+            const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                Cg + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+                EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float res[16];
+                    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; r2 += 2) {
+                        f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
+                        if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
+                        else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int r = r2 + h2;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, h2 ? v2.y : v2.x), c_rsrc, lane_c,
+                                                                  ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {                           // edge tiles: clamped reads, guarded stores
+                const int col = n0 + wn * WN + j * 32 + li;
+                const bool col_ok = col < g.N;
+                const int colc = min(col, g.N - 1);
+                const float bias = biasg ? biasg[colc] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float vv = acc[i][j][r] + bias;
+                        if (EPI == EPI_GELU) vv = gelu_new_s3_1(vv);
+                        else if (EPI == EPI_RESIDUAL) vv += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
+                        if (row < g.M && col_ok) Cg[(long long)row * g.ldc + col] = vv;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        m0 = m0n; n0 = n0n; ao = aon;
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) bo[i] = bon[i];
+    }
+    if (tid == 0) {                                                   // last workgroup out resets the slot for its next launch
+        if (__hip_atomic_fetch_add(&tickets[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(&tickets[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#undef P_ITER
+#undef P_MFMAS
+#undef P_MFMA
+#undef P_FRAGS
+#undef P_STORE
+#undef P_LOAD
 }
 
 // ---------------------------------------------------------------------------------------------- 4-wave form, two workgroups per CU
@@ -646,7 +934,36 @@ static int launch_s3w4(const S3Args& a, hipStream_t stream) {
     return R4D_OK;
 }
 
+static int launch_s3p(const S3Args& a, hipStream_t stream) {
+    const int ntiles = cdiv(a.M, 128) * cdiv(a.N, 256);
+    ProfScope prof(PK_GEMM_S3_128x256, 2.0 * (double)a.M * a.N * a.K, stream);
+    S3Shape sh;
+    sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
+    const int grid = 256;                                            // one workgroup per CU (144 KB of LDS each); ntiles > 256 here
+    static std::atomic<unsigned> seq{0};
+    const int slot = (int)(seq.fetch_add(1) % 64u);
+#define SP_LAUNCH_(E) hipLaunchKernelGGL((gemm_s3p_kernel<E>), dim3(grid), dim3(512), 0, stream, a.A, a.planes, a.C, a.bias, a.resid, sh, ntiles, slot)
+    switch (a.epilogue) {
+        case EPI_NONE: SP_LAUNCH_(EPI_NONE); break;
+        case EPI_GELU: SP_LAUNCH_(EPI_GELU); break;
+        case EPI_RESIDUAL: SP_LAUNCH_(EPI_RESIDUAL); break;
+        default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
+    }
+#undef SP_LAUNCH_
+    R4D_CHECK_LAUNCH("gemm_s3p");
+    return R4D_OK;
+}
+
 static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
+    static int pers = -1;
+    if (pers < 0) { const char* e = getenv("R4D_GEMM_S3_PERSISTENT"); pers = e ? atoi(e) : 1; }   // tuning aid: 0 = one launch slot per tile
+    // measured (M = 63232; tools/s3_bench.py): K 512 N 1536 593 -> 576 us, K 512 N 2048 + gelu 689 -> 665 us, M 8864 81 -> 75 us;
+    // with the RESIDUAL epilogue the persistent form is SLOWER (K 512 N 512: 189 -> 227 us, K 2048 N 512: 625 -> 700 us, static and
+    // dynamic tile hand-out alike), so those launches keep one launch slot per tile (pers == 2 forces it for them too)
+    if (t == 0 && pers && (pers == 2 || a.epilogue != EPI_RESIDUAL) && (a.K / 32) % 2 == 0 && cdiv(a.M, 128) * cdiv(a.N, 256) > 256) {
+        R4D_BRANCH(S3_PERSISTENT);
+        return launch_s3p(a, stream);
+    }
     switch (t) { case 0: R4D_BRANCH(S3_128x256); break; case 1: R4D_BRANCH(S3_128x128); break; default: R4D_BRANCH(S3_W4); }
     switch (t) {
         case 0: return launch_s3<128, 256, 2, 4, 2, S3_NRS>(a, kS3[0].cls, stream);

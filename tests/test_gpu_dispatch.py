@@ -54,6 +54,7 @@ def test_every_dispatcher_branch_is_exercised(dev):
     for M, K, N in ((4096, 512, 1536), (333, 2048, 512), (45, 112, 80), (700, 96, 128), (2048, 512, 192), (16384, 512, 2048)):
         conv_check(M, K, N, wt=False)
     conv_check(4096, 512, 1536, wt=False, planes=True)       # gemm_s3 128 x 256
+    conv_check(40000, 64, 1536, wt=False, planes=True)       # > 256 tiles, even k-tile count: the persistent form
     conv_check(4096, 512, 128, wt=False, planes=True)        # gemm_s3 128 x 128 (one column tile of 128)
     h = rnd(9, 48).to(dev)                                    # B as [N,K] with K % 32 != 0: reference-layout kernel, NT form
     wte = rnd(50, 48).to(dev)

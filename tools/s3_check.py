@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from rag4dyg_amd import ops
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-for (M, K, N) in [(128, 32, 256), (130, 64, 100), (257, 512, 513), (1000, 96, 1536)]:
+for (M, K, N) in [(128, 32, 256), (130, 64, 100), (257, 512, 513), (1000, 96, 1536), (40000, 64, 300), (33000, 512, 512), (20000, 128, 1000)]:
     x = torch.randn(M, K, device=dev); w = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev)
     pl = ops.split3_planes(w)
