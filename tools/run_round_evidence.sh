@@ -10,13 +10,15 @@ LOG=$R/gpurun_out/evidence_$TAG.log
 EV=$R/gpurun_out/evidence_$TAG
 mkdir -p $EV
 cd $R
-echo "== profile bench UCI_13" >> $LOG
+echo "== profile bench UCI_13 (bf16x3 GEMMs: the headline)" >> $LOG
 bash tools/profile_bench.sh $TAG >> $LOG 2>&1
+echo "== profile bench UCI_13 (exact-f32 MFMA GEMMs)" >> $LOG
+R4D_PROFILE_GEMM=f32 bash tools/profile_bench.sh ${TAG}f >> $LOG 2>&1
 echo "== profile bench wikiv2" >> $LOG
 R4D_PROFILE_SHAPE=wikiv2 bash tools/profile_bench.sh ${TAG}w >> $LOG 2>&1
 echo "== profile scan" >> $LOG
 bash tools/profile_scan.sh $TAG >> $LOG 2>&1
-cp gpurun_out/profiles_$TAG/* gpurun_out/profiles_${TAG}w/* $EV/
+cp gpurun_out/profiles_$TAG/* gpurun_out/profiles_${TAG}f/* gpurun_out/profiles_${TAG}w/* $EV/
 cp gpurun_out/profiles_$TAG/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 cp gpurun_out/profiles_${TAG}w/${TAG}w_pmc_traffic.json profiles/pmc_traffic_wikiv2.json
 cp gpurun_out/prof_scan_$TAG/pmc_scan.json profiles/pmc_scan.json
@@ -27,6 +29,10 @@ echo "== bench UCI_13" >> $LOG
 python bench.py > $EV/${TAG}_bench_line.json 2>> $LOG
 echo "== bench wikiv2" >> $LOG
 python bench.py --shape wikiv2 > $EV/${TAG}_bench_line_wikiv2.json 2>> $LOG
+echo "== bf16x3 acceptance table + end-to-end CLI timings" >> $LOG
+python tools/s3_acceptance.py > $EV/${TAG}_s3_acceptance.md 2>> $LOG
+python tools/annotation_e2e.py annotation retriever 2>> $LOG | grep "^{" > $EV/${TAG}_cli_end_to_end.jsonl
+python tools/s3_bench.py auto 2>> $LOG | grep "^{" > $EV/${TAG}_s3_gemm_shapes.jsonl
 echo "== components" >> $LOG
 python tools/bench_components.py > $EV/${TAG}_components.jsonl 2>> $LOG
 echo "== profile jaccard" >> $LOG
