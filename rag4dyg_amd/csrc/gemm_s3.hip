@@ -28,9 +28,6 @@
 #ifndef S3_NRS
 #define S3_NRS 1   // register stages of the 128 x 256 tile; 2 measured no faster (K = 512: 157-166 vs 163-168 TFLOP/s, 240 vs 206 VGPRs): the k-tile loads are not latency-bound
 #endif
-#ifndef S3_EPI_LDS
-#define S3_EPI_LDS 0   // 1: interior tiles leave through LDS as whole rows (16 dwordx4 stores per lane instead of 64 dword stores). Measured: NO change (K = 512: 608 vs 607, 711 vs 708, 191 vs 194 us) -- the epilogue is not store-issue-bound; kept switchable
-#endif
 #ifndef S3_DBG
 #define S3_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 4 only the split arithmetic
 #endif
@@ -330,52 +327,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     // epilogue: the one of gemm_f32_kc.hip (C/D layout is dtype-independent: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
-#if S3_EPI_LDS
-    if (interior && ((g.ldc | g.ldr) & 3) == 0 && ((uintptr_t)Cg & 15) == 0 && ((uintptr_t)residg & 15) == 0 && ((uintptr_t)biasg & 15) == 0) {
-        // Interior tiles: the wave's WM x WN accumulator block goes through ITS OWN region of the (now idle) LDS stages and comes
-        // back as whole rows, so that the tile leaves with 16-byte stores covering 256 contiguous bytes per row (64 dword stores
-        // per lane in the accumulator layout -> 16 dwordx4; the residual is read the same way).  No barrier: a wave reads only
-        // what it wrote, and LDS operations of one wave complete in order.  [WM][WN] floats, unpadded: conflict-free for the
-        // ds_write_b32 (32 consecutive columns per half-wave) and for the ds_read_b128 (16-lane groups cover 64 distinct banks).
-        static_assert(NBUF * STAGE * 16 >= WGM * WGN * WM * WN * 4, "epilogue staging fits the LDS stages");
-        float* reg = reinterpret_cast<float*>(lds) + wid * (WM * WN);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    reg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + li] = acc[i][j][r];
-        constexpr int LPR = WN / 4, RPP = 64 / LPR, NPASS = WM / RPP;     // lanes per row, rows per pass, passes
-        const int er = lane / LPR, ec = 4 * (lane % LPR);
-        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            C + (long long)(m0 + wm * WM) * g.ldc + n0 + wn * WN, 0, ((WM - 1) * g.ldc + WN) * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)(m0 + wm * WM) * g.ldr + n0 + wn * WN : Ag), 0,
-            EPI == EPI_RESIDUAL ? ((WM - 1) * g.ldr + WN) * 4 : 0, 0x00020000);
-        const int lane_c = (er * g.ldc + ec) * 4, lane_r = (er * g.ldr + ec) * 4;
-        f32x4s bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (biasg) bias4 = *reinterpret_cast<const f32x4s*>(biasg + n0 + wn * WN + ec);
-        u32x4s res4[NPASS];
-        if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) res4[ps] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, lane_r, ps * RPP * g.ldr * 4, 0);
-        }
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            f32x4s v = *reinterpret_cast<const f32x4s*>(reg + (ps * RPP + er) * WN + ec);
-            v = v + bias4;
-            if (EPI == EPI_GELU) {
-                const f32x2s lo_ = gelu_new_s3(f32x2s{v[0], v[1]}), hi_ = gelu_new_s3(f32x2s{v[2], v[3]});
-                v = f32x4s{lo_[0], lo_[1], hi_[0], hi_[1]};
-            } else if (EPI == EPI_RESIDUAL) {
-                v = v + __builtin_bit_cast(f32x4s, res4[ps]);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), c_rsrc, lane_c, ps * RPP * g.ldc * 4, 0);
-        }
-        return;
-    }
-#endif
     if (interior) {
         const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
         const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
@@ -679,223 +630,13 @@ __global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
 #undef P_LOAD
 }
 
-// ---------------------------------------------------------------------------------------------- 4-wave form, two workgroups per CU
-// 128 x 128 tile, BK = 16, four wavefronts (2 x 2, wave tile 64 x 64), THREE LDS stages of 24 KB (72 KB: two workgroups
-// per CU = two waves per SIMD that belong to DIFFERENT tiles, so one tile's prologue, barrier waits and epilogue sit under
-// the other's MFMAs -- at K = 512 a tile is only 32 k-tiles long and the 8-wave kernel above, alone on its CU, exposes all
-// of that), two register stages (a k-tile's global loads are requested two iterations before they are split and stored).
-// LDS rows are 32 bytes (2 chunks of 8 k), chunk index XOR-ed with (row >> 3) & 1: conflict-free b128 reads and writes.
-// Iteration kt:  MFMAs of k-tile kt (fragment set kt & 1, read during iteration kt-1 -- legal before that iteration's
-// barrier: stage kt % 3 was stored in iteration kt-2);  between them the reads of k-tile kt+1 into the other fragment
-// set, the split + LDS stores of k-tile kt+2 (register set kt & 1) into stage (kt+2) % 3 [last read in iteration kt-1],
-// and the global loads of k-tile kt+4 into the same register set;  one barrier.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_s3w4_kernel(
-    const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
-    const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
-    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2, WM = 64, WN = 64;
-    constexpr int A_PLANE = BM * 2, B_PLANE = BN * 2;                 // uint4 units (a row = 2 chunks of 16 bytes)
-    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);                    // 1536 uint4 = 24 KB
-    __shared__ u32x4s lds[3 * STAGE];
-
-    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
-    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-    constexpr int GROUP_M = 8;
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nkt = g.K / BK;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
-
-    // staging: thread -> (row = tid >> 1, chunk = tid & 1) of the A tile AND of the W tile (three planes)
-    const int st_row = tid >> 1, st_c = tid & 1;
-    const int a_off = (min(m0 + st_row, g.M - 1) * g.lda + st_c * 8) * 4;
-    const int b_off = (min(n0 + st_row, g.N - 1) * g.K + st_c * 8) * 2;
-    const int st_dst = st_row * 2 + (st_c ^ ((st_row >> 3) & 1));
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
-
-    u32x4s ra[2][2], rb[2][3];                                        // two register stages
-#define W4_LOAD(RS, KT)                                                                            \
-    {                                                                                              \
-        const int kt_ = min((KT), nkt - 1);                                                        \
-        ra[RS][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off, kt_ * (BK * 4), 0);       \
-        ra[RS][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off + 16, kt_ * (BK * 4), 0);  \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                              \
-            rb[RS][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off, kt_ * (BK * 2) + p * g.plane_bytes, 0); \
-    }
-#define W4_STORE(RS, STG)                                                                          \
-    {                                                                                              \
-        u32x4s* sa_ = lds + (STG) * STAGE + st_dst;                                                \
-        u32x4s h_, m_, l_;                                                                         \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
-            const f32x4s src_ = __builtin_bit_cast(f32x4s, ra[RS][q >> 1]);                        \
-            unsigned hh_, mm_, ll_;                                                                \
-            split3_pair(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, mm_, ll_);                  \
-            h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                                 \
-        }                                                                                          \
-        sa_[0] = h_; sa_[A_PLANE] = m_; sa_[2 * A_PLANE] = l_;                                     \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) sa_[3 * A_PLANE + p * B_PLANE] = rb[RS][p];  \
-    }
-    const int f_off = li * 2 + (lh ^ ((li >> 3) & 1));
-    const int fa_base = wm * WM * 2 + f_off, fb_base = 3 * A_PLANE + wn * WN * 2 + f_off;
-    u32x4s fa[2][TM][3], fb[2][TN][3];
-#define W4_FRAGS(SET, STG)                                                                         \
-    {                                                                                              \
-        const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][2] = st_[fa_base + 2 * A_PLANE + i * 64]; \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = st_[fb_base + 0 * B_PLANE + j * 64]; \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = st_[fa_base + 0 * A_PLANE + i * 64]; \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][2] = st_[fb_base + 2 * B_PLANE + j * 64]; \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = st_[fa_base + 1 * A_PLANE + i * 64]; \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = st_[fb_base + 1 * B_PLANE + j * 64]; \
-    }
-    f32x16s acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#define W4_MFMA(A_, B_, I_, J_) \
-    acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
-#define W4_MFMAS(SET)                                                                              \
-    {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][2], fb[SET][j][0], i, j); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][2], i, j); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][1], fb[SET][j][1], i, j); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][1], fb[SET][j][0], i, j); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][1], i, j); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) W4_MFMA(fa[SET][i][0], fb[SET][j][0], i, j); \
-    }
-
-    // prologue: k-tiles 0 and 1 into stages 0 and 1, k-tiles 2 and 3 into the two register stages, fragments of k-tile 0
-    W4_LOAD(0, 0)
-    W4_LOAD(1, 1)
-    W4_STORE(0, 0)
-    W4_LOAD(0, 2)
-    W4_STORE(1, 1)
-    W4_LOAD(1, 3)
-    __syncthreads();
-    W4_FRAGS(0, 0)
-
-    // one k-tile; SET = kt & 1 (compile time: the loop is unrolled by two), stages rotate at run time
-#define W4_ITER(SET)                                                                               \
-    {                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        W4_STORE(SET, wr)                                                                          \
-        W4_LOAD(SET, kt + 4)                                                                       \
-        W4_FRAGS((SET) ^ 1, nxt)                                                                   \
-        W4_MFMAS(SET)                                                                              \
-        _Pragma("unroll") for (int m_ = 0; m_ < 24; ++m_) {                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-            if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
-            if (m_ >= 12 && m_ < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            \
-            if (m_ >= 18 && m_ < 23) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        __syncthreads();                                                                           \
-        const int t_ = cur; cur = nxt; nxt = wr; wr = t_;                                          \
-    }
-    int cur = 0, nxt = 1, wr = 2;
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-        W4_ITER(0)
-        { ++kt; W4_ITER(1) }
-        --kt;
-    }
-    if (kt < nkt) W4_ITER(0)
-#undef W4_ITER
-#undef W4_MFMAS
-#undef W4_MFMA
-#undef W4_FRAGS
-#undef W4_STORE
-#undef W4_LOAD
-
-    float* __restrict__ C = Cg;
-    const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);
-    if (interior) {
-        const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
-        const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
-        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
-            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                float res[16];
-                if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
-                }
-#pragma unroll
-                for (int r2 = 0; r2 < 16; r2 += 2) {
-                    f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
-                    if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
-                    else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int r = r2 + h2;
-                        const float v = h2 ? v2.y : v2.x;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
-                                                              ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + li;
-        const bool col_ok = col < g.N;
-        const int colc = min(col, g.N - 1);
-        const float bias = biasg ? biasg[colc] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float res[16];
-            if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
-                    res[r] = residg[(long long)row * g.ldr + colc];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[i][j][r] + bias;
-                if (EPI == EPI_GELU) v = gelu_new_s3_1(v);
-                else if (EPI == EPI_RESIDUAL) v += res[r];
-                if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- host side
 struct S3Tile { int bm, bn, cls; double eff; };
 static const S3Tile kS3[] = {
     {128, 256, PK_GEMM_S3_128x256, 1.0},
     {128, 128, PK_GEMM_S3_128x128, 0.9},
-    {128, 128, PK_GEMM_S3_W4_128x128, 0.0},          // 4 waves, two workgroups per CU (eff 0: via R4D_GEMM_S3_TILE=2 until measured)
 };
-constexpr int kNumS3 = 3;
+constexpr int kNumS3 = 2;
 
 template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS>
 static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
@@ -914,23 +655,6 @@ static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
     }
 #undef S3_LAUNCH_
     R4D_CHECK_LAUNCH("gemm_s3");
-    return R4D_OK;
-}
-
-static int launch_s3w4(const S3Args& a, hipStream_t stream) {
-    const int tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
-    ProfScope prof(PK_GEMM_S3_W4_128x128, 2.0 * (double)a.M * a.N * a.K, stream);
-    S3Shape sh;
-    sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
-#define W4_LAUNCH_(E) hipLaunchKernelGGL((gemm_s3w4_kernel<E>), dim3(tiles), dim3(256), 0, stream, a.A, a.planes, a.C, a.bias, a.resid, sh)
-    switch (a.epilogue) {
-        case EPI_NONE: W4_LAUNCH_(EPI_NONE); break;
-        case EPI_GELU: W4_LAUNCH_(EPI_GELU); break;
-        case EPI_RESIDUAL: W4_LAUNCH_(EPI_RESIDUAL); break;
-        default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
-    }
-#undef W4_LAUNCH_
-    R4D_CHECK_LAUNCH("gemm_s3w4");
     return R4D_OK;
 }
 
@@ -964,11 +688,10 @@ static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
         R4D_BRANCH(S3_PERSISTENT);
         return launch_s3p(a, stream);
     }
-    switch (t) { case 0: R4D_BRANCH(S3_128x256); break; case 1: R4D_BRANCH(S3_128x128); break; default: R4D_BRANCH(S3_W4); }
+    if (t == 0) R4D_BRANCH(S3_128x256); else R4D_BRANCH(S3_128x128);
     switch (t) {
         case 0: return launch_s3<128, 256, 2, 4, 2, S3_NRS>(a, kS3[0].cls, stream);
-        case 1: return launch_s3<128, 128, 2, 4, 3, 1>(a, kS3[1].cls, stream);
-        default: return launch_s3w4(a, stream);
+        default: return launch_s3<128, 128, 2, 4, 3, 1>(a, kS3[1].cls, stream);
     }
 }
 

@@ -72,6 +72,8 @@ def bench_class(k):
     m = re.match(r"gemm_s3_kernel<(\d+), (\d+), ", k)
     if m:
         return f"gemm_s3_{m.group(1)}x{m.group(2)}x32"
+    if k.startswith("gemm_s3p_kernel"):                      # persistent form of the same tile: same bench.py class
+        return "gemm_s3_128x256x32"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
