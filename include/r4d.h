@@ -322,8 +322,8 @@ int r4d_topk_f64(const double* m_d, int32_t rows, int32_t n, int32_t k, double* 
 /* ------------------------------------------------------------------------------------------------
  * Retriever TRAINING step.  Replaces, for the encoder, what torch autograd does for the reference in
  * train/train_retriever.py:177-214: five forwards (anchor, positive, hard negative, two augmented views), loss.backward(),
- * clip_grad_norm_, AdamW.  The contrastive losses themselves ([B,3B] / [2B,2B] similarity tables, :40-98) stay with the
- * caller: it receives the mean-pooled embeddings and hands back their gradient.  Dropout is the identity.
+ * clip_grad_norm_, AdamW.  The contrastive losses ([B,3B] / [2B,2B] similarity tables, :40-98) and their gradient on the
+ * mean-pooled embeddings are r4d_retriever_losses_f32 below (round 3; a caller may still substitute its own).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct r4d_gpt2_layer_grads {   /* device pointers, same shapes as r4d_gpt2_layer's reference-layout tensors */
     float* ln_1_w;      float* ln_1_b;
@@ -374,6 +374,15 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
                                 int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
                                 const float* d_meanpool_d, const r4d_train_dropout* dropout,
                                 void* workspace_d, size_t workspace_bytes, void* stream);
+/* The step's loss head on the device (train/train_retriever.py:40-98,196): emb_d f32 [5,B,d] = the mean-pooled embeddings of
+ * anchors, positives, hard negatives and the two augmented views (r4d_gpt2_train_forward_f32's output); t_*_d f32 [B] the query
+ * times of the three sequence families.  losses_d f32[3] <- { CLtime_loss, alpha * info_nce, their sum };  d_emb_d (nullable)
+ * f32 [5,B,d] <- grad_scale * d(sum)/d(emb): what r4d_gpt2_train_backward_f32 takes as d_meanpool_d.  Fixed summation order
+ * (the same bits on every launch and rank).  cosine_similarity clamps each norm at 1e-8 like torch. */
+size_t r4d_retriever_losses_workspace_bytes(int32_t B);
+int r4d_retriever_losses_f32(const float* emb_d, const float* t_anchor_d, const float* t_pos_d, const float* t_neg_d, int32_t B,
+                             int32_t d, float temperature, float lambda_decay, float alpha, float grad_scale, float* losses_d,
+                             float* d_emb_d, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Single backward ops, exported for per-op parity tests (the kernels the step launches). */
 /* Conv1D parameter gradients (modeling_utils.py:1267-1271 under autograd): dw_d [in,out] = x^T . dy, db_d [out] (nullable) =
  * column sums of dy, for x_d [rows,in] and dy_d [rows,out]; in / out multiples of 4. */

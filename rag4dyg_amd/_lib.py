@@ -107,6 +107,8 @@ PROTOTYPES = {
                                              POINTER(c_int32), _P, POINTER(TrainDropoutC), _P, c_size_t, _P]),
     "r4d_gpt2_train_backward_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), POINTER(GPT2GradsC), c_int32, POINTER(_P),
                                               POINTER(c_int32), POINTER(c_int32), _P, POINTER(TrainDropoutC), _P, c_size_t, _P]),
+    "r4d_retriever_losses_workspace_bytes": (c_size_t, [c_int32]),
+    "r4d_retriever_losses_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, c_float, c_float, c_float, _P, _P, _P, c_size_t, _P]),
     "r4d_dropout_f32": (c_int32, [_P, _P, c_int64, _P, c_float, c_uint64, c_uint64, c_uint32, c_uint64, _P]),
     "r4d_weight_grad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_weight_grad_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),

@@ -3,7 +3,7 @@
 the AdamW update) and the training loop of ``main_retriever.py --do_train``.
 
 Mirrors ``dataloader/retriever.py:68-111`` (``PairSequenceDataset``), ``models/modeling_rag.py:774-840`` (``_aug``),
-``train/train_retriever.py:40-98,120-354`` (``CLtime_loss``, ``mask_correlated_samples``, ``info_nce``, ``adjust_learning_rate``,
+``train/train_retriever.py:40-98,120-354`` (the two contrastive losses -- on the device, ``csrc/losses.hip`` --, ``adjust_learning_rate``,
 ``train_epoch``, ``train``) and ``utils/model.py:56-102`` (checkpoints, the ``transformers.AdamW`` configuration).  The five
 batches of a step (anchor, positive, hard negative, two augmented views) go through ONE launch sequence over their concatenated
 rows (``r4d_gpt2_train_forward_f32`` / ``_backward_f32``); the losses themselves are [B, 3B] / [2B, 2B] similarity tables:
@@ -17,7 +17,6 @@ import random
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .dataloader import read_nonblank_lines
 
@@ -74,59 +73,32 @@ def aug(batch_seqs, eta, gamma, mask_token):
     return torch.tensor(view1, dtype=torch.long, device=dev), torch.tensor(view2, dtype=torch.long, device=dev)
 
 
-def CLtime_loss(args, anchors, positives, hard_negatives, anchors_time, positives_time, negatives_time):
-    """``train/train_retriever.py:40-72``."""
-    B = anchors.size(0)
-    allv = torch.cat([anchors, positives, hard_negatives], dim=0)
-    sim = F.cosine_similarity(allv.unsqueeze(1), allv.unsqueeze(0), dim=2)
-    dev = anchors.device
-    d_pos = torch.exp(-args.lambda_decay * torch.abs(anchors_time.unsqueeze(1) - positives_time).squeeze()).to(dev)
-    d_neg = torch.exp(-args.lambda_decay * torch.abs(anchors_time.unsqueeze(1) - anchors_time).squeeze())
-    d_neg.fill_diagonal_(0)
-    d_neg = d_neg.to(dev)
-    d_hard = torch.exp(-args.lambda_decay * torch.abs(anchors_time.unsqueeze(1) - negatives_time).squeeze()).to(dev)
-    logits = torch.cat([sim[:B, B:2 * B] * d_pos, sim[:B, :B] * d_neg, sim[:B, 2 * B:] * d_hard], dim=1) / args.temperature
-    return F.cross_entropy(logits, torch.arange(B, device=dev))
-
-
-def mask_correlated_samples(batch_size):
-    """``train/train_retriever.py:74-82``."""
-    N = 2 * batch_size
-    mask = torch.ones((N, N), dtype=bool)
-    mask = mask.fill_diagonal_(0)
-    for i in range(batch_size):
-        mask[i, batch_size + i] = 0
-        mask[batch_size + i, i] = 0
-    return mask
-
-
-_NCE_COLS = {}
-
-
-def info_nce(args, z_i, z_j, temp, batch_size, mask):
-    """``train/train_retriever.py:84-98`` (the mask is rebuilt for a last, smaller batch, :92-93)."""
-    N = 2 * batch_size
-    z = torch.cat((z_i, z_j), dim=0)
-    sim = torch.mm(z, z.T) / temp
-    positive = torch.cat((torch.diag(sim, batch_size), torch.diag(sim, -batch_size)), dim=0).reshape(N, 1)
-    if mask is None or batch_size != args.per_gpu_train_batch_size:
-        mask = mask_correlated_samples(batch_size)
-    # ``sim[mask].reshape(N, -1)`` as a gather: every row of the mask keeps the same number of columns, so the selected
-    # columns are a fixed [N, N - 2] index table -- boolean indexing would make the host wait for the device (nonzero count)
-    key = (id(mask), batch_size, str(sim.device))
-    cols = _NCE_COLS.get(key)
-    if cols is None:
-        cols = mask.nonzero()[:, 1].reshape(N, -1).to(sim.device)
-        _NCE_COLS.clear()
-        _NCE_COLS[key] = cols
-        _NCE_COLS["mask"] = mask                                # keeps id(mask) from being reused while cached
-    negative = sim.gather(1, cols)
-    labels = torch.zeros(N, device=sim.device).long()
-    return F.cross_entropy(torch.cat((positive, negative), dim=1), labels)
+def retriever_losses(args, emb, t_anchor, t_pos, t_neg, grad_scale=1.0, want_grad=True):
+    """The step's two contrastive losses on the device (``csrc/losses.hip``, ``r4d_retriever_losses_f32``):
+    ``CLtime_loss`` (``train/train_retriever.py:40-72``) on emb[0..2] with the query times, ``alpha * info_nce`` (:84-98) on the
+    two augmented views emb[3], emb[4], and -- with ``want_grad`` -- ``grad_scale * d(loss)/d(emb)``.  ``emb`` [5, B, d] fp32;
+    the times are the ``all_query_time[idx]`` tensors of the reference ([B] or [B, 1]).  Returns (losses [3] = CLtime,
+    alpha * info_nce, their sum; device tensor, no host sync), d_emb [5, B, d] or None).  The last, smaller batch of an epoch
+    needs no rebuilt mask: info_nce's negatives are simply "every other row but the partner" for whatever B arrives."""
+    lib = _lib.load()
+    emb = emb.contiguous()
+    _five, B, d = emb.shape
+    dev = emb.device
+    ts = [t.to(device=dev, dtype=torch.float32).reshape(-1).contiguous() for t in (t_anchor, t_pos, t_neg)]
+    if any(t.numel() != B for t in ts):
+        raise _lib.R4DError(f"retriever_losses: {B} sequences but times of {[t.numel() for t in ts]} elements")
+    ws = ops.workspace(lib.r4d_retriever_losses_workspace_bytes(B), dev, "losses")
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    demb = torch.empty_like(emb) if want_grad else None
+    _lib.check(lib.r4d_retriever_losses_f32(emb.data_ptr(), ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), B, d,
+                                            float(args.temperature), float(args.lambda_decay), float(args.alpha), float(grad_scale),
+                                            losses.data_ptr(), demb.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream), "retriever_losses")
+    return losses, demb
 
 
 @torch.no_grad()
-def training_step_forward(args, model, batch, all_query_time, mask_nce=None):
+def training_step_forward(args, model, batch, all_query_time):
     """Forward half of one ``train_epoch`` iteration (``train/train_retriever.py:164-196``): ``batch`` = (anchor, positive,
     negative, anchor_idx, positive_idx, negative_idx) as the ``PairSequenceDataset`` loader yields them.  Returns
     dict(cl_loss, aug_loss, loss, embeddings [5, B, d], aug1, aug2)."""
@@ -137,9 +109,8 @@ def training_step_forward(args, model, batch, all_query_time, mask_nce=None):
     B = anchor_seq.size(0)
     emb = model.encode_groups_meanpool([anchor_seq, pos_seq, neg_seq, aug1, aug2]).view(5, B, -1)   # one fused launch sequence
     t = all_query_time
-    cl = CLtime_loss(args, emb[0], emb[1], emb[2], t[anchor_idx], t[pos_idx], t[neg_idx])
-    au = args.alpha * info_nce(args, emb[3], emb[4], args.temperature, B, mask_nce)
-    return dict(cl_loss=cl, aug_loss=au, loss=cl + au, embeddings=emb, aug1=aug1, aug2=aug2)
+    losses, _ = retriever_losses(args, emb, t[anchor_idx], t[pos_idx], t[neg_idx], want_grad=False)
+    return dict(cl_loss=losses[0], aug_loss=losses[1], loss=losses[2], embeddings=emb, aug1=aug1, aug2=aug2)
 
 
 # ------------------------------------------------------------------------------------------------ backward + optimizer
@@ -369,9 +340,10 @@ def _to_device(x, dev):
     return x.pin_memory().to(dev, non_blocking=True)
 
 
-def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce=None, micro_step=0, sync=True):
+def training_step(args, model, trainer, optimizer, batch, all_query_time, micro_step=0, sync=True):
     """One iteration of ``train_epoch`` (``train/train_retriever.py:164-214``) on the device: five forwards (one launch
-    sequence), the two contrastive losses (torch autograd over the [5, B, d] embeddings only), the encoder's backward pass
+    sequence), the two contrastive losses and their gradient on the [5, B, d] embeddings (``retriever_losses``: three small
+    launches, no framework autograd anywhere in the step), the encoder's backward pass
     and -- every ``gradient_accumulation_steps``-th micro-step -- the gradient average over the data-parallel ranks,
     gradient clipping and the AdamW update.  Returns dict(loss, cl_loss, aug_loss, stepped); with ``sync=False`` the three
     losses are 0-d device tensors instead of floats, so the host does not wait for the GPU and prepares the next batch (the
@@ -385,17 +357,11 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
         anchor_idx, pos_idx, neg_idx = (_to_device(x, dev) for x in (anchor_idx, pos_idx, neg_idx))
     B = anchor_seq.size(0)
     emb = trainer.forward([anchor_seq, pos_seq, neg_seq, aug1, aug2])
-    leaf = emb.view(5, B, -1).detach().requires_grad_(True)
-    with torch.enable_grad():
-        t = all_query_time
-        cl = CLtime_loss(args, leaf[0], leaf[1], leaf[2], t[anchor_idx], t[pos_idx], t[neg_idx])
-        au = args.alpha * info_nce(args, leaf[3], leaf[4], args.temperature, B, mask_nce)
-        loss = cl + au
-        gas = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
-        if gas > 1:
-            loss = loss / gas
-        loss.backward()
-    trainer.backward(leaf.grad.view(5 * B, -1))
+    t = all_query_time
+    gas = max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
+    losses, demb = retriever_losses(args, emb.view(5, B, -1), t[anchor_idx], t[pos_idx], t[neg_idx], grad_scale=1.0 / gas)
+    cl, au, loss = losses[0], losses[1], losses[2] / gas
+    trainer.backward(demb.view(5 * B, -1))
     if gas > 1:
         trainer.accumulate()
     stepped = (micro_step + 1) % gas == 0
@@ -407,7 +373,7 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, mask_n
         trainer.refresh_transposed()
         model.transformer.__dict__.pop("_wt_cache", None)        # transposed weight copies of the inference path are stale now
     if not sync:
-        return dict(loss=loss.detach(), cl_loss=cl.detach(), aug_loss=au.detach(), stepped=stepped)
+        return dict(loss=loss, cl_loss=cl, aug_loss=au, stepped=stepped)
     return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()), stepped=stepped)
 
 
@@ -454,7 +420,7 @@ def save_checkpoint(model, optimizer, tokenizer, args, global_step):
     torch.save({"last_epoch": optimizer.t}, os.path.join(out, "r4d_scheduler.pt"))
 
 
-def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args, mask_nce):
+def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args):
     """``train/train_retriever.py:132-227``: one pass over the shuffled triples.  Returns (global_step, summed loss,
     summed contrastive loss, summed augmentation loss)."""
     tr_loss = tr_cl = tr_aug = 0.0
@@ -462,7 +428,7 @@ def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataload
     for i, batch in enumerate(train_dataloader):
         if args.lrdecay == 1:
             adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
-        r = training_step(args, model, trainer, optimizer, batch, all_query_time, mask_nce, micro_step=i, sync=False)
+        r = training_step(args, model, trainer, optimizer, batch, all_query_time, micro_step=i, sync=False)
         tr_loss = tr_loss + r["loss"]; tr_cl = tr_cl + r["cl_loss"]; tr_aug = tr_aug + r["aug_loss"]   # device sums: no wait per step
         if r["stepped"]:                                       # an optimizer update (train_retriever.py:212-221)
             global_step += 1
@@ -517,7 +483,6 @@ def train(args, train_dataset, model, tokenizer):
     print("  Num examples = {}".format(len(train_dataset)))
     print("  Num Epochs = {}".format(args.num_train_epochs))
     print("  Instantaneous batch size per GPU = {}".format(args.per_gpu_train_batch_size))
-    mask_nce = mask_correlated_samples(args.per_gpu_train_batch_size)
     all_query_time = torch.load(os.path.join("resources/", args.dataset + '_train_query_time.pt'))     # get_train_query_time.py
     all_query_time = torch.as_tensor(all_query_time).to(args.device)
     global_step, tr_loss = 0, 0.0
@@ -526,8 +491,7 @@ def train(args, train_dataset, model, tokenizer):
     last_state, epoch = None, 0
     for epoch in range(int(args.num_train_epochs)):
         print('==> Training Epoch: ', epoch)
-        global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step,
-                                                   args, mask_nce)
+        global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args)
         tr_loss = ep_loss            # the reference resets tr_loss every epoch (train_retriever.py:158): its logged / returned
                                      # "train_loss" is the LAST epoch's summed loss over the cumulative step count (:303, :354)
         val_metrics, val_loss = test(epoch, args, model, tokenizer, evaluate=True)

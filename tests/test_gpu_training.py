@@ -22,6 +22,43 @@ def dev():
     return torch.device("cuda:0")
 
 
+def test_device_loss_head_matches_reference_values_and_autograd(dev):
+    """csrc/losses.hip (r4d_retriever_losses_f32) against the REFERENCE's CLtime_loss / info_nce values (G8: l4 and l32, computed
+    by train/train_retriever.py itself), and its gradient on the [5, B, d] embeddings against float64 autograd of the oracle's
+    restatement (oracle/train_ref.py, pinned by the same fixture) -- element-wise; last-batch size (B != per_gpu_train_batch_size:
+    the reference rebuilds its mask, the kernel needs none); gradient scale; determinism (same bits on a second launch)."""
+    from oracle import train_ref
+    from rag4dyg_amd import training
+    g = load_golden("g8_training_step")
+    T = torch.from_numpy
+    for tag in ("l4", "l32"):
+        a, p, n = (T(x) for x in g[tag + "_emb"])
+        ta, tp, tn = (T(x) for x in g[tag + "_time"])
+        B, d = a.shape
+        gen = torch.Generator().manual_seed(B)
+        s1, s2 = torch.randn(B, d, generator=gen), torch.randn(B, d, generator=gen)
+        for alpha, scale in ((1.0, 1.0), (0.3, 0.25)):
+            args = types.SimpleNamespace(temperature=0.07, lambda_decay=0.05, alpha=alpha, per_gpu_train_batch_size=B + 1)
+            emb = torch.stack([a, p, n, s1, s2]).to(dev)
+            losses, demb = training.retriever_losses(args, emb, ta, tp, tn, grad_scale=scale)
+            assert abs(losses[0].item() - float(g[tag + "_cltime"])) < 1e-5 * max(1.0, abs(float(g[tag + "_cltime"])))
+            # info_nce of the fixture is on (a, p) as the two views
+            l2, _ = training.retriever_losses(args, torch.stack([a, p, n, a, p]).to(dev), ta, tp, tn, want_grad=False)
+            assert abs(l2[1].item() / (alpha * float(g[tag + "_infonce_raw"])) - 1) < 1e-5
+            assert abs(l2[1].item() / (alpha * float(g[tag + "_infonce_rebuilt"])) - 1) < 1e-5
+            # gradient: float64 autograd of the oracle's loss functions
+            leaf = torch.stack([a, p, n, s1, s2]).double().requires_grad_(True)
+            cl = train_ref.cltime_loss(0.07, 0.05, leaf[0], leaf[1], leaf[2], ta.double(), tp.double(), tn.double())
+            au = alpha * train_ref.info_nce(leaf[3], leaf[4], 0.07, B)
+            ((cl + au) * scale).backward()
+            assert abs(losses[2].item() / float((cl + au).item()) - 1) < 1e-5
+            ratio = elementwise_err(demb.cpu().numpy(), leaf.grad.numpy())
+            print(f"{tag} alpha {alpha}: loss head gradient element-wise ratio {ratio:.3f} (pass < 1), max-norm {rel_err(demb.cpu().numpy(), leaf.grad.numpy()):.2e}")
+            assert ratio < 1
+            losses_b, demb_b = training.retriever_losses(args, emb, ta, tp, tn, grad_scale=scale)
+            assert torch.equal(demb, demb_b) and torch.equal(losses, losses_b)
+
+
 @pytest.mark.parametrize("tag", ["ts_tiny", "ts_cfg2"])
 def test_training_step_forward_losses_equal_reference(dev, tag):
     """anchor / positive / negative / two augmented views through ONE fused launch sequence of the HIP encoder, the
@@ -44,7 +81,7 @@ def test_training_step_forward_losses_equal_reference(dev, tag):
     idx = T(g[tag + "_idx"])
     batch = (T(g[tag + "_anchor"]), T(g[tag + "_pos"]), T(g[tag + "_neg"]), idx[:, 0:1], idx[:, 1:2], idx[:, 2:3])
     random.seed(seed)
-    r = training.training_step_forward(args, m, batch, T(g[tag + "_times"]), training.mask_correlated_samples(B))
+    r = training.training_step_forward(args, m, batch, T(g[tag + "_times"]).to(dev))
     assert np.array_equal(r["aug1"].cpu().numpy(), g[tag + "_aug1"]) and np.array_equal(r["aug2"].cpu().numpy(), g[tag + "_aug2"])
     emb = r["embeddings"].cpu().numpy()
     assert rel_err(emb, g[tag + "_emb"]) < 1e-4 and elementwise_err(emb, g[tag + "_emb"]) < 1
@@ -79,13 +116,10 @@ def test_training_step_gradients_equal_reference_autograd(dev, tag):
     trainer = training.EncoderTrainer(m)
     emb = trainer.forward([anchor, pos, neg, aug1, aug2])
     assert rel_err(emb.view(5, B, -1).cpu().numpy(), g[tag + "_emb"]) < 1e-4          # training forward == inference forward
-    leaf = emb.view(5, B, -1).detach().requires_grad_(True)
     t = T(g[tag + "_times"])
-    with torch.enable_grad():
-        cl = training.CLtime_loss(args, leaf[0], leaf[1], leaf[2], t[idx[:, 0:1]], t[idx[:, 1:2]], t[idx[:, 2:3]])
-        au = alpha * training.info_nce(args, leaf[3], leaf[4], temp, B, training.mask_correlated_samples(B))
-        (cl + au).backward()
-    grads = trainer.backward(leaf.grad.view(5 * B, -1))
+    losses, demb = training.retriever_losses(args, emb.view(5, B, -1), t[idx[:, 0:1]], t[idx[:, 1:2]], t[idx[:, 2:3]])
+    cl, au = losses[0], losses[1]
+    grads = trainer.backward(demb.view(5 * B, -1))
     names = [str(n) for n in g[tag + "_grad_names"]]
     got = np.array([grads["transformer.wte.weight" if n == "lm_head.weight" else n].double().norm().item() for n in names])
     worst = np.abs(got / g[tag + "_grad_norms"] - 1).max()
@@ -147,7 +181,7 @@ def test_training_step_parameter_update_equals_oracle_adamw(dev):
     trainer = training.EncoderTrainer(m)
     opt = training.AdamW(trainer.params, trainer.grads, lr=lr, eps=1e-8, weight_decay=wd)
     random.seed(seed)
-    r = training.training_step(args, m, trainer, opt, batch, T(g[tag + "_times"]), training.mask_correlated_samples(B))
+    r = training.training_step(args, m, trainer, opt, batch, T(g[tag + "_times"]))
     assert abs(r["loss"] / float(g[tag + "_losses"][2]) - 1) < 1e-5
     # oracle AdamW on the DEVICE's gradients (their parity with the reference's autograd is the previous test; at step 1 the
     # update is ~lr * sign(g), which would amplify 1e-5 gradient noise on the near-zero elements into a different test)
@@ -206,12 +240,9 @@ def test_training_gradients_other_shapes_equal_oracle(dev, L, H, d, V, B, Ts):
     aug1, aug2 = training.aug(anchor, cfg.eta, cfg.gamma, V - 1)
     trainer = training.EncoderTrainer(m)
     emb = trainer.forward([t.to(dev) for t in (anchor, pos, neg, aug1, aug2)])
-    leaf = emb.view(5, B, -1).detach().requires_grad_(True)
-    with torch.enable_grad():
-        cl = training.CLtime_loss(args, leaf[0], leaf[1], leaf[2], times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
-        au = alpha * training.info_nce(args, leaf[3], leaf[4], temp, B, training.mask_correlated_samples(B))
-        (cl + au).backward()
-    grads = trainer.backward(leaf.grad.view(5 * B, -1))
+    losses, demb = training.retriever_losses(args, emb.view(5, B, -1), times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
+    cl, au = losses[0], losses[1]
+    grads = trainer.backward(demb.view(5 * B, -1))
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "lm_head.weight"}
     sdg["lm_head.weight"] = sdg["transformer.wte.weight"]
     r = train_ref.training_step(sdg, H, anchor, pos, neg, times, idx, cfg.eta, cfg.gamma, alpha, temp, lam, V - 1, seed, with_grad=True)
@@ -244,7 +275,7 @@ def test_three_training_steps_track_the_oracle(dev):
     V_ = {k: torch.zeros_like(v) for k, v in P.items()}
     for step, b in enumerate((batch, batch2, batch), start=1):
         random.seed(seed + step)
-        r = training.training_step(args, m, trainer, opt, b, times, mask)
+        r = training.training_step(args, m, trainer, opt, b, times)
         sdg = {k: v.float().requires_grad_(True) for k, v in P.items()}
         sdg["lm_head.weight"] = sdg["transformer.wte.weight"]
         idx = torch.cat(b[3:6], dim=1)
@@ -332,7 +363,7 @@ def _tiny_step_inputs(dev, roll=0):
              idx[:, 1:2], idx[:, 2:3])
     args = types.SimpleNamespace(device=dev, temperature=temp, lambda_decay=lam, alpha=alpha, per_gpu_train_batch_size=B,
                                  max_grad_norm=1.0, gradient_accumulation_steps=1)
-    return m, args, batch, T(g[tag + "_times"]), training.mask_correlated_samples(B), seed
+    return m, args, batch, T(g[tag + "_times"]), None, seed
 
 
 def test_gradient_accumulation_equals_mean_of_micro_batch_gradients(dev):
@@ -346,16 +377,16 @@ def test_gradient_accumulation_equals_mean_of_micro_batch_gradients(dev):
         tr = training.EncoderTrainer(m)
         opt = training.AdamW(tr.params, tr.grads, lr=0.0, flat_grads=tr.flat_grads)
         random.seed(seed)
-        training.training_step(args, m, tr, opt, b, times, mask)
+        training.training_step(args, m, tr, opt, b, times)
         singles.append(tr.flat_grads.clone())
     args.gradient_accumulation_steps = 2
     tr = training.EncoderTrainer(m)
     opt = training.AdamW(tr.params, tr.grads, lr=0.0, flat_grads=tr.flat_grads)
     random.seed(seed)
-    r1 = training.training_step(args, m, tr, opt, b1, times, mask, micro_step=0)
+    r1 = training.training_step(args, m, tr, opt, b1, times, micro_step=0)
     assert not r1["stepped"] and opt.t == 0
     random.seed(seed)
-    r2 = training.training_step(args, m, tr, opt, b2, times, mask, micro_step=1)
+    r2 = training.training_step(args, m, tr, opt, b2, times, micro_step=1)
     assert r2["stepped"] and opt.t == 1
     want = (singles[0].double() + singles[1].double()) / 2
     assert rel_err(tr.flat_grads.cpu().numpy(), want.cpu().numpy()) < 1e-6
@@ -382,7 +413,7 @@ def spy():
     local["g"] = tr.flat_grads.clone()
     orig()
 tr.all_reduce_mean = spy
-training.training_step(args, m, tr, opt, batch, times, mask)
+training.training_step(args, m, tr, opt, batch, times)
 both = [torch.empty_like(local["g"]) for _ in range(2)]
 dist.all_gather(both, local["g"])
 want = (both[0].double() + both[1].double()) / 2
@@ -543,12 +574,9 @@ def test_training_step_with_dropout_equals_oracle_given_the_same_masks(dev):
         aug1, aug2 = training.aug(anchor, eta, gamma, V - 1)
         emb = trainer.forward([anchor, pos, neg, aug1, aug2])
         embs.append(emb.clone())
-        leaf = emb.view(5, B, -1).detach().requires_grad_(True)
-        with torch.enable_grad():
-            cl = training.CLtime_loss(args, leaf[0], leaf[1], leaf[2], times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
-            au = alpha * training.info_nce(args, leaf[3], leaf[4], temp, B, mask)
-            (cl + au).backward()
-        grads = trainer.backward(leaf.grad.view(5 * B, -1))
+        losses, demb = training.retriever_losses(args, emb.view(5, B, -1), times[idx[:, 0:1]], times[idx[:, 1:2]], times[idx[:, 2:3]])
+        cl, au = losses[0], losses[1]
+        grads = trainer.backward(demb.view(5 * B, -1))
         sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "lm_head.weight"}
         sdg["lm_head.weight"] = sdg["transformer.wte.weight"]
         drop = train_ref.PhiloxDropout(*ps, seed=991, step=step)

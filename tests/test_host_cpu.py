@@ -612,24 +612,13 @@ def test_annotation_rank_row_ranges_cover_in_order_and_parts_join(tmp_path):
 
 # ------------------------------------------------------------------------------------------- training step, host side (8f-4)
 def test_training_losses_and_augmentation_match_reference_fixtures():
-    """rag4dyg_amd.training against the reference's own functions (G8): CLtime_loss, info_nce (+ rebuilt mask), the
-    crop / mask augmentation under a seeded python ``random``."""
+    """rag4dyg_amd.training against the reference's own functions (G8): the crop / mask augmentation under a seeded python
+    ``random``.  (The two contrastive losses run on the device since round 3 -- csrc/losses.hip -- and are checked against the
+    same fixture values in tests/test_gpu_training.py::test_device_loss_head_matches_reference_values_and_autograd.)"""
     import random
-    from types import SimpleNamespace
     from rag4dyg_amd import training
     g = load_golden("g8_training_step")
     T = torch.from_numpy
-    for tag in ("l4", "l32"):
-        a, p, n = (T(x) for x in g[tag + "_emb"])
-        ta, tp, tn = (T(x) for x in g[tag + "_time"])
-        B = a.shape[0]
-        args = SimpleNamespace(temperature=0.07, lambda_decay=0.05, per_gpu_train_batch_size=B)
-        assert abs(training.CLtime_loss(args, a, p, n, ta, tp, tn).item() - float(g[tag + "_cltime"])) < 1e-5
-        mask = training.mask_correlated_samples(B)
-        assert np.array_equal(mask.numpy(), g[tag + "_mask"])
-        assert abs(training.info_nce(args, a, p, 0.07, B, mask).item() / float(g[tag + "_infonce_raw"]) - 1) < 1e-6
-        args.per_gpu_train_batch_size = B + 1
-        assert abs(training.info_nce(args, a, p, 0.07, B, None).item() / float(g[tag + "_infonce_rebuilt"]) - 1) < 1e-6
     for tag in ("ts_tiny", "ts_cfg2"):
         L, H, d, V, pad, B, seed = (int(x) for x in g[tag + "_cfg"])
         eta, gamma = float(g[tag + "_hyper"][0]), float(g[tag + "_hyper"][1])

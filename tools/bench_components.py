@@ -319,7 +319,6 @@ def training():
         trip = [right_pad_batches(seqs[(3 * i + j) * B:(3 * i + j + 1) * B], B, shape.pad_id, "cpu")[0] for j in range(3)]   # as the DataLoader hands them over
         idx = [torch.arange((3 * i + j) * B, (3 * i + j + 1) * B).view(B, 1) for j in range(3)]
         batches.append((*trip, *idx))
-    mask = tr.mask_correlated_samples(B)
     n = nb - 2
     flop = sum(3.0 * (f_enc(shape, B, b[0].shape[1]) * 3 + f_enc(shape, B, b[1].shape[1]) + f_enc(shape, B, b[2].shape[1]))
                for b in batches[2:])
@@ -330,11 +329,11 @@ def training():
         opt = tr.AdamW(trainer.params, trainer.grads, lr=1e-5, eps=1e-8, weight_decay=0.0, flat_grads=trainer.flat_grads)
         random.seed(0)
         for b in batches[:2]:
-            tr.training_step(args, m, trainer, opt, b, times, mask)
+            tr.training_step(args, m, trainer, opt, b, times)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in batches[2:]:
-            tr.training_step(args, m, trainer, opt, b, times, mask, sync=False)      # as train_epoch runs it: losses summed on the device
+            tr.training_step(args, m, trainer, opt, b, times, sync=False)      # as train_epoch runs it: losses summed on the device
         torch.cuda.synchronize()
         wall[mode] = time.perf_counter() - t0
     el = wall["train"]
