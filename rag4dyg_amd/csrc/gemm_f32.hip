@@ -407,6 +407,15 @@ int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, i
                 "gemm_tn: M=%d N=%d Kt=%d lda=%d ldb=%d (multiples of 4 wanted)", M, N, Kt, lda, ldb);
     R4D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm_tn: 16-byte alignment");
     const int S = tn_splits(M, N, Kt);
+    if (g_gemm_split3 && S > 1 && gemm_s3tn_supported(M, N, Kt, lda, ldb)) {    // bf16x3 form (gemm_s3tn.hip); S == 1: tiny problems stay here
+        int Sx3 = 1;
+        const int rc3 = launch_gemm_s3tn(A, B, scratch, M, N, Kt, lda, ldb, gemm_s3tn_slices(M, N, Kt, S), &Sx3, stream);
+        if (rc3) return rc3;
+        const long long mn4_ = (long long)M * N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4_ + 255) / 256)), dim3(256), 0, stream, scratch, mn4_, Sx3, C);
+        R4D_CHECK_LAUNCH("splitk_reduce");
+        return R4D_OK;
+    }
     const int kper = cdiv(cdiv(Kt, S), BKT) * BKT;
     const int Sx = cdiv(Kt, kper);                                   // splits that have rows
     R4D_REQUIRE(S == 1 || scratch, "gemm_tn: split-K scratch missing");

@@ -71,6 +71,7 @@ def test_every_dispatcher_branch_is_exercised(dev):
         assert rel_err(dw.cpu().numpy(), (x.double().t() @ dy.double()).cpu().numpy()) < 2e-6
     wgrad(20000, 128, 128)
     wgrad(100, 128, 128)
+    wgrad(20000, 128, 256)                                   # I % 128 == 0, J % 256 == 0, split over the rows: the bf16x3 TN kernel
 
     # ---- LayerNorm widths, ln_f + mean-pool widths, attention per head_dim, decode kernels, skinny forms: through models
     for rows, d in ((5, 512), (5, 768), (3, 2048), (7, 192)):
