@@ -463,9 +463,10 @@ def main():
         dom = max(prof, key=lambda n: prof[n]["ms"])
         v = prof[dom]
         traffic, util = None, None
-        tf = os.path.join(REPO, "profiles", f"pmc_traffic_{args.shape}.json")
+        sfx = "" if ops.gemm_split3_enabled() else "_f32"           # the exact-f32 run has its own PMC pass
+        tf = os.path.join(REPO, "profiles", f"pmc_traffic_{args.shape}{sfx}.json")
         if not os.path.exists(tf):
-            tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            tf = os.path.join(REPO, "profiles", f"pmc_traffic{sfx}.json")
         if os.path.exists(tf):              # PMC figure of a separate rocprofv3 pass: valid for the workload AND the sources
             pmc = json.load(open(tf))       # it was profiled on only -- otherwise null
             meta = pmc.get("_workload", {})

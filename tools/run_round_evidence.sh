@@ -21,8 +21,9 @@ bash tools/profile_scan.sh $TAG >> $LOG 2>&1
 cp gpurun_out/profiles_$TAG/* gpurun_out/profiles_${TAG}f/* gpurun_out/profiles_${TAG}w/* $EV/
 cp gpurun_out/profiles_$TAG/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 cp gpurun_out/profiles_${TAG}w/${TAG}w_pmc_traffic.json profiles/pmc_traffic_wikiv2.json
+cp gpurun_out/profiles_${TAG}f/${TAG}f_pmc_traffic.json profiles/pmc_traffic_f32.json
 cp gpurun_out/prof_scan_$TAG/pmc_scan.json profiles/pmc_scan.json
-cp profiles/pmc_traffic.json profiles/pmc_traffic_wikiv2.json profiles/pmc_scan.json $EV/
+cp profiles/pmc_traffic.json profiles/pmc_traffic_wikiv2.json profiles/pmc_traffic_f32.json profiles/pmc_scan.json $EV/
 cp gpurun_out/prof_scan_$TAG/pmc.txt $EV/${TAG}_scan_pmc.txt
 for f in gpurun_out/prof_scan_$TAG/kernel_stats_*.csv; do cp $f $EV/${TAG}_scan_$(basename $f); done
 echo "== bench UCI_13" >> $LOG
