@@ -304,25 +304,17 @@ def _rag_batch_finish(st):
 def decode_rag_batches(args, model, tokenizer, dataset, batches, mode, max_len, n_spl):
     """``greedy_decode_rag_batch`` over a list of (token_lists, index_lists) batches, yielding each batch's outputs.  The host
     half of the next batch's fusion (graph construction, pure Python / numpy) runs on a helper thread while the current batch
-    decodes.  ``R4D_DECODE_PIPELINE=1`` (off by default) additionally runs batch b + 1's fusion rows and prefill on a second
-    HIP stream, into a second decoder slot, while batch b decodes -- identical ids, but MEASURED SLOWER (UCI_13 shape, batch 32:
-    35.5 k against 38.2 k tokens/s): the prefill's GEMM workgroups hold every CU for tens of microseconds at a time, and each
-    of the decode step's 33 dependent launches then queues behind them; the decode chain loses more than the prefill hides."""
+    decodes.  (A second form that also ran batch b + 1's fusion rows and prefill on a second HIP stream while batch b decoded was
+    built in round 2, measured SLOWER -- UCI_13 shape, batch 32: 35.5 k against 38.2 k tokens/s: the prefill's GEMM workgroups hold
+    every CU for tens of microseconds at a time and each of the decode step's 33 dependent launches queues behind them -- and
+    removed in round 3.)"""
     from concurrent.futures import ThreadPoolExecutor
     if not batches:
         return
-    pipelined = os.environ.get("R4D_DECODE_PIPELINE", "0") == "1" and len(batches) > 1
-    cur = torch.cuda.current_stream()
-    s_fill, s_dec = (torch.cuda.Stream(), torch.cuda.Stream()) if pipelined else (cur, cur)
-    if pipelined:
-        s_fill.wait_stream(cur); s_dec.wait_stream(cur)
 
     def start(b, prep):
         toks, idxs = batches[b]
-        with torch.cuda.stream(s_fill):
-            st = _rag_batch_start(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl, prep, slot=b % 2)
-            st["ready"] = s_fill.record_event() if pipelined else None
-        return st
+        return _rag_batch_start(args, model, tokenizer, dataset, toks, idxs, mode, max_len, n_spl, prep, slot=b % 2)
 
     with ThreadPoolExecutor(max_workers=1) as pool:
         nxt = start(0, pool.submit(fusion_host_prep, args, model, dataset, batches[0][1], args.topK).result())
@@ -334,14 +326,7 @@ def decode_rag_batches(args, model, tokenizer, dataset, batches, mode, max_len, 
                 if b + 2 < len(batches):
                     fut = pool.submit(fusion_host_prep, args, model, dataset, batches[b + 2][1], args.topK)
                 nxt = start(b + 1, prep)                               # its decoder slot was released by finish(b - 1)
-            with torch.cuda.stream(s_dec):
-                if pipelined:
-                    s_dec.wait_event(st["ready"])
-                    st["last"].record_stream(s_dec); st["lens"].record_stream(s_dec)
-                out = _rag_batch_finish(st)
-            yield out
-    if pipelined:
-        cur.wait_stream(s_fill); cur.wait_stream(s_dec)
+            yield _rag_batch_finish(st)
 
 
 # ------------------------------------------------------------------------------------------------ dataset / eval

@@ -164,9 +164,9 @@ def test_reddit_shape_graphpooling_decode_batch32(dev, topk):
     print(f"reddit top-{topk}: {exact} of 32 generated lists identical to the oracle's")
 
 
-def test_pipelined_batches_equal_one_batch_at_a_time(dev, monkeypatch):
-    """decode_rag_batches overlaps batch b's decode with batch b + 1's fusion + prefill on a second stream (two decoder
-    slots): the ids must be those of the one-batch-at-a-time form, for ragged batch sizes, with the overlap on and off."""
+def test_pipelined_batches_equal_one_batch_at_a_time(dev):
+    """decode_rag_batches prepares batch b + 1's fusion (host half on a helper thread, device half queued before batch b's
+    decode is waited for; two decoder slots): the ids must be those of the one-batch-at-a-time form, for ragged batch sizes."""
     from oracle import gpt2_ref
     from rag4dyg_amd import generator, synth
     sh = synth.SHAPES["reddit"]
@@ -185,8 +185,6 @@ def test_pipelined_batches_equal_one_batch_at_a_time(dev, monkeypatch):
     cuts = [0, 32, 64, 96, 100]                                        # three full batches and a ragged last one
     batches = [(queries[a:b], idxs[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
     want = [generator.greedy_decode_rag_batch(args, model, tok, ds, q, ix, "val", 1024, 19) for q, ix in batches]
-    for mode_env in ("1", "0"):
-        monkeypatch.setenv("R4D_DECODE_PIPELINE", mode_env)
-        got = list(generator.decode_rag_batches(args, model, tok, ds, batches, "val", 1024, 19))
-        assert got == want, mode_env
+    got = list(generator.decode_rag_batches(args, model, tok, ds, batches, "val", 1024, 19))
+    assert got == want
     torch.cuda.synchronize()
