@@ -7,7 +7,7 @@
 #include "common.h"
 
 #ifndef SCAN_DBG
-#define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs, bit 1 the score stores, bit 2 the cross-wave reduction, bit 3 writes s_memrealtime stamps (100 MHz) of workgroup phases over the score rows of queries >= 16 (tools/scan_timeline.py)
+#define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs (and the split), bit 1 the score stores, bit 2 the cross-wave reduction (one-tile form), bit 3 writes s_memrealtime stamps (100 MHz) of workgroup phases over the score rows of queries >= 16 (tools/scan_timeline.py), bit 4 skips the bf16x3 split arithmetic only, bit 5 makes every query load read ONE line, bit 6 makes every pool load read 8 whole lines (timing of other access patterns)
 #endif
 
 namespace r4d {
@@ -55,9 +55,44 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 // Fusing the selection into this epilogue was priced and NOT done: a score costs 16 SIMD-cycles of MFMA here, an exact
 // per-workgroup top-k costs ~2.3 more on the same issue port (+14 %), which buys nothing over the separate launch while
 // the raw rows (6 % of the pool bytes) stay cache-resident.
+//
+// S3 (the default, r4d_set_gemm_split3): the same kernel on the bf16 matrix cores at fp32 accuracy -- both operands written
+// as exact sums of three bf16 numbers (the queries once, into registers; a pool row's 8 consecutive k of a lane right before
+// its MFMAs: 11 VALU instructions per two elements), six v_mfma_f32_32x32x16_bf16 per 16 k instead of eight
+// v_mfma_f32_32x32x2_f32: 2.67x fewer matrix-pipe cycles per pool byte, which takes the scan OFF the fp32 ridge (the timeline
+// of tools/scan_timeline.py at a 12.5k-row shard: 4 of 11 us were exact-f32 MFMA on two tiles per CU).  The arithmetic of a
+// score does not depend on the tile, the workgroup or the shard the row falls in (shard merge == single GPU bit for bit).
 typedef float f32x16s __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 
-template <int KW, int NG, bool TWO>                     // d == 32 * KW * NG; TWO: two tiles of a workgroup in flight
+__device__ __forceinline__ unsigned scan_cvt_pk(float a, float b) {   // v_cvt_pk_bf16_f32: low half = bf16(a), RNE
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+// two fp32 -> packed (hi, hi), (mid, mid), (lo, lo): x == hi + mid + lo exactly (gemm_s3.hip)
+__device__ __forceinline__ void scan_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = scan_cvt_pk(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = scan_cvt_pk(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = scan_cvt_pk(s0, s1);
+}
+// a lane's 8 k of one bf16 MFMA step (two 16-byte pieces) -> three bf16x8 operands
+__device__ __forceinline__ void scan_split8(const float4& a, const float4& b, u32x4v& h, u32x4v& m, u32x4v& l) {
+    unsigned hh[4], mm[4], ll[4];
+    scan_split_pair(a.x, a.y, hh[0], mm[0], ll[0]); scan_split_pair(a.z, a.w, hh[1], mm[1], ll[1]);
+    scan_split_pair(b.x, b.y, hh[2], mm[2], ll[2]); scan_split_pair(b.z, b.w, hh[3], mm[3], ll[3]);
+    h = u32x4v{hh[0], hh[1], hh[2], hh[3]}; m = u32x4v{mm[0], mm[1], mm[2], mm[3]}; l = u32x4v{ll[0], ll[1], ll[2], ll[3]};
+}
+// the six products of one 16-k step, smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi (gemm_s3.hip)
+#define SCAN_STEP6(ACC_, Q_, BH_, BM_, BL_) do { SCAN_MFMA16(Q_[2], BH_, ACC_); SCAN_MFMA16(Q_[0], BL_, ACC_); SCAN_MFMA16(Q_[1], BM_, ACC_); \
+    SCAN_MFMA16(Q_[1], BH_, ACC_); SCAN_MFMA16(Q_[0], BM_, ACC_); SCAN_MFMA16(Q_[0], BH_, ACC_); } while (0)
+#define SCAN_MFMA16(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, A_), __builtin_bit_cast(bf16x8v, B_), ACC_, 0, 0, 0)
+
+template <int KW, int NG, bool TWO, bool S3>            // d == 32 * KW * NG; TWO: two tiles of a workgroup in flight; S3: bf16x3
 __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_scan_ks_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
                                                               int Q, int N, int rpw, float* __restrict__ scores,
                                                               unsigned* __restrict__ zero_d, int nzero) {
@@ -81,27 +116,104 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
     if (r0 >= N) return;
 #if SCAN_DBG & 8
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(scores + (long long)16 * N) + blockIdx.x * 16;
-    if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[5] = __builtin_amdgcn_s_memtime(); }
+    if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[5] = __builtin_amdgcn_s_memtime(); stamps[10] = gridDim.x; }
+    unsigned long long* wst = reinterpret_cast<unsigned long long*>(scores + (long long)16 * N) + gridDim.x * 16 + (blockIdx.x * KW + w) * 8;   // per wavefront
+    if (lane == 0) wst[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int ntiles = rpw > 0 ? (r1 - r0 + 31) / 32 : ((N + 31) / 32 - (int)blockIdx.x + G - 1) / G;
     // k order: load u of lane half h of row j is the 16-byte piece 2u + h of the wave's 128-byte line g, so ONE load
     // instruction touches a whole 32-byte sector of each of its 32 rows; component c of that load is
     // k = 32 (g KW + w) + 8 u + 4 h + c on BOTH operands.
-    float4 qf[NG][4];
-    {
-        const bool ok = q0 + li < Q;
-        const float4* src = reinterpret_cast<const float4*>(qhat + (long long)min(q0 + li, Q - 1) * D) + lh;
+#if SCAN_DBG & 64                                       // WRONG results: every load instruction reads 8 whole 128-byte lines (timing of the coalesced pattern)
+#define SCAN_TIDX(g, u) (8 * KW * (g) + (u) * 8 * (D / 4))
+    auto tile_ptr = [&](int tt) {
+        return reinterpret_cast<const float4*>(pool + (long long)min(r0 + tt * tstep + (lane >> 3), N - 25) * D) + (lane & 7) + 8 * w;
+    };
+#else
+#define SCAN_TIDX(g, u) (8 * KW * (g) + 2 * (u))
+    auto tile_ptr = [&](int tt) {                       // rows past the shard are clamped (always valid); rows past r1 belong to the
+        return reinterpret_cast<const float4*>(pool + (long long)min(r0 + tt * tstep + li, N - 1) * D) + lh + 8 * w;   // next workgroup: computed, not stored
+    };
+#endif
+    auto load_tile = [&](float4 (&bb)[NG][4], int tt) {
+        const float4* __restrict__ p = tile_ptr(tt);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float4 v = src[8 * (g * KW + w) + 2 * u];
-                if (!ok) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
-                qf[g][u] = v;
+            for (int u = 0; u < 4; ++u) bb[g][u] = p[SCAN_TIDX(g, u)];
+    };
+    float4 b0[NG][4];
+    load_tile(b0, 0);                                   // the HBM stream starts BEFORE the (L2-resident) queries pass the CU's 64 B/clk vector-memory path (0.5 us for 64 KB)
+    // S3: MFMA step s of line g takes loads 2s and 2s + 1 of the lane as its 8 consecutive "k" (the same bijection on both
+    // operands), q3[g][s][plane] holding the query side split once
+    float4 qf[NG][4];
+    u32x4v q3[S3 ? NG : 1][2][3];
+    float4 b1[TWO ? NG : 1][4];
+    {
+        const bool ok = q0 + li < Q;
+        const float4* src = reinterpret_cast<const float4*>(qhat + (long long)((SCAN_DBG & 32) ? 0 : min(q0 + li, Q - 1)) * D) + ((SCAN_DBG & 32) ? 0 : lh);   // bit 5: one line per query load (WRONG results)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qf[g][u] = src[8 * (g * KW + w) + 2 * u];
+        if constexpr (TWO) {                            // the second tile's loads go out before anything waits
+            const float4* __restrict__ p1 = tile_ptr(min(1, ntiles - 1));
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b1[g][u] = p1[SCAN_TIDX(g, u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);              // ... and the compiler does not sink them below the query split
+#if SCAN_DBG & 8
+        if (lane == 0) wst[1] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("" :: "v"(qf[NG - 1][3].w));
+        if (lane == 0) wst[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!ok) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { qf[g][u].x = 0.f; qf[g][u].y = 0.f; qf[g][u].z = 0.f; qf[g][u].w = 0.f; }
             }
+            if constexpr (S3) {
+                scan_split8(qf[g][0], qf[g][1], q3[g][0][0], q3[g][0][1], q3[g][0][2]);
+                scan_split8(qf[g][2], qf[g][3], q3[g][1][0], q3[g][1][1], q3[g][1][2]);
+            }
+        }
     }
-    auto tile_ptr = [&](int tt) {                       // rows past the shard are clamped (always valid); rows past r1 belong to the
-        return reinterpret_cast<const float4*>(pool + (long long)min(r0 + tt * tstep + li, N - 1) * D) + lh + 8 * w;   // next workgroup: computed, not stored
+#if SCAN_DBG & 8
+    if constexpr (S3) { asm volatile("" :: "v"(q3[NG - 1][1][2])); if (lane == 0) wst[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // the MFMAs of one 128-byte line group of the staged rows
+    auto mfma_group = [&](f32x16s& acc, int g, const float4 (&b)[4]) {
+        if constexpr ((SCAN_DBG & 1) != 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += b[u].x + b[u].y + b[u].z + b[u].w;
+        } else if constexpr (S3) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4v bh, bm, bl;
+                if constexpr ((SCAN_DBG & 16) != 0) {
+                    bh = __builtin_bit_cast(u32x4v, b[2 * st]); bm = __builtin_bit_cast(u32x4v, b[2 * st + 1]); bl = bh ^ bm;
+                } else {
+                    scan_split8(b[2 * st], b[2 * st + 1], bh, bm, bl);
+                }
+                SCAN_MFMA16(q3[g][st][2], bh, acc);                      // smallest terms first: lo.hi, hi.lo, mid.mid,
+                SCAN_MFMA16(q3[g][st][0], bl, acc);                      // mid.hi, hi.mid, hi.hi (gemm_s3.hip)
+                SCAN_MFMA16(q3[g][st][1], bm, acc);
+                SCAN_MFMA16(q3[g][st][1], bh, acc);
+                SCAN_MFMA16(q3[g][st][0], bm, acc);
+                SCAN_MFMA16(q3[g][st][0], bh, acc);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].x, b[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].y, b[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].z, b[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].w, b[u].w, acc, 0, 0, 0);
+            }
+        }
     };
     int buf = 0;
     // one tile: MFMAs over the staged rows `bb`, each group's registers refilled with tile `trefill` (< 0: none) right after
@@ -113,21 +225,10 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (!(SCAN_DBG & 1)) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].x, bb[g][u].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].y, bb[g][u].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].z, bb[g][u].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].w, bb[g][u].w, acc, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] += bb[g][u].x + bb[g][u].y + bb[g][u].z + bb[g][u].w;
-            }
+            mfma_group(acc, g, bb[g]);
             if (trefill >= 0) {                                          // wave-uniform
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bb[g][u] = pn[8 * KW * g + 2 * u];
+                for (int u = 0; u < 4; ++u) bb[g][u] = pn[SCAN_TIDX(g, u)];
             }
         }
 #if SCAN_DBG & 8
@@ -166,15 +267,6 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
             }
         }
     };
-    auto load_tile = [&](float4 (&bb)[NG][4], int tt) {
-        const float4* __restrict__ p = tile_ptr(tt);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bb[g][u] = p[8 * KW * g + 2 * u];
-    };
-    float4 b0[NG][4];
-    load_tile(b0, 0);
 #if SCAN_DBG & 8
     if (tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();              // all loads issued
     {   // wait for the first tile and the queries
@@ -188,11 +280,53 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
         // with the first's -- ONE memory latency in front of the MFMAs instead of one per tile -- and the two tiles share ONE
         // cross-wave reduction (timeline of the one-tile-at-a-time form, tools/scan_timeline.py: the barrier of the first
         // tile's reduction waits 1.8 us for the wave whose loads landed last, while the matrix pipe idles)
-        float4 b1[NG][4];
-        load_tile(b1, min(1, ntiles - 1));
         for (int t = 0; t < ntiles; t += 2) {
             const bool has2 = t + 1 < ntiles;                             // workgroup-uniform
             f32x16s acc2[2];
+            if constexpr (S3 && !(SCAN_DBG & 17)) {
+                // The split of a step's pool operand (36 VALU instructions) is issued INSIDE the six MFMAs of the step before
+                // it, six per MFMA gap (sched_group_barrier): left to the compiler the stream is split, split, ..., MFMA x 6,
+                // and two wavefronts of a SIMD fall into lock step -- both splitting, then both multiplying -- so that the
+                // vector ALU and the matrix pipe take turns (timeline: 4,600 cycles per tile and SIMD = 48 x 32 + 704 x 4.2).
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+                u32x4v ch, cm, cl;
+                scan_split8(b0[0][0], b0[0][1], ch, cm, cl);
+#pragma unroll
+                for (int i = 0; i < 2 * NG; ++i) {
+                    const int g = i >> 1, st = i & 1, gn = (i + 1) >> 1, un = 2 * ((i + 1) & 1);
+                    u32x4v nh, nm, nl;
+                    if (i + 1 < 2 * NG) scan_split8(b0[gn][un], b0[gn][un + 1], nh, nm, nl);
+                    else scan_split8(b1[0][0], b1[0][1], nh, nm, nl);
+                    SCAN_STEP6(acc2[0], q3[g][st], ch, cm, cl);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+                    ch = nh; cm = nm; cl = nl;
+                }
+                if (t + 2 < ntiles) load_tile(b0, t + 2);
+#if SCAN_DBG & 8
+                if (t == 0) { asm volatile("" :: "v"(acc2[0][0])); if (lane == 0) wst[4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+                if (has2) {
+#pragma unroll
+                    for (int i = 0; i < 2 * NG; ++i) {
+                        const int g = i >> 1, st = i & 1, gn = (i + 1) >> 1, un = 2 * ((i + 1) & 1);
+                        u32x4v nh, nm, nl;
+                        if (i + 1 < 2 * NG) scan_split8(b1[gn][un], b1[gn][un + 1], nh, nm, nl);
+                        SCAN_STEP6(acc2[1], q3[g][st], ch, cm, cl);
+                        if (i + 1 < 2 * NG) {
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+                            ch = nh; cm = nm; cl = nl;
+                        }
+                    }
+                    if (t + 3 < ntiles) load_tile(b1, t + 3);
+                }
+#if SCAN_DBG & 8
+                if (t == 0) { asm volatile("" :: "v"(acc2[0][0]), "v"(acc2[1][15])); if (tid == 0) { stamps[8] = __builtin_amdgcn_s_memrealtime(); stamps[12] = stamps[8]; }
+                              if (lane == 0) wst[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float4 (&bb)[NG][4] = h ? b1 : b0;
@@ -203,19 +337,16 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
                 if (h == 0 || has2) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].x, bb[g][u].x, acc2[h], 0, 0, 0);
-                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].y, bb[g][u].y, acc2[h], 0, 0, 0);
-                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].z, bb[g][u].z, acc2[h], 0, 0, 0);
-                            acc2[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g][u].w, bb[g][u].w, acc2[h], 0, 0, 0);
-                        }
+                        mfma_group(acc2[h], g, bb[g]);
                         if (tn < ntiles) {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) bb[g][u] = pn[8 * KW * g + 2 * u];
+                            for (int u = 0; u < 4; ++u) bb[g][u] = pn[SCAN_TIDX(g, u)];
                         }
                     }
                 }
+#if SCAN_DBG & 8
+                if (t == 0) { asm volatile("" :: "v"(acc2[h][0]), "v"(acc2[h][15])); if (tid == 0) stamps[8 + 4 * h] = __builtin_amdgcn_s_memrealtime(); }
+#endif
             }
             // red[tile h][src wave][dst wave][lane][R]; same fixed summation order as the one-tile form: identical bits
 #pragma unroll
@@ -227,6 +358,10 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
                     for (int i = 0; i < R; ++i) base[((w * KW + wd) * 64 + lane) * R + i] = acc2[h][wd * R + i];
             }
             __syncthreads();
+#if SCAN_DBG & 8
+            if (t == 0 && tid == 0) { stamps[9] = __builtin_amdgcn_s_memrealtime(); stamps[13] = stamps[9]; }
+            if (t == 0 && lane == 0) wst[6] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float* base = red + h * (KW * KW * 64 * R);
@@ -243,7 +378,7 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
                     for (int i = 0; i < R; ++i) {
                         const int r = w * R + i;
                         const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (q < Q) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+                        if (q < Q && (!(SCAN_DBG & 8) || q < 16) && !(SCAN_DBG & 2)) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
                     }
                 }
             }
@@ -254,18 +389,233 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && NG == 4) ? 3 : 1) void pool_sc
     }
 #if SCAN_DBG & 8
     if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();              // all stores issued
+    if (lane == 0) wst[7] = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) { stamps[3] = __builtin_amdgcn_s_memrealtime(); stamps[6] = __builtin_amdgcn_s_memtime(); stamps[4] = (unsigned long long)__builtin_amdgcn_s_getreg(6164); }   // end; XCC id
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------ short shards: LDS-DMA staged form
+// A shard of 8k-16k rows is ONE cold burst: every CU reads its <= 64 rows (two 32-row tiles) plus the 32 queries once, and
+// the kernel is as long as that burst.  The per-wavefront timeline of the register-staged form above (tools/scan_timeline.py)
+// showed what the burst costs there: a load instruction whose lane (row j, half h) reads 32 bytes of ITS row touches 32
+// cache lines, the CU's vector-memory path takes ~40 cycles for it, and the second wavefront of every SIMD gets its loads
+// issued 2.7 us after the first (stream complete at 8.3 us); with 8 whole 128-byte lines per instruction the same bytes are
+// issued by 2.8 us and landed by 6 us.  Whole lines per instruction and row-per-lane MFMA operands need a transposition, so
+// the rows go global -> LDS by DMA (global_load_lds_dwordx4: lane l of instruction i copies 16 bytes of row 8 i + l / 8,
+// no VGPRs) and come back as ds_read_b128 fragments:
+//   * wavefront w still owns the 128-byte lines w, w + KW, ... of every row, so it reads back ONLY what it copied itself:
+//     its own counted s_waitcnt vmcnt orders the DMA in front of the ds_read (no barrier until the cross-wave reduction);
+//   * a "piece" = 32 rows x one line = 4 KB = four DMA instructions; pieces run through a ring of P = 4 slots per
+//     wavefront (16 KB; 128 KB per workgroup at KW = 8): the queries' NG pieces first, then tile 0's, then tile 1's, a
+//     slot refilled as soon as its fragments are in registers (s_waitcnt lgkmcnt(0) in front of the DMA);
+//   * LDS image: row r's 16-byte chunk c sits at slot c ^ ((r >> 1) & 7) of its 128 bytes -- written by permuting the
+//     SOURCE chunk per lane (the DMA destination is lane-linear), read with the same XOR: both sides conflict-free;
+//   * rows past the workgroup's share are CLAMPED to its last row (cache hits), so a 49-row share reads 49 rows from HBM,
+//     not two whole tiles (the form above reads 64);
+//   * arithmetic: the same chunk -> MFMA-slot bijection, the same six products in the same order and the same reduction
+//     order as pool_scan_ks_kernel<.., S3 = true>: scores are bit-identical to the long-shard form (shard merge == one GPU).
+// one piece = four DMA instructions of 1 KB: global address = base + 32-bit lane offset + i KB, LDS address = M0 + i KB + 16 lane
+// (the instruction offset moves BOTH sides, so the lane offsets of instruction i are built i KB short); M0 is written in the
+// statement that uses it and restored (the compiler owns it)
+__device__ __forceinline__ void scan_glds_piece(const void* base, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\t"
+                 "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N_> __device__ __forceinline__ void scan_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
+__device__ __forceinline__ void scan_wait_vmcnt(int n) {                                   // n is a constant after unrolling
+    switch (n) { case 0: scan_wait_vm<0>(); break; case 4: scan_wait_vm<4>(); break; case 8: scan_wait_vm<8>(); break;
+                 default: scan_wait_vm<12>(); break; }
+}
+template <int N_> struct ScanInt { static constexpr int value = N_; };
+
 template <int KW, int NG>
-static int launch_scan_variant(const float* qhat, const float* pool, int Q, int N, float* scores, unsigned* zero_d, int nzero,
+__global__ __launch_bounds__(64 * KW, 1) void pool_scan_dma_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
+                                                                  int Q, int N, int rpw, float* __restrict__ scores,
+                                                                  unsigned* __restrict__ zero_d, int nzero) {
+    constexpr int D = 32 * KW * NG;
+    constexpr int R = 16 / KW;
+    constexpr int P = 4;                                  // ring slots of 4 KB per wavefront
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.y * 32;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = tid; i < nzero; i += 64 * KW) zero_d[i] = 0u;
+    const int r0 = blockIdx.x * rpw, r1 = min(N, r0 + rpw);              // rpw <= 64: one or two tiles
+    if (r0 >= N) return;
+#if SCAN_DBG & 8
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(scores + (long long)16 * N) + blockIdx.x * 16;
+    unsigned long long* wst = reinterpret_cast<unsigned long long*>(scores + (long long)16 * N) + gridDim.x * 16 + (blockIdx.x * KW + w) * 8;
+    if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[5] = __builtin_amdgcn_s_memtime(); stamps[10] = gridDim.x; }
+    if (lane == 0) wst[0] = __builtin_amdgcn_s_memrealtime();
+#define SCAN_WSTAMP(i) do { if (lane == 0) wst[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SCAN_WSTAMP(i) do { } while (0)
+#endif
+    unsigned char* ring = scan_lds + w * (P * 4096);
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);
+    // DMA sources: instruction i of a piece copies rows 8 i + lane / 8 of the piece, lane % 8 picking the (permuted) chunk:
+    // byte offsets from (pointer - 3 KB), instruction i's built i KB short (scan_glds_piece); rows past the share / the
+    // query block are clamped to its last row
+    unsigned voff[3][4];                                  // queries, tile 0, tile 1
+    {
+        const int c0 = (lane & 7) ^ (lane >> 4);          // chunk of instruction i: c0 ^ 4 (i & 1)   [= (lane & 7) ^ ((row >> 1) & 7)]
+        const int lrow = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned in_row = 128u * w + 16u * (c0 ^ (4 * (i & 1))) + 3072u - 1024u * i;
+            voff[0][i] = (unsigned)min(q0 + 8 * i + lrow, Q - 1) * (unsigned)(D * 4) + in_row;
+            voff[1][i] = (unsigned)min(r0 + 8 * i + lrow, r1 - 1) * (unsigned)(D * 4) + in_row;
+            voff[2][i] = (unsigned)min(r0 + 32 + 8 * i + lrow, r1 - 1) * (unsigned)(D * 4) + in_row;
+        }
+    }
+    const char* qbase = reinterpret_cast<const char*>(qhat) - 3072;
+    const char* pbase = reinterpret_cast<const char*>(pool) - 3072;
+    auto issue = [&](int p) {                             // piece p: kind p / NG, line group p % NG -> ring slot p % P
+        const int kind = p / NG;
+        scan_glds_piece((kind == 0 ? qbase : pbase) + 128 * KW * (p % NG), voff[kind][0], voff[kind][1], voff[kind][2], voff[kind][3],
+                        ring_lds + (p % P) * 4096);
+    };
+    const int fsw = (li >> 1) & 7;
+    auto read_piece = [&](int p, float4 (&f)[4]) {        // lane (row li, half lh): chunks lh, 2 + lh, 4 + lh, 6 + lh of its row
+        const float4* base = reinterpret_cast<const float4*>(ring + (p % P) * 4096 + li * 128);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = base[(2 * u + lh) ^ fsw];
+    };
+    f32x16s acc2[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+    const bool has2 = r1 - r0 > 32;                       // workgroup-uniform
+    auto body = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;       // tiles of this workgroup
+        constexpr int NP = NG * (1 + NT);                 // pieces: queries, tile 0, (tile 1)
+        // pieces outstanding BEHIND piece k when it is waited for: min(NP, k + P) have been issued by then
+#define SCAN_BEHIND(k) (4 * (((NP) < (k) + P ? (NP) : (k) + P) - (k) - 1))
+#pragma unroll
+        for (int p = 0; p < P && p < NP; ++p) issue(p);
+        SCAN_WSTAMP(1);
+        u32x4v q3[NG][2][3];
+        const bool ok = q0 + li < Q;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 f[4];
+            scan_wait_vmcnt(SCAN_BEHIND(g));
+            if (g == NG - 1) SCAN_WSTAMP(2);
+            read_piece(g, f);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (g + P < NP) issue(g + P);
+            if (!ok) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { f[u].x = 0.f; f[u].y = 0.f; f[u].z = 0.f; f[u].w = 0.f; }
+            }
+            scan_split8(f[0], f[1], q3[g][0][0], q3[g][0][1], q3[g][0][2]);
+            scan_split8(f[2], f[3], q3[g][1][0], q3[g][1][1], q3[g][1][2]);
+        }
+#if SCAN_DBG & 8
+        asm volatile("" :: "v"(q3[NG - 1][1][2]));
+        SCAN_WSTAMP(3);
+#endif
+        constexpr int NTP = NG * NT;                      // tile pieces; piece NG + tp = (tile tp / NG, line group tp % NG)
+        float4 cur[4], nxt[4];
+        scan_wait_vmcnt(SCAN_BEHIND(NG));
+        read_piece(NG, cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (NG + P < NP) issue(NG + P);
+        u32x4v ch, cm, cl;
+        scan_split8(cur[0], cur[1], ch, cm, cl);
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+            const int p = NG + tp, g = tp % NG, h = tp / NG;
+            u32x4v nh, nm, nl;
+            scan_split8(cur[2], cur[3], nh, nm, nl);                         // ... inside the six MFMAs of the step before it
+            SCAN_STEP6(acc2[h], q3[g][0], ch, cm, cl);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+            if (tp + 1 < NTP) {
+                scan_wait_vmcnt(SCAN_BEHIND(p + 1));
+                read_piece(p + 1, nxt);
+                scan_split8(nxt[0], nxt[1], ch, cm, cl);
+            }
+            SCAN_STEP6(acc2[h], q3[g][1], nh, nm, nl);
+            if (tp + 1 < NTP) {
+                // the next piece's fragments are still on their way from LDS: two MFMAs first, then the split in the gaps
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (p + 1 + P < NP) issue(p + 1 + P);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            }
+#if SCAN_DBG & 8
+            if (tp == NG - 1) { asm volatile("" :: "v"(acc2[0][0])); SCAN_WSTAMP(4); }
+#endif
+        }
+#if SCAN_DBG & 8
+        asm volatile("" :: "v"(acc2[0][0]), "v"(acc2[1][0]));
+        SCAN_WSTAMP(5);
+#endif
+#undef SCAN_BEHIND
+    };
+    if (has2) body(ScanInt<2>{}); else body(ScanInt<1>{});
+    // cross-wave reduction: wavefront w's partial tiles go into ITS OWN ring (all of its pieces are consumed), 4 KB per tile,
+    // [dst wave][lane][R]; same fixed summation order as pool_scan_ks_kernel
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float* base = reinterpret_cast<float*>(ring + h * 4096);
+#pragma unroll
+        for (int wd = 0; wd < KW; ++wd)
+#pragma unroll
+            for (int i = 0; i < R; ++i) base[(wd * 64 + lane) * R + i] = acc2[h][wd * R + i];
+    }
+    __syncthreads();
+    SCAN_WSTAMP(6);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float fin[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) fin[i] = 0.f;
+#pragma unroll
+        for (int p = 0; p < KW; ++p) {
+            const float* base = reinterpret_cast<const float*>(scan_lds + p * (P * 4096) + h * 4096);
+#pragma unroll
+            for (int i = 0; i < R; ++i) fin[i] += base[(w * 64 + lane) * R + i];
+        }
+        const int row = r0 + 32 * h + li;
+        if (row < r1) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = w * R + i;
+                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (q < Q && (!(SCAN_DBG & 8) || q < 16) && !(SCAN_DBG & 2)) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+            }
+        }
+    }
+#if SCAN_DBG & 8
+    SCAN_WSTAMP(7);
+    if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { stamps[3] = __builtin_amdgcn_s_memrealtime(); stamps[6] = __builtin_amdgcn_s_memtime(); stamps[4] = (unsigned long long)__builtin_amdgcn_s_getreg(6164);
+                    stamps[1] = stamps[0]; stamps[2] = stamps[0]; stamps[8] = stamps[9] = stamps[12] = stamps[13] = stamps[3]; }
+#endif
+#undef SCAN_WSTAMP
+}
+
+template <int KW, int NG, bool S3>
+static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, int N, float* scores, unsigned* zero_d, int nzero,
                                hipStream_t s) {
     static int wgs_per_cu = 0;
     if (wgs_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ks_kernel<KW, NG, false>, 64 * KW, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ks_kernel<KW, NG, false, S3>, 64 * KW, 0) != hipSuccess || nb < 1) nb = 1;
         wgs_per_cu = nb;
     }
     static int force = -1, two = -1;
@@ -276,18 +626,42 @@ static int launch_scan_variant(const float* qhat, const float* pool, int Q, int 
     // short shards (<= 3 tiles per CU): ONE workgroup per CU owning an equal, contiguous share of the rows, two tiles in
     // flight and one joint reduction; long ones: round-robin tiles over the occupancy-sized grid
     const bool shortr = two && KW * NG >= 8 && ntiles > 256 && ntiles <= 3 * 256;
-    if (shortr) {
+    static int dma = -1;
+    if (dma < 0) { const char* e = getenv("R4D_SCAN_DMA"); dma = e ? atoi(e) : 1; }                // tuning aid: 0 = register-staged form only
+    if (S3 && dma && KW * NG >= 8 && ntiles <= 2 * 256) { // <= 64 rows per CU: the LDS-DMA staged form
+        R4D_BRANCH(SCAN_DMA);
+        constexpr int lds_bytes = KW * 4 * 4096;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_scan_dma_kernel<KW, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+                set_error("pool_scan: cannot reserve %d bytes of LDS", lds_bytes);
+                return R4D_ERR_HIP;
+            }
+            attr = true;
+        }
+        const int rpw = max(8, cdiv(N, 256));            // rows dealt evenly over the CUs (a share below 32 rows leaves MFMA columns idle, not CUs)
+        hipLaunchKernelGGL((pool_scan_dma_kernel<KW, NG>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), lds_bytes, s, qhat, pool, Q, N,
+                           rpw, scores, zero_d, nzero);
+    } else if (shortr) {
         R4D_BRANCH(SCAN_SHORT);
         const int rpw = cdiv(N, 256);
-        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, (KW * NG >= 8)>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat,
+        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, (KW * NG >= 8), S3>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat,
                            pool, Q, N, rpw, scores, zero_d, nzero);
     } else {
         const int gx = max(1, min(ntiles, 256 * per_cu));
-        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, false>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat, pool, Q, N, 0,
+        hipLaunchKernelGGL((pool_scan_ks_kernel<KW, NG, false, S3>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), 0, s, qhat, pool, Q, N, 0,
                            scores, zero_d, nzero);
     }
     R4D_CHECK_LAUNCH("pool_scan");
     return R4D_OK;
+}
+
+template <int KW, int NG>
+static int launch_scan_variant(const float* qhat, const float* pool, int Q, int N, float* scores, unsigned* zero_d, int nzero,
+                               hipStream_t s) {
+    if (g_gemm_split3) { R4D_BRANCH(SCAN_BF16X3); return launch_scan_variant_p<KW, NG, true>(qhat, pool, Q, N, scores, zero_d, nzero, s); }
+    R4D_BRANCH(SCAN_F32);
+    return launch_scan_variant_p<KW, NG, false>(qhat, pool, Q, N, scores, zero_d, nzero, s);
 }
 
 // d -> (KW, NG) with d == 32 * KW * NG; +1 = no instantiation (the tiled GEMM takes the call)

@@ -112,7 +112,15 @@ def test_every_dispatcher_branch_is_exercised(dev):
         assert np.array_equal(idx.cpu().numpy(), order), (Q, N, d)           # exact selection on the device's own scores
     for d in (32, 64, 128, 256, 384, 512, 768, 1024):
         scan(32, 700, d)
-    scan(32, 12500, 512)         # short shard: even row ranges, two tiles in flight
+    scan(32, 12500, 512)         # short shard (<= 64 rows per CU): LDS-DMA staged form
+    scan(32, 20000, 512)         # 65-96 rows per CU: even row ranges, two tiles in flight, register-staged
+    scan(32, 40000, 768)         # long shard: round-robin tiles
+    ops.set_gemm_split3(False)   # the exact-f32 form of the scan (bench.py --gemm f32)
+    try:
+        scan(32, 12500, 512)
+        scan(32, 700, 256)
+    finally:
+        ops.set_gemm_split3(True)
     scan(80, 3000, 512)          # Q > 64: tiled GEMM + (x+1)/2 epilogue
     scan(7, 300, 96)             # no scan variant for d = 96: tiled GEMM
     for rows, n, k, dt in ((3, 900, 7, torch.float32), (2, 100000, 10, torch.float32), (2, 300000, 64, torch.float32),

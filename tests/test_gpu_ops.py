@@ -416,6 +416,34 @@ def test_score_topk_every_scan_variant(dev, d):
         assert np.array_equal(i2.cpu().numpy(), ei + 7) and np.array_equal(v2.cpu().numpy(), ev), (d, Q, N)
 
 
+@pytest.mark.parametrize("d", [256, 384, 512, 768, 1024])
+def test_short_shard_scan_forms_agree_bit_for_bit(dev, d):
+    """A shard of 8k-16k rows takes the LDS-DMA staged form of the pool scan (<= 64 rows per CU), 16k-24k rows the
+    register-staged two-tile form, longer ones the round-robin form: the same rows must score identically in all of them
+    (shard merge == one GPU), for one or two tiles per workgroup, ragged last tiles and query counts around the 32-query
+    block; values against the oracle."""
+    from rag4dyg_amd import ops
+    from oracle import retrieval_ref
+    g = torch.Generator().manual_seed(1000 + d)
+    p = torch.randn(30000, d, generator=g) + 0.1
+    ph = ops.normalize_rows(p.to(dev))
+    for Q in (1, 32, 33, 64):
+        q = torch.randn(Q, d, generator=g)
+        qh = ops.normalize_rows(q.to(dev))
+        _, _, S_long = ops.score_topk(qh, ph, 10, want_scores=True)                       # 938 tiles: round-robin form
+        _, _, S_two = ops.score_topk(qh, ph[:20000].contiguous(), 10, want_scores=True)   # 625 tiles: two tiles in flight, registers
+        assert torch.equal(S_two, S_long[:, :20000]), (d, Q)
+        for n in (8193, 8224, 12500, 16383, 16384):
+            v, i, S = ops.score_topk(qh, ph[:n].contiguous(), 10, index_offset=3, want_scores=True)
+            assert torch.equal(S, S_long[:, :n]), (d, Q, n)
+            ev, ei = retrieval_ref.topk_stable(S.cpu().numpy(), 10)
+            assert np.array_equal(i.cpu().numpy(), ei + 3) and np.array_equal(v.cpu().numpy(), ev), (d, Q, n)
+        if Q == 33:
+            ref = retrieval_ref.score_batch(q, p[:12500]).numpy()
+            S = ops.score_topk(qh, ph[:12500].contiguous(), 10, want_scores=True)[2].cpu().numpy()
+            assert rel_err(S, ref) < 1e-5 and elementwise_err(S, ref) < 1, (d, Q)
+
+
 def _rank_inputs(rows, n, seed, dtype):
     """Score rows full of ties and special values: quantised normals, duplicated columns, +-inf, -0.0, NaN."""
     rng = np.random.default_rng(seed)

@@ -74,6 +74,7 @@ def graph_wall(fn, iters=20, reps=5):
 
 
 def scan():
+    s3 = ops.gemm_split3_enabled()                      # R4D_GEMM_SPLIT3=0: the exact-f32 form of the scan
     cases = [(12500, 512), (100000, 512), (12500, 768), (100000, 768)]
     if os.environ.get("R4D_SCAN_CASES"):
         cases = [tuple(int(x) for x in c.split("x")) for c in os.environ["R4D_SCAN_CASES"].split(",")]
@@ -91,7 +92,7 @@ def scan():
                        "frac": round(s["gbs"] / PEAK, 4)},
              topk_us=round(sum(v["us"] * v["launches"] for n, v in pr.items() if n == "topk"), 2),
              topk_launches=sum(v["launches"] for n, v in pr.items() if n == "topk"),
-             env={k_: v for k_, v in os.environ.items() if k_.startswith("R4D_SCAN")},
+             operands="bf16x3" if s3 else "f32", env={k_: v for k_, v in os.environ.items() if k_.startswith("R4D_SCAN")},
              queries_per_s_scan_topk=round(Q / gw, 1))
     # full-row ranking (file-compat mode) at the north-star pool size
     S = torch.rand(32, 100000, generator=torch.Generator().manual_seed(2)).to(dev)

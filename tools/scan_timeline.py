@@ -23,7 +23,8 @@ for it in range(4):
 st = S[16:].contiguous().view(-1).view(torch.int64).cpu().numpy()
 nwg = 0
 rows = []
-while (nwg + 1) * 16 <= st.size and st[nwg * 16] > 0 and 0 < st[nwg * 16 + 3] - st[nwg * 16] < 10**7:
+grid = int(st[10]) if 0 < st[10] < 10**6 else 10**9
+while nwg < grid and (nwg + 1) * 16 <= st.size and st[nwg * 16] > 0 and 0 < st[nwg * 16 + 3] - st[nwg * 16] < 10**7:
     rows.append(st[nwg * 16:nwg * 16 + 16])
     nwg += 1
 a = np.array(rows, dtype=np.int64)
@@ -41,3 +42,15 @@ print(f"  per-workgroup duration: median {np.median(dur):.2f} max {dur.max():.2f
 clk = (a[:, 6] - a[:, 5]) / np.maximum(a[:, 3] - a[:, 0], 1) * 0.1      # shader cycles per 10 ns -> GHz
 print(f"  shader clock over the workgroup's lifetime (s_memtime / s_memrealtime): median {np.median(clk):.2f} GHz, min {clk.min():.2f}, max {clk.max():.2f}")
 print("  workgroups per XCC id:", np.bincount((a[:, 4] & 0xf).astype(int)))
+
+# per-wavefront stamps (two-tiles-in-flight bf16x3 form): [nwg * KW waves][8]
+KW = 8 if d in (512, 768, 1024) else (4 if d >= 128 else d // 32)
+ws = st[nwg * 16: nwg * 16 + nwg * KW * 8].reshape(nwg, KW, 8)
+if (ws[:, :, 0] > 0).all() and (ws[:, :, 7] >= ws[:, :, 0]).all():
+    rel = (ws - t0) * 0.01
+    names = ("start", "loads issued", "tile 0 + queries landed", "queries split", "tile 0 MFMAs done", "tile 1 MFMAs done", "past the barrier", "stores issued")
+    print("  per wavefront (median over workgroups; us):")
+    print("    wave " + "".join(f"{n[:14]:>16s}" for n in names))
+    for w in range(KW):
+        print(f"    {w:4d} " + "".join(f"{np.median(rel[:, w, c]):16.2f}" for c in range(8)))
+    print("    slowest wavefront of a workgroup, median over workgroups: " + ", ".join(f"{names[c]} {np.median(rel[:, :, c].max(axis=1)):.2f}" for c in (2, 4, 5)))
