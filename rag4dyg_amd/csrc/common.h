@@ -73,7 +73,7 @@ struct ProfScope {
     X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
     X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
     X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \
-    X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_DMA, "scan:short shard, LDS-DMA staged") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)") X(SCAN_BF16X3, "scan:bf16x3 operands") X(SCAN_F32, "scan:exact-f32 operands")  \
+    X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_DMA, "scan:short shard, LDS-DMA staged") X(SCAN_RING, "scan:long shard, LDS-DMA ring") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)") X(SCAN_BF16X3, "scan:bf16x3 operands") X(SCAN_F32, "scan:exact-f32 operands")  \
     X(TOPK_ONE_WG, "topk:one workgroup per row") X(TOPK_TICKET, "topk:cross-workgroup ticket merge")                      \
     X(TOPK_MULTI, "topk:second launch over candidates") X(TOPK_F64, "topk:f64 rows")                                      \
     X(LN4_2, "layernorm:ln4<2>") X(LN4_4, "layernorm:ln4<4>") X(LN4_8, "layernorm:ln4<8>") X(LN_GENERIC, "layernorm:generic") \

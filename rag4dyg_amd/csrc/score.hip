@@ -1,11 +1,16 @@
-// Retrieval scoring on gfx950: row normalisation and the query-vs-pool cosine scan (exact-f32 MFMA), handing the
-// score rows to the one-launch top-k of topk.hip.
+// Retrieval scoring on gfx950: row normalisation and the query-vs-pool cosine scan, handing the score rows to the one-launch
+// top-k of topk.hip.  Three forms of the scan, bit-identical in their scores: pool_scan_ks_kernel (operands straight from
+// global memory into MFMA registers: the exact-f32 mode and d <= 128), pool_scan_dma_kernel (bf16x3 operands, LDS-DMA staged:
+// shards of up to 64 rows per CU) and pool_scan_ring_kernel (the same staging as a stream: longer shards).
 // Reference: train/train_retriever.py:433-438 (normalise, matmul, (x+1)/2) and :357-358,461-467 (argsort).
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef SCAN_RING_P
+#define SCAN_RING_P 3   // ring slots per wavefront of the long-shard form (tuning aid: 4 = deeper ring, single-buffered partial tiles)
+#endif
 #ifndef SCAN_DBG
 #define SCAN_DBG 0   // tuning aid (tools/kc_ablate.sh score.hip SCAN_DBG n): bit 0 skips the MFMAs (and the split), bit 1 the score stores, bit 2 the cross-wave reduction (one-tile form), bit 3 writes s_memrealtime stamps (100 MHz) of workgroup phases over the score rows of queries >= 16 (tools/scan_timeline.py), bit 4 skips the bf16x3 split arithmetic only, bit 5 makes every query load read ONE line, bit 6 makes every pool load read 8 whole lines (timing of other access patterns)
 #endif
@@ -609,6 +614,161 @@ __global__ __launch_bounds__(64 * KW, 1) void pool_scan_dma_kernel(const float* 
 #undef SCAN_WSTAMP
 }
 
+
+// ------------------------------------------------------------------------------------ long shards: the same staging as a ring
+// pool_scan_dma_kernel's pieces (32 rows x one 128-byte line, four DMA instructions of whole lines, chunk-permuted source,
+// ds_read_b128 fragments, split pinned into the MFMA gaps) as a STREAM: workgroup b walks the tiles b, b + G, ... of the shard
+// (round-robin: at any moment the workgroups read adjacent lines), wavefront w keeps P = 3 pieces of its own lines in flight
+// in a private ring (a slot is refilled as soon as its fragments are in registers), and after the NG pieces of a tile the KW
+// partial tiles meet in LDS exactly as in pool_scan_ks_kernel (double-buffered, ONE barrier per tile -- a raw s_barrier behind
+// lgkmcnt(0): __syncthreads() would also wait vmcnt(0) and drain the ring).  LDS: 96 KB ring + 64 KB partial tiles at KW = 8.
+// Same chunk -> MFMA-slot bijection, product order and reduction order as every other form: bit-identical scores.
+template <int KW, int NG>
+__global__ __launch_bounds__(64 * KW, KW == 8 ? 1 : 2) void pool_scan_ring_kernel(const float* __restrict__ qhat, const float* __restrict__ pool,
+                                                                                int Q, int N, float* __restrict__ scores,
+                                                                                unsigned* __restrict__ zero_d, int nzero) {
+    constexpr int D = 32 * KW * NG;
+    constexpr int R = 16 / KW;
+    constexpr int P = SCAN_RING_P;                        // 3: partial tiles double-buffered, one barrier per tile; 4: one buffer, two barriers
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.y * 32;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = tid; i < nzero; i += 64 * KW) zero_d[i] = 0u;
+    const int G = (int)gridDim.x;
+    const int ntl = ((N + 31) / 32 - (int)blockIdx.x + G - 1) / G;       // tiles of this workgroup (>= 1: G <= tiles)
+    const int NPt = NG * (1 + ntl);                                       // pieces: the queries', then NG per tile
+    unsigned char* ring = scan_lds + w * (P * 4096);
+    float* red = reinterpret_cast<float*>(scan_lds + KW * (P * 4096));
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);
+    const int c0 = (lane & 7) ^ (lane >> 4), lrow = lane >> 3;
+    unsigned in_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in_row[i] = 128u * w + 16u * (c0 ^ (4 * (i & 1))) + 3072u - 1024u * i;
+    const char* qbase = reinterpret_cast<const char*>(qhat) - 3072;
+    const char* pbase = reinterpret_cast<const char*>(pool) - 3072;
+    // issue side: piece `ik` goes to slot `islot`; its lane offsets are the queries' or those of tile (ik - NG) / NG
+    int ik = 0, islot = 0, ig = 0, itile = (int)blockIdx.x;
+    unsigned ivoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ivoff[i] = (unsigned)min(q0 + 8 * i + lrow, Q - 1) * (unsigned)(D * 4) + in_row[i];
+    auto issue_next = [&]() {                             // workgroup-uniform control flow
+        if (ik >= NPt) return;
+        scan_glds_piece((ik < NG ? qbase : pbase) + 128 * KW * ig, ivoff[0], ivoff[1], ivoff[2], ivoff[3], ring_lds + islot * 4096);
+        ++ik;
+        islot = islot + 1 == P ? 0 : islot + 1;
+        if (++ig == NG) {
+            ig = 0;
+            if (ik > NG) itile += G;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ivoff[i] = (unsigned)min(itile * 32 + 8 * i + lrow, N - 1) * (unsigned)(D * 4) + in_row[i];
+        }
+    };
+    const int fsw = (li >> 1) & 7;
+    int ck = 0, cslot = 0;                                // consume side
+    auto wait_piece = [&]() {                             // pieces issued behind piece ck: min(NPt, ck + P) - ck - 1
+        const int behind = min(NPt, ck + P) - ck - 1;
+        if (behind >= 3) scan_wait_vm<12>(); else if (behind == 2) scan_wait_vm<8>(); else if (behind == 1) scan_wait_vm<4>(); else scan_wait_vm<0>();
+    };
+    auto read_piece = [&](float4 (&f)[4]) {
+        const float4* base = reinterpret_cast<const float4*>(ring + cslot * 4096 + li * 128);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = base[(2 * u + lh) ^ fsw];
+        ++ck;
+        cslot = cslot + 1 == P ? 0 : cslot + 1;
+    };
+#pragma unroll
+    for (int p = 0; p < P; ++p) issue_next();
+    u32x4v q3[NG][2][3];
+    {
+        const bool ok = q0 + li < Q;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 f[4];
+            wait_piece();
+            read_piece(f);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_next();
+            if (!ok) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { f[u].x = 0.f; f[u].y = 0.f; f[u].z = 0.f; f[u].w = 0.f; }
+            }
+            scan_split8(f[0], f[1], q3[g][0][0], q3[g][0][1], q3[g][0][2]);
+            scan_split8(f[2], f[3], q3[g][1][0], q3[g][1][1], q3[g][1][2]);
+        }
+    }
+    float4 cur[4], nxt[4];
+    wait_piece();
+    read_piece(cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue_next();
+    u32x4v ch, cm, cl;
+    scan_split8(cur[0], cur[1], ch, cm, cl);
+    int buf = 0;
+    for (int j = 0; j < ntl; ++j) {
+        f32x16s acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            u32x4v nh, nm, nl;
+#if SCAN_DBG & 1
+            acc[0] += cur[0].x + cur[1].y + cur[2].z + cur[3].w; nh = ch; nm = cm; nl = cl;
+#else
+            scan_split8(cur[2], cur[3], nh, nm, nl);
+            SCAN_STEP6(acc, q3[g][0], ch, cm, cl);
+#endif
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+            if (ck < NPt) {                               // workgroup-uniform: false only at the very last piece
+                wait_piece();
+                read_piece(nxt);
+#if !(SCAN_DBG & 1)
+                scan_split8(nxt[0], nxt[1], ch, cm, cl);
+                SCAN_STEP6(acc, q3[g][1], nh, nm, nl);
+#endif
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_next();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            } else {
+#if !(SCAN_DBG & 1)
+                SCAN_STEP6(acc, q3[g][1], nh, nm, nl);
+#endif
+            }
+        }
+        // cross-wave reduction of the tile: red[buf][src wave][dst wave][lane][R], fixed summation order
+        float* base = red + (P == 3 ? buf : 0) * (KW * KW * 64 * R);
+#pragma unroll
+        for (int wd = 0; wd < KW; ++wd)
+#pragma unroll
+            for (int i = 0; i < R; ++i) base[((w * KW + wd) * 64 + lane) * R + i] = acc[wd * R + i];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float fin[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) fin[i] = 0.f;
+#pragma unroll
+        for (int p = 0; p < KW; ++p)
+#pragma unroll
+            for (int i = 0; i < R; ++i) fin[i] += base[((p * KW + w) * 64 + lane) * R + i];
+        buf ^= 1;
+        if (P != 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the one buffer is rewritten by the next tile
+        const int row = ((int)blockIdx.x + j * G) * 32 + li;
+        if (row < N) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = w * R + i;
+                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (q < Q && !(SCAN_DBG & 2)) scores[(long long)q * N + row] = (fin[i] + 1.0f) / 2.0f;
+            }
+        }
+    }
+}
+
 template <int KW, int NG, bool S3>
 static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, int N, float* scores, unsigned* zero_d, int nzero,
                                hipStream_t s) {
@@ -627,8 +787,8 @@ static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, in
     // flight and one joint reduction; long ones: round-robin tiles over the occupancy-sized grid
     const bool shortr = two && KW * NG >= 8 && ntiles > 256 && ntiles <= 3 * 256;
     static int dma = -1;
-    if (dma < 0) { const char* e = getenv("R4D_SCAN_DMA"); dma = e ? atoi(e) : 1; }                // tuning aid: 0 = register-staged form only
-    if (S3 && dma && KW * NG >= 8 && ntiles <= 2 * 256) { // <= 64 rows per CU: the LDS-DMA staged form
+    if (dma < 0) { const char* e = getenv("R4D_SCAN_DMA"); dma = e ? atoi(e) : 3; }                // tuning aid: bit 0 = LDS-DMA form for short shards, bit 1 = ring form for long ones (0: register-staged forms only)
+    if (S3 && (dma & 1) && KW * NG >= 8 && ntiles <= 2 * 256) { // <= 64 rows per CU: the LDS-DMA staged form
         R4D_BRANCH(SCAN_DMA);
         constexpr int lds_bytes = KW * 4 * 4096;
         static bool attr = false;
@@ -642,6 +802,22 @@ static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, in
         const int rpw = max(8, cdiv(N, 256));            // rows dealt evenly over the CUs (a share below 32 rows leaves MFMA columns idle, not CUs)
         hipLaunchKernelGGL((pool_scan_dma_kernel<KW, NG>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), lds_bytes, s, qhat, pool, Q, N,
                            rpw, scores, zero_d, nzero);
+    } else if (S3 && (dma & 2) && KW * NG >= 8) {         // long shards: the ring form
+        R4D_BRANCH(SCAN_RING);
+        constexpr int lds_bytes = KW * SCAN_RING_P * 4096 + (SCAN_RING_P == 3 ? 2 : 1) * KW * KW * 64 * (16 / KW) * 4;
+        static int ring_per_cu = 0;
+        if (ring_per_cu == 0) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_scan_ring_kernel<KW, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+                set_error("pool_scan: cannot reserve %d bytes of LDS", lds_bytes);
+                return R4D_ERR_HIP;
+            }
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pool_scan_ring_kernel<KW, NG>, 64 * KW, lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            ring_per_cu = nb;
+        }
+        const int gx = max(1, min(ntiles, 256 * (force > 0 ? force : ring_per_cu)));
+        hipLaunchKernelGGL((pool_scan_ring_kernel<KW, NG>), dim3(gx, cdiv(Q, 32)), dim3(64 * KW), lds_bytes, s, qhat, pool, Q, N, scores,
+                           zero_d, nzero);
     } else if (shortr) {
         R4D_BRANCH(SCAN_SHORT);
         const int rpw = cdiv(N, 256);
