@@ -94,7 +94,10 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------ fp32 MFMA GEMM (gemm_f32.hip)
-enum GemmEpilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_SCALE_DIV = 3, EPI_HALF_PLUS = 4 };
+enum GemmEpilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_SCALE_DIV = 3, EPI_HALF_PLUS = 4,
+                    // gemm_s3 only (training): GELU_KEEP writes gelu(v) to C and the pre-activation v to the `resid` buffer;
+                    // GELU_GRAD writes v * gelu'(u) with u read from the `resid` buffer
+                    EPI_GELU_KEEP = 5, EPI_GELU_GRAD = 6 };
 enum GemmCausal { CAUSAL_NONE = 0, CAUSAL_QK = 1, CAUSAL_PV = 2 };
 
 struct GemmArgs {

@@ -70,6 +70,15 @@ __device__ __forceinline__ float gelu_new_s3_1(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
+// d gelu_new / dx with the exponential of gelu_new_s3: tanh(u) = 1 - 2 / (1 + e^(2u))
+__device__ __forceinline__ float gelu_new_grad_s3(float x) {
+    const float c = 0.7978845608028654f;
+    const float x2 = x * x;
+    const float u2 = 2.0f * c * 1.4426950408889634f * x * __builtin_fmaf(x2, 0.044715f, 1.0f);     // 2u log2(e)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * __builtin_fmaf(x2, 3.0f * 0.044715f, 1.0f);
+}
+
 struct S3Shape {
     int M, N, K, lda, ldc, ldr;
     int plane_bytes;          // N * K * 2: distance between the bf16 planes of W
@@ -333,15 +342,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
-            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+            const_cast<float*>(EPI >= EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            EPI >= EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float res[16];
-                if (EPI == EPI_RESIDUAL) {
+                if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -350,8 +359,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #pragma unroll
                 for (int r2 = 0; r2 < 16; r2 += 2) {
                     f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
-                    if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
+                    if (EPI == EPI_GELU_KEEP) {                       // the pre-activation, for the backward pass
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int r = r2 + h2;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, h2 ? v2.y : v2.x), r_rsrc, lane_r,
+                                                                  ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0);
+                        }
+                    }
+                    if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v2 = gelu_new_s3(v2);
                     else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+                    else if (EPI == EPI_GELU_GRAD) { v2.x *= gelu_new_grad_s3(res[r2]); v2.y *= gelu_new_grad_s3(res[r2 + 1]); }
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = r2 + h2;
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float res[16];
-            if (EPI == EPI_RESIDUAL) {
+            if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
@@ -384,8 +402,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bias;
-                if (EPI == EPI_GELU) v = gelu_new_s3_1(v);
+                if (EPI == EPI_GELU_KEEP && row < g.M && col_ok) const_cast<float*>(residg)[(long long)row * g.ldr + col] = v;
+                if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v = gelu_new_s3_1(v);
                 else if (EPI == EPI_RESIDUAL) v += res[r];
+                else if (EPI == EPI_GELU_GRAD) v *= gelu_new_grad_s3(res[r]);
                 if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
         }
@@ -563,15 +583,15 @@ __global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
             const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 Cg + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
-                EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+                const_cast<float*>(EPI >= EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+                EPI >= EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     float res[16];
-                    if (EPI == EPI_RESIDUAL) {
+                    if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -580,8 +600,17 @@ __global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
 #pragma unroll
                     for (int r2 = 0; r2 < 16; r2 += 2) {
                         f32x2s v2 = {acc[i][j][r2] + bias, acc[i][j][r2 + 1] + bias};
-                        if (EPI == EPI_GELU) v2 = gelu_new_s3(v2);
+                        if (EPI == EPI_GELU_KEEP) {
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const int r = r2 + h2;
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, h2 ? v2.y : v2.x), r_rsrc, lane_r,
+                                                                      ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0);
+                            }
+                        }
+                        if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v2 = gelu_new_s3(v2);
                         else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+                        else if (EPI == EPI_GELU_GRAD) { v2.x *= gelu_new_grad_s3(res[r2]); v2.y *= gelu_new_grad_s3(res[r2 + 1]); }
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const int r = r2 + h2;
@@ -604,8 +633,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float vv = acc[i][j][r] + bias;
-                        if (EPI == EPI_GELU) vv = gelu_new_s3_1(vv);
+                        if (EPI == EPI_GELU_KEEP && row < g.M && col_ok) const_cast<float*>(residg)[(long long)row * g.ldr + col] = vv;
+                        if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) vv = gelu_new_s3_1(vv);
                         else if (EPI == EPI_RESIDUAL) vv += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
+                        else if (EPI == EPI_GELU_GRAD) vv *= gelu_new_grad_s3(residg[(long long)min(row, g.M - 1) * g.ldr + colc]);
                         if (row < g.M && col_ok) Cg[(long long)row * g.ldc + col] = vv;
                     }
                 }
@@ -651,6 +682,8 @@ static int launch_s3(const S3Args& a, int cls, hipStream_t stream) {
         case EPI_NONE: S3_LAUNCH_(EPI_NONE); break;
         case EPI_GELU: S3_LAUNCH_(EPI_GELU); break;
         case EPI_RESIDUAL: S3_LAUNCH_(EPI_RESIDUAL); break;
+        case EPI_GELU_KEEP: S3_LAUNCH_(EPI_GELU_KEEP); break;
+        case EPI_GELU_GRAD: S3_LAUNCH_(EPI_GELU_GRAD); break;
         default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
     }
 #undef S3_LAUNCH_
@@ -671,6 +704,8 @@ static int launch_s3p(const S3Args& a, hipStream_t stream) {
         case EPI_NONE: SP_LAUNCH_(EPI_NONE); break;
         case EPI_GELU: SP_LAUNCH_(EPI_GELU); break;
         case EPI_RESIDUAL: SP_LAUNCH_(EPI_RESIDUAL); break;
+        case EPI_GELU_KEEP: SP_LAUNCH_(EPI_GELU_KEEP); break;
+        case EPI_GELU_GRAD: SP_LAUNCH_(EPI_GELU_GRAD); break;
         default: set_error("gemm_s3: unknown epilogue %d", a.epilogue); return R4D_ERR_INVALID;
     }
 #undef SP_LAUNCH_
@@ -684,7 +719,8 @@ static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
     // measured (M = 63232; tools/s3_bench.py): K 512 N 1536 593 -> 576 us, K 512 N 2048 + gelu 689 -> 665 us, M 8864 81 -> 75 us;
     // with the RESIDUAL epilogue the persistent form is SLOWER (K 512 N 512: 189 -> 227 us, K 2048 N 512: 625 -> 700 us, static and
     // dynamic tile hand-out alike), so those launches keep one launch slot per tile (pers == 2 forces it for them too)
-    if (t == 0 && pers && (pers == 2 || a.epilogue != EPI_RESIDUAL) && (a.K / 32) % 2 == 0 && cdiv(a.M, 128) * cdiv(a.N, 256) > 256) {
+    const bool loads_in_epilogue = a.epilogue == EPI_RESIDUAL || a.epilogue == EPI_GELU_GRAD;     // (GELU_GRAD: 57.6 vs 57.9 ms per training step)
+    if (t == 0 && pers && (pers == 2 || !loads_in_epilogue) && (a.K / 32) % 2 == 0 && cdiv(a.M, 128) * cdiv(a.N, 256) > 256) {
         R4D_BRANCH(S3_PERSISTENT);
         return launch_s3p(a, stream);
     }
@@ -704,7 +740,8 @@ int launch_gemm_s3(const S3Args& a, hipStream_t stream) {
     R4D_REQUIRE(a.A && a.planes && a.C, "gemm_s3: null pointer");
     R4D_REQUIRE(gemm_s3_supported(a.M, a.K, a.N), "gemm_s3: unsupported shape M=%d K=%d N=%d (K %% 32 == 0 wanted)", a.M, a.K, a.N);
     R4D_REQUIRE(a.lda % 4 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_s3: alignment");
-    R4D_REQUIRE(a.epilogue != EPI_RESIDUAL || a.resid, "gemm_s3: residual epilogue needs the residual");
+    R4D_REQUIRE(a.epilogue < EPI_RESIDUAL || a.resid, "gemm_s3: this epilogue needs the second buffer");
+    R4D_REQUIRE(a.epilogue != EPI_SCALE_DIV && a.epilogue != EPI_HALF_PLUS, "gemm_s3: epilogue %d has no instantiation", a.epilogue);
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("R4D_GEMM_S3_TILE"); forced = e ? atoi(e) : -1; }
     if (forced >= 0 && forced < kNumS3) return s3_launch_tile(a, forced, stream);

@@ -17,6 +17,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <stdlib.h>
 #include "common.h"
 
 namespace r4d {
@@ -28,6 +29,7 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
 size_t colsum_scratch_floats(long long rows, int n);
 int launch_colsum(const float* x, long long rows, int n, int ld, float* out, float* scratch, int accumulate, hipStream_t s);
 int launch_gelu_fwd(const float* pre, long long n, float* y, hipStream_t s);
+static int g_train_fuse_gelu = -1;    // tuning aid: R4D_TRAIN_FUSE_GELU=0 keeps the two element-wise GELU launches (read once, below)
 int launch_gelu_bwd(const float* pre, const float* dy, long long n, float* dx, hipStream_t s);
 int launch_softmax_bwd(const float* P, float* dP, int nbh, int T, int ld, float scale_div, hipStream_t s);
 int launch_transpose(const float* in, int rows, int cols, long long ld_in, long long stride_in, float* out, long long ld_out,
@@ -120,13 +122,17 @@ static int fwd_linear(const float* x, const float* w, const float* wT, const flo
 }
 // dx[M,K] = dy[M,N] . W[K,N]^T : W's rows are k(N)-contiguous, i.e. W IS the [N' = K, K' = N] operand of the fast kernel;
 // `w3t` (nullable): its bf16x3 planes [3][K][N] -> the bf16 matrix cores at fp32 accuracy
-static int bwd_data(const float* dy, const float* w, int M, int K, int N, float* dx, hipStream_t s, const unsigned short* w3t = nullptr) {
+// `gelu_pre` (bf16x3 path only): dx = (dy . W^T) * gelu_new'(gelu_pre), gelu_pre [M,K]
+static int bwd_data(const float* dy, const float* w, int M, int K, int N, float* dx, hipStream_t s, const unsigned short* w3t = nullptr,
+                    const float* gelu_pre = nullptr) {
     if (w3t && g_gemm_split3 && gemm_s3_supported(M, N, K)) {
         S3Args a;
         memset(&a, 0, sizeof(a));
-        a.A = dy; a.planes = w3t; a.C = dx; a.M = M; a.N = K; a.K = N; a.lda = N; a.ldc = K; a.ldr = K; a.epilogue = EPI_NONE;
+        a.A = dy; a.planes = w3t; a.C = dx; a.M = M; a.N = K; a.K = N; a.lda = N; a.ldc = K; a.ldr = K;
+        a.epilogue = gelu_pre ? EPI_GELU_GRAD : EPI_NONE; a.resid = gelu_pre;
         return launch_gemm_s3(a, s);
     }
+    R4D_REQUIRE(!gelu_pre, "bwd_data: the fused GELU derivative needs the bf16x3 planes");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = w; g.C = dx;
@@ -288,6 +294,7 @@ size_t r4d_gpt2_train_workspace_bytes(const r4d_gpt2_config* cfg, int32_t n_grou
 int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, int32_t n_groups,
                                const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts, float* out_meanpool_d,
                                const r4d_train_dropout* dropout, void* workspace_d, size_t workspace_bytes, void* stream) {
+    if (g_train_fuse_gelu < 0) { const char* e = getenv("R4D_TRAIN_FUSE_GELU"); g_train_fuse_gelu = e ? atoi(e) : 1; }
     hipStream_t s = (hipStream_t)stream;
     std::vector<TrainGroup> gs;
     int rc = check_groups(cfg, n_groups, ids_d, Bs, Ts, gs);
@@ -327,8 +334,13 @@ int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
             if ((rc = launch_dropout(branch, x_in, (long long)M * d, x_mid, dc.resid_p, dc.key, 4u * l + 1u, 0, s))) return rc;
         } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s, Lw.attn_proj_w3))) return rc;
         if ((rc = launch_layernorm(x_mid, Lw.ln_2_w, Lw.ln_2_b, M, d, cfg->ln_eps, ln2, s))) return rc;
-        if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s, Lw.c_fc_w3))) return rc;
-        if ((rc = launch_gelu_fwd(pre, (long long)M * 4 * d, f, s))) return rc;
+        if (g_train_fuse_gelu && Lw.c_fc_w3 && g_gemm_split3 && gemm_s3_supported(M, d, 4 * d)) {
+            // one launch: f = gelu_new(v) and the pre-activation v (kept for the backward pass) both leave the GEMM's epilogue
+            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, pre, M, d, 4 * d, EPI_GELU_KEEP, f, s, Lw.c_fc_w3))) return rc;
+        } else {
+            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s, Lw.c_fc_w3))) return rc;
+            if ((rc = launch_gelu_fwd(pre, (long long)M * 4 * d, f, s))) return rc;
+        }
         float* x_next = l + 1 < cfg->n_layer ? ws + t.x_in[l + 1] : ws + t.x_out;
         if (dc.resid_p > 0.f) {                                      // x + dropout(c_proj(act(c_fc(x)))), :212,233
             if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s, Lw.mlp_proj_w3))) return rc;
@@ -343,6 +355,7 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
                                 int32_t n_groups, const int64_t* const* ids_d, const int32_t* Bs, const int32_t* Ts,
                                 const float* d_meanpool_d, const r4d_train_dropout* dropout, void* workspace_d,
                                 size_t workspace_bytes, void* stream) {
+    if (g_train_fuse_gelu < 0) { const char* e = getenv("R4D_TRAIN_FUSE_GELU"); g_train_fuse_gelu = e ? atoi(e) : 1; }
     hipStream_t s = (hipStream_t)stream;
     std::vector<TrainGroup> gs;
     int rc = check_groups(cfg, n_groups, ids_d, Bs, Ts, gs);
@@ -377,8 +390,13 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
             dbr = dy;
         }
         if ((rc = bwd_weight(f, dbr, M, 4 * d, d, Lg.mlp_proj_w, Lg.mlp_proj_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t))) return rc;                        // d(f)
-        if ((rc = launch_gelu_bwd(pre, dbig, (long long)M * 4 * d, dbig, s))) return rc;                  // d(pre), in place
+        if (g_train_fuse_gelu && Lw.mlp_proj_w3t && g_gemm_split3 && gemm_s3_supported(M, d, 4 * d)) {
+            // d(pre) = (d(branch) . Wp^T) * gelu_new'(pre): the derivative is applied in the GEMM's epilogue
+            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t, pre))) return rc;
+        } else {
+            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t))) return rc;                    // d(f)
+            if ((rc = launch_gelu_bwd(pre, dbig, (long long)M * 4 * d, dbig, s))) return rc;              // d(pre), in place
+        }
         if ((rc = bwd_weight(ln2, dbig, M, d, 4 * d, Lg.c_fc_w, Lg.c_fc_b, xT, red, s))) return rc;
         if ((rc = bwd_data(dbig, Lw.c_fc_w, M, d, 4 * d, dy, s, Lw.c_fc_w3t))) return rc;                              // d(ln_2 out)
         if ((rc = launch_ln_bwd(x_mid, Lw.ln_2_w, dy, dx, M, d, cfg->ln_eps, dx, Lg.ln_2_w, Lg.ln_2_b, red, 0, s))) return rc;   // dx = d(x_mid)
