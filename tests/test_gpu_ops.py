@@ -180,6 +180,44 @@ def test_kv_cache_decode_step_equals_full_forward(dev, L, H, d):
     assert torch.isnan(h2[2]).all() and not torch.isnan(h2[[0, 1, 3, 4]]).any()
 
 
+@pytest.mark.parametrize("H,d", [(8, 768), (2, 512)])
+def test_decode_step_fused_layernorm_with_large_mean_rows(dev, H, d):
+    """The decode step folds LayerNorm into the projection that follows it (rstd * (sum_k x_k g_k W_kn - mean * c1_n) + c2_n):
+    with a residual stream whose mean dwarfs its spread (embeddings shifted by 50, one outlier channel at +300 -- GPT-2's
+    outlier channels) the subtraction must not cancel: the cached step against a float64 evaluation of the same model and
+    against the library's own full forward (LayerNorm as a separate kernel)."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModel
+    L, V, P, B, cap = 2, 90, 64, 4, 32
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=P, seed=77, random_affine=True)
+    sd["transformer.wte.weight"] = sd["transformer.wte.weight"] + 50.0
+    sd["transformer.wte.weight"][:, 7] += 300.0
+    m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    m = m.to(dev).eval()
+    tr = m.transformer
+    g = torch.Generator().manual_seed(5)
+    lens = [9, 20, 3, 14]
+    seqs = [torch.randint(0, V, (n,), generator=g).tolist() for n in lens]
+    ids = torch.zeros(B, max(lens), dtype=torch.int64)
+    for i, s_ in enumerate(seqs):
+        ids[i, :len(s_)] = torch.tensor(s_)
+    cache = tr.new_kv_cache(B, cap, dev)
+    tr.prefill(cache, input_ids=ids.to(dev))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for step in range(3):
+        new = torch.randint(0, V, (B,), generator=g)
+        pos = torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32)
+        h = tr.decode_step(cache, pos, input_ids=new).cpu()
+        for i in range(B):
+            seqs[i].append(int(new[i]))
+            ref = gpt2_ref.gpt2_forward(sd64, torch.tensor([seqs[i]]), H, want_logits=False)["hidden"][0, -1]
+            full = tr.encode(torch.tensor([seqs[i]], device=dev))["hidden"][0, -1].cpu()
+            e_dec, e_full = rel_err(h[i].numpy(), ref.numpy()), rel_err(full.numpy(), ref.numpy())
+            assert e_dec < 1e-4, (step, i, e_dec, e_full)
+            assert e_dec < 20 * max(e_full, 1e-6), (step, i, e_dec, e_full)      # no worse than the unfused LayerNorm by more than rounding
+
+
 @pytest.mark.parametrize("L,H,d,B,V", [(2, 2, 64, 5, 90), (2, 8, 768, 32, 90), (1, 2, 512, 33, 90), (1, 8, 1024, 7, 90), (2, 2, 256, 32, 90),
                                        (1, 8, 1280, 4, 90), (1, 8, 1024, 4, 5000), (1, 2, 512, 9, 11919)])
 def test_device_greedy_loop_graph_equals_host_loop(dev, monkeypatch, L, H, d, B, V):
