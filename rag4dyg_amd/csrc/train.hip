@@ -34,8 +34,9 @@ int launch_gelu_bwd(const float* pre, const float* dy, long long n, float* dx, h
 int launch_softmax_bwd(const float* P, float* dP, int nbh, int T, int ld, float scale_div, hipStream_t s);
 int launch_transpose(const float* in, int rows, int cols, long long ld_in, long long stride_in, float* out, long long ld_out,
                      long long stride_out, int nbatch, hipStream_t s);
-int launch_embedding_bwd(const float* dx, const int64_t* ids, long long rows, int T, int d, int vocab, float* dwte, float* dwpe,
-                         hipStream_t s);
+int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int d, int vocab, unsigned long long* acc_wte, float* dwpe,
+                         int first_group, hipStream_t s);
+int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, float* out, hipStream_t s);
 int launch_meanpool_bwd(const float* d_pool, long long rows, int T, int d, float* dh, hipStream_t s);
 
 static inline int tpad128(int T) { return (T + 127) / 128 * 128; }
@@ -52,6 +53,7 @@ struct TrainLayout {
     size_t x_out, pool_scratch;
     // backward temporaries
     size_t dx, dy, dbig, dqkv, xT, dP, PT, red;
+    size_t emb_acc;                                     // [vocab, d] 64-bit fixed-point token-gradient table (two floats per entry)
     size_t total;
 };
 
@@ -90,6 +92,7 @@ static TrainLayout layout(const r4d_gpt2_config* cfg, const TrainGroup* gs, int 
     const size_t cs = colsum_scratch_floats((long long)t.M, 4 * t.d);
     if (cs > red) red = cs;
     t.red = take(red);
+    t.emb_acc = take((size_t)cfg->vocab * d * 2);
     t.total = off;
     return t;
 }
@@ -418,11 +421,13 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
     // embeddings: x_in[0] = drop(wte[ids] + wpe[0..T-1])
     if (dc.embd_p > 0.f && (rc = launch_dropout(dx, nullptr, (long long)M * d, dx, dc.embd_p, dc.key, R4D_DROPOUT_SITE_EMBD, 0, s)))
         return rc;
-    R4D_HIP(hipMemsetAsync(gr->wte, 0, (size_t)cfg->vocab * d * sizeof(float), s));
+    // deterministic sums (train_ops.hip): tokens through a 64-bit fixed-point table, positions as ordered column sums
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + t.emb_acc);
+    R4D_HIP(hipMemsetAsync(acc, 0, (size_t)cfg->vocab * d * sizeof(unsigned long long), s));
     R4D_HIP(hipMemsetAsync(gr->wpe, 0, (size_t)cfg->n_positions * d * sizeof(float), s));
     for (const TrainGroup& G : gs)
-        if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, (long long)G.B * G.T, G.T, d, cfg->vocab, gr->wte, gr->wpe, s))) return rc;
-    return R4D_OK;
+        if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, G.B, G.T, d, cfg->vocab, acc, gr->wpe, 0, s))) return rc;
+    return launch_embedding_fix_to_f32(acc, (long long)cfg->vocab * d, gr->wte, s);
 }
 
 }  // extern "C"

@@ -211,21 +211,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------ embedding backward
 // x[m,:] = wte[ids[m]] + wpe[t(m)]  (modeling_gpt2.py:463-469)  =>  dwte[ids[m]] += dx[m], dwpe[t(m)] += dx[m].
-// Unordered float atomics, like torch's embedding backward on a GPU.
+// torch's embedding backward on a GPU uses unordered float atomics (run-to-run differences in the last bits); here both sums
+// are DETERMINISTIC:
+//   * dwpe: the rows of position t are row t of every sequence of a batch -- a plain column sum over the sequences in a fixed
+//     order, one thread per (t, column), the batches of a step one launch after the other;
+//   * dwte: which rows share a token is data dependent, so the contributions are added as 64-bit FIXED-POINT integers
+//     (value * 2^44, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
+//     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 5.7e-14, range +-5.2e5.
+constexpr double EMB_FIX = 17592186044416.0;            // 2^44
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
-                                                            long long rows, int T, int d, int vocab, float* __restrict__ dwte,
-                                                            float* __restrict__ dwpe) {
+                                                            long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const long long id = ids[row];
-    const int t = (int)(row % T);
     if (id < 0 || id >= vocab) return;
     for (int c = lane; c < d; c += 64) {
-        const float g = dx[row * d + c];
-        atomicAdd(dwte + id * d + c, g);
-        atomicAdd(dwpe + (long long)t * d + c, g);
+        const long long q = __double2ll_rn((double)dx[row * d + c] * EMB_FIX);
+        atomicAdd(acc_wte + id * d + c, (unsigned long long)q);
     }
+}
+// dwpe[t, c] (+)= sum over the B sequences of dx[b * T + t, c], b ascending; `first`: overwrite instead of add
+__global__ __launch_bounds__(256) void wpe_bwd_kernel(const float* __restrict__ dx, int B, int T, int d, int first, float* __restrict__ dwpe) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T * d) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(long long)b * T * d + i];
+    dwpe[i] = first ? s : dwpe[i] + s;
+}
+__global__ __launch_bounds__(256) void embedding_fix_to_f32_kernel(const unsigned long long* __restrict__ acc, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / EMB_FIX));
 }
 
 // dh[row, :] = d_pool[seq(row), :] / T   (torch.mean(h, dim=1) backward, train_retriever.py:181-183)
@@ -429,12 +445,22 @@ int launch_transpose(const float* in, int rows, int cols, long long ld_in, long 
     R4D_CHECK_LAUNCH("transpose");
     return R4D_OK;
 }
-int launch_embedding_bwd(const float* dx, const int64_t* ids, long long rows, int T, int d, int vocab, float* dwte, float* dwpe,
-                         hipStream_t s) {
+// one batch [B, T] of a step: token part into the fixed-point table `acc_wte` [vocab, d] (zeroed by the caller once per step),
+// position part into dwpe rows [0, T) (`first_group`: the step's first batch overwrites, later ones add -- in call order)
+int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int d, int vocab, unsigned long long* acc_wte, float* dwpe,
+                         int first_group, hipStream_t s) {
+    const long long rows = (long long)B * T;
     if (rows <= 0) return R4D_OK;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, T, d, vocab, dwte,
-                       dwpe);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte);
     R4D_CHECK_LAUNCH("embedding_bwd");
+    hipLaunchKernelGGL(wpe_bwd_kernel, dim3((unsigned)(((long long)T * d + 255) / 256)), dim3(256), 0, s, dx, B, T, d, first_group, dwpe);
+    R4D_CHECK_LAUNCH("wpe_bwd");
+    return R4D_OK;
+}
+int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, float* out, hipStream_t s) {
+    if (n <= 0) return R4D_OK;
+    hipLaunchKernelGGL(embedding_fix_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, n, out);
+    R4D_CHECK_LAUNCH("embedding_fix_to_f32");
     return R4D_OK;
 }
 int launch_meanpool_bwd(const float* d_pool, long long rows, int T, int d, float* dh, hipStream_t s) {

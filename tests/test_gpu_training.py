@@ -252,6 +252,14 @@ def test_training_gradients_other_shapes_equal_oracle(dev, L, H, d, V, B, Ts):
     errs = {n: rel_err(grads[n].cpu().numpy(), sdg[n].grad.numpy()) for n in grads}
     print(f"L{L} H{H} d{d}: worst element-wise (max-norm) gradient error {max(errs.values()):.2e}")
     assert max(errs.values()) < 1e-3, {n: e for n, e in errs.items() if e > 1e-3}
+    # run-to-run determinism, bit for bit: every sum of the step has a fixed order (the token-embedding gradient, whose rows
+    # collide by data, is accumulated in 64-bit fixed point; the reference's GPU embedding backward is not reproducible)
+    first = {n: t.clone() for n, t in grads.items()}
+    for _ in range(2):
+        emb2 = trainer.forward([t.to(dev) for t in (anchor, pos, neg, aug1, aug2)])
+        grads2 = trainer.backward(demb.view(5 * B, -1))
+        assert torch.equal(emb2, emb)
+        assert all(torch.equal(grads2[n], first[n]) for n in first), [n for n in first if not torch.equal(grads2[n], first[n])]
 
 
 def test_three_training_steps_track_the_oracle(dev):
