@@ -788,7 +788,11 @@ static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, in
     const bool shortr = two && KW * NG >= 8 && ntiles > 256 && ntiles <= 3 * 256;
     static int dma = -1;
     if (dma < 0) { const char* e = getenv("R4D_SCAN_DMA"); dma = e ? atoi(e) : 3; }                // tuning aid: bit 0 = LDS-DMA form for short shards, bit 1 = ring form for long ones (0: register-staged forms only)
-    if (S3 && (dma & 1) && KW * NG >= 8 && ntiles <= 2 * 256) { // <= 64 rows per CU: the LDS-DMA staged form
+    // the DMA forms copy 16-byte pieces and address the pool with 32-bit byte offsets: 16-byte aligned operands below 4 GB, else
+    // the register-staged forms (any dword-aligned pointer, 64-bit addressing) take the call
+    const bool dma_ok = ((reinterpret_cast<uintptr_t>(qhat) | reinterpret_cast<uintptr_t>(pool)) & 15u) == 0 &&
+                        (unsigned long long)N * (32ull * KW * NG) * 4ull < (1ull << 32) && (unsigned long long)Q * (32ull * KW * NG) * 4ull < (1ull << 32);
+    if (S3 && (dma & 1) && dma_ok && KW * NG >= 8 && ntiles <= 2 * 256) { // <= 64 rows per CU: the LDS-DMA staged form
         R4D_BRANCH(SCAN_DMA);
         constexpr int lds_bytes = KW * 4 * 4096;
         static bool attr = false;
@@ -802,7 +806,7 @@ static int launch_scan_variant_p(const float* qhat, const float* pool, int Q, in
         const int rpw = max(8, cdiv(N, 256));            // rows dealt evenly over the CUs (a share below 32 rows leaves MFMA columns idle, not CUs)
         hipLaunchKernelGGL((pool_scan_dma_kernel<KW, NG>), dim3(cdiv(N, rpw), cdiv(Q, 32)), dim3(64 * KW), lds_bytes, s, qhat, pool, Q, N,
                            rpw, scores, zero_d, nzero);
-    } else if (S3 && (dma & 2) && KW * NG >= 8) {         // long shards: the ring form
+    } else if (S3 && (dma & 2) && dma_ok && KW * NG >= 8) {   // long shards: the ring form
         R4D_BRANCH(SCAN_RING);
         constexpr int lds_bytes = KW * SCAN_RING_P * 4096 + (SCAN_RING_P == 3 ? 2 : 1) * KW * KW * 64 * (16 / KW) * 4;
         static int ring_per_cu = 0;

@@ -476,6 +476,15 @@ def test_short_shard_scan_forms_agree_bit_for_bit(dev, d):
             assert torch.equal(S, S_long[:, :n]), (d, Q, n)
             ev, ei = retrieval_ref.topk_stable(S.cpu().numpy(), 10)
             assert np.array_equal(i.cpu().numpy(), ei + 3) and np.array_equal(v.cpu().numpy(), ev), (d, Q, n)
+        if Q == 32:                                        # operands that are only dword-aligned: the register-staged forms, same bits
+            buf = torch.empty(12500 * d + 1, device=dev)
+            pu = buf[1:].view(12500, d)
+            pu.copy_(ph[:12500])
+            bq = torch.empty(Q * d + 3, device=dev)
+            qu = bq[3:].view(Q, d)
+            qu.copy_(qh)
+            assert pu.data_ptr() % 16 == 4 and qu.data_ptr() % 16 == 12
+            assert torch.equal(ops.score_topk(qu, pu, 10, want_scores=True)[2], S_long[:, :12500]), (d, "unaligned")
         if Q == 33:
             ref = retrieval_ref.score_batch(q, p[:12500]).numpy()
             S = ops.score_topk(qh, ph[:12500].contiguous(), 10, want_scores=True)[2].cpu().numpy()
