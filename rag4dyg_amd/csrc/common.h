@@ -62,7 +62,7 @@ struct ProfScope {
 #define R4D_BRANCH_LIST(X)                                                                                              \
     X(KC_128x128x16, "gemm_kc:128x128x16") X(KC_128x64x16, "gemm_kc:128x64x16") X(KC_64x64x32, "gemm_kc:64x64x32")       \
     X(KC_128x128x32, "tuning:gemm_kc:128x128x32") X(KC_ROWSPLIT, "gemm_kc:row-split (two launches)")                      \
-    X(S3_128x256, "gemm_s3:128x256x32") X(S3_PERSISTENT, "gemm_s3:128x256x32 persistent (pipeline across tiles)") X(S3_128x128, "gemm_s3:128x128x32") X(S3_TN, "gemm_s3tn:128x256x32 (weight gradients, transposing LDS reads)")      \
+    X(S3_128x256, "gemm_s3:128x256x32") X(S3_PERSISTENT, "gemm_s3:128x256x32 persistent (pipeline across tiles)") X(S3_128x128, "gemm_s3:128x128x32") X(S3_F32B, "gemm_s3:both operands split on the fly (scoring GEMM)") X(S3_TN, "gemm_s3tn:128x256x32 (weight gradients, transposing LDS reads)")      \
     X(F32_128x128, "gemm_f32:128x128") X(F32_128x64, "gemm_f32:128x64") X(F32_64x64, "gemm_f32:64x64")                   \
     X(F32_NT, "gemm_f32:B as [N,K]") X(F32_NN, "gemm_f32:B as [K,N]") X(TN_SPLITK, "gemm_tn:split-K") X(TN_SINGLE, "gemm_tn:one slice") \
     X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
@@ -140,6 +140,8 @@ struct S3Args {
 };
 bool gemm_s3_supported(int M, int K, int N);
 int launch_gemm_s3(const S3Args& a, hipStream_t stream);
+bool gemm_s3_f32b_supported(int M, int K, int N);
+int launch_gemm_s3_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream);
 // w element (n, k) at w[k * ld_k + n * ld_n] -> planes [3][N][K] bf16 (hi, mid, lo)
 extern int g_gemm_split3;             // 1: layers that carry bf16x3 planes use them (r4d_set_gemm_split3)
 // Conv1D dispatch shared by the encoder and the training forward (encoder.hip): skinny weight stream (decode), bf16x3 planes,

@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- the GEMM
-template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS, int EPI>
+// BF32: the second operand is NOT pre-split -- Bp points at fp32 rows [N][K] (k-contiguous, row stride K) that are split on the
+// fly like A (the pool of the retrieval scoring GEMM: 4 bytes per element read instead of 6, no plane copy to keep)
+template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS, int EPI, bool BF32 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kernel(
     const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
     const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
@@ -154,18 +156,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
         const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
-        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * 2;
+        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * (BF32 ? 4 : 2);
         b_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(Bp), 0, 3 * g.plane_bytes, 0x00020000);
+        const_cast<unsigned short*>(Bp), 0, BF32 ? (int)((long long)g.N * g.K * 4) : 3 * g.plane_bytes, 0x00020000);
 
     // staging registers (fully unrolled indices only).  NRS = 2: two register stages -- a k-tile's loads are requested TWO
     // iterations before they are split and stored (at K = 512 the A rows of a tile come from beyond the XCD's L2, one
     // iteration of flight time does not cover that latency)
-    u32x4s ra[NRS][NIA][2], rb[NRS][NIB][3];
+    u32x4s ra[NRS][NIA][2], rb[NRS][NIB][3];            // BF32: rb[..][0..1] = the 8 fp32 of the item, split at the LDS store
 #define S3_LOAD(RS, KT)                                                                            \
     {                                                                                              \
         const int kt_ = min((KT), nkt - 1);                                                        \
@@ -173,9 +175,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             ra[RS][i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
             ra[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
         }                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                          \
-                rb[RS][i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
+            if (BF32) {                                                                            \
+                rb[RS][i][0] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 4), 0); \
+                rb[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i] + 16, kt_ * (BK * 4), 0); \
+            } else {                                                                               \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p)                                      \
+                    rb[RS][i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+            }                                                                                      \
+        }                                                                                          \
     }
 #define S3_STORE(RS, STG)                                                                          \
     {                                                                                              \
@@ -194,8 +202,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             }                                                                                      \
             sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = m_; sa_[2 * A_PLANE + a_dst[i]] = l_;    \
         }                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < NIB; ++i)                                            \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[RS][i][p]; \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
+            if (BF32) {                                                                            \
+                u32x4s h_, m_, l_;                                                                 \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
+                    const f32x4s src_ = __builtin_bit_cast(f32x4s, rb[RS][i][q >> 1]);            \
+                    unsigned hh_, mm_, ll_;                                                        \
+                    split3_pair(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, mm_, ll_);          \
+                    h_[q] = hh_; m_[q] = mm_; l_[q] = ll_;                                         \
+                }                                                                                  \
+                sb_[b_dst[i]] = h_; sb_[B_PLANE + b_dst[i]] = m_; sb_[2 * B_PLANE + b_dst[i]] = l_; \
+            } else {                                                                               \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[RS][i][p]; \
+            }                                                                                      \
+        }                                                                                          \
     }
 
     // fragment addresses: lane (li, lh), k-step s -> chunk 2s + lh of row li (+ 32 per tile)
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     //   barrier.
     // sched_group_barrier pins that interleaving: left alone, the scheduler reads each fragment group right in front of
     // its MFMAs (exposed LDS latency) and sinks the loads to the end of the iteration (half an iteration of flight time).
-    constexpr int NMF = 6 * TM * TN, NFR = 3 * (TM + TN), NDW = 3 * (NIA + NIB), NVM = 2 * NIA + 3 * NIB;
+    constexpr int NMF = 6 * TM * TN, NFR = 3 * (TM + TN), NDW = 3 * (NIA + NIB), NVM = 2 * NIA + (BF32 ? 2 : 3) * NIB;
     // (two register stages: the set that holds k-tile kt+1 has the parity of its LDS stage WR; it is refilled with k-tile kt+3)
 #define S3_ITER(CUR, WR)                                                                           \
     {                                                                                              \
@@ -342,8 +362,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(EPI >= EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
-            EPI >= EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+            const_cast<float*>((EPI == EPI_RESIDUAL || EPI >= EPI_GELU_KEEP) ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            (EPI == EPI_RESIDUAL || EPI >= EPI_GELU_KEEP) ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
@@ -370,6 +390,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
                     if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v2 = gelu_new_s3(v2);
                     else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
                     else if (EPI == EPI_GELU_GRAD) { v2.x *= gelu_new_grad_s3(res[r2]); v2.y *= gelu_new_grad_s3(res[r2 + 1]); }
+                    else if (EPI == EPI_HALF_PLUS) { v2.x = (v2.x + 1.0f) / 2.0f; v2.y = (v2.y + 1.0f) / 2.0f; }     // train_retriever.py:438
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = r2 + h2;
@@ -406,6 +427,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
                 if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v = gelu_new_s3_1(v);
                 else if (EPI == EPI_RESIDUAL) v += res[r];
                 else if (EPI == EPI_GELU_GRAD) v *= gelu_new_grad_s3(res[r]);
+                else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
                 if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
         }
@@ -583,8 +605,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s3p_kernel(
             const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 Cg + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(EPI >= EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
-                EPI >= EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+                const_cast<float*>((EPI == EPI_RESIDUAL || EPI >= EPI_GELU_KEEP) ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+                (EPI == EPI_RESIDUAL || EPI >= EPI_GELU_KEEP) ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
@@ -754,6 +776,29 @@ int launch_gemm_s3(const S3Args& a, hipStream_t stream) {
         if (cost < best_cost) { best_cost = cost; best = t; }
     }
     return s3_launch_tile(a, best, stream);
+}
+
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T) with BOTH operands fp32 and split on the fly (the retrieval scoring GEMM at Q > 64:
+// A = normalised queries, B = the normalised pool shard); epilogue EPI_NONE or EPI_HALF_PLUS
+bool gemm_s3_f32b_supported(int M, int K, int N) {
+    return gemm_s3_supported(M, K, N) && (long long)N * K * 4 < (1ll << 31);
+}
+int launch_gemm_s3_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream) {
+    R4D_REQUIRE(A && B && C && gemm_s3_f32b_supported(M, K, N), "gemm_s3_f32b: unsupported shape M=%d K=%d N=%d", M, K, N);
+    R4D_REQUIRE(lda % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_s3_f32b: alignment");
+    R4D_BRANCH(S3_F32B);
+    const int tiles = cdiv(M, 128) * cdiv(N, 256);
+    ProfScope prof(PK_GEMM_S3_128x256, 2.0 * (double)M * N * K, stream);
+    S3Shape sh;
+    sh.M = M; sh.N = N; sh.K = K; sh.lda = lda; sh.ldc = ldc; sh.ldr = ldc; sh.plane_bytes = 0;
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(B);
+    if (epilogue == EPI_HALF_PLUS)
+        hipLaunchKernelGGL((gemm_s3_kernel<128, 256, 2, 4, 2, 1, EPI_HALF_PLUS, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
+    else if (epilogue == EPI_NONE)
+        hipLaunchKernelGGL((gemm_s3_kernel<128, 256, 2, 4, 2, 1, EPI_NONE, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
+    else { set_error("gemm_s3_f32b: epilogue %d has no instantiation", epilogue); return R4D_ERR_INVALID; }
+    R4D_CHECK_LAUNCH("gemm_s3_f32b");
+    return R4D_OK;
 }
 
 int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s) {

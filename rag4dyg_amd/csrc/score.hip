@@ -906,6 +906,11 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
         rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, (unsigned*)ws, Q, s);
         zeroed = rc == R4D_OK;
     }
+    if (rc > 0 && g_gemm_split3 && gemm_s3_f32b_supported(Q, d, N) && ((reinterpret_cast<uintptr_t>(q_hat_d) | reinterpret_cast<uintptr_t>(pool_hat_d)) & 15u) == 0) {
+        // MFMA-bound regime on the bf16 matrix cores: queries AND pool rows split on the fly (no plane copy of the pool)
+        R4D_BRANCH(SCAN_GEMM);
+        rc = launch_gemm_s3_f32b(q_hat_d, pool_hat_d, scores, Q, N, d, d, N, EPI_HALF_PLUS, s);
+    }
     if (rc > 0) {                                                                // MFMA-bound regime / other d: tiled GEMM
         R4D_BRANCH(SCAN_GEMM);
         GemmArgs g;
