@@ -118,8 +118,11 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_f32_kc(const GemmArgs& g, hipStream_t stream);      // B given as [N,K]: k-contiguous kernel
 // C[M,N] = A[Kt,M]^T . B[Kt,N] (weight gradients), split-K partials in scratch (gemm_tn_scratch_floats floats)
 size_t gemm_tn_scratch_floats(int M, int N, int Kt);
+// `colsum_out` (nullable, with `colsum_scratch` of `colsum_scratch_floats` floats): ALSO the column sums of B over its Kt rows
+// (the bias gradient), when the bf16x3 kernel takes the call; *colsum_done says whether they were written
 int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, int Kt, int lda, int ldb, float* scratch,
-                       hipStream_t stream);
+                       hipStream_t stream, float* colsum_out = nullptr, float* colsum_scratch = nullptr,
+                       size_t colsum_scratch_floats = 0, bool* colsum_done = nullptr);
 // gemm_skinny.hip: M <= 32 rows against a k-contiguous weight [N,K], K % 256 == 0 (decode step); split-K partials in scratch
 bool gemm_skinny_supported(int M, int K, int N);
 size_t gemm_skinny_scratch_floats(int K, int N);
@@ -153,7 +156,7 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
 bool gemm_s3tn_supported(int I, int J, int M, int lda, int ldb);
 int gemm_s3tn_slices(int I, int J, int M, int max_slices);
 int launch_gemm_s3tn(const float* X, const float* dY, float* out, int I, int J, int M, int lda, int ldb, int S, int* slices_out,
-                     hipStream_t stream);
+                     hipStream_t stream, float* db_partials = nullptr);
 int launch_split3_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s);
 
 // ------------------------------------------------------------------ train_ops.hip

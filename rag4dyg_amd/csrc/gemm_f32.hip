@@ -402,18 +402,27 @@ size_t gemm_tn_scratch_floats(int M, int N, int Kt) {
     return S > 1 ? (size_t)S * M * N : 0;
 }
 int launch_gemm_f32_tn(const float* A, const float* B, float* C, int M, int N, int Kt, int lda, int ldb, float* scratch,
-                       hipStream_t stream) {
+                       hipStream_t stream, float* colsum_out, float* colsum_scratch, size_t colsum_scratch_floats, bool* colsum_done) {
+    if (colsum_done) *colsum_done = false;
     R4D_REQUIRE(M > 0 && N > 0 && Kt > 0 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
                 "gemm_tn: M=%d N=%d Kt=%d lda=%d ldb=%d (multiples of 4 wanted)", M, N, Kt, lda, ldb);
     R4D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm_tn: 16-byte alignment");
     const int S = tn_splits(M, N, Kt);
     if (g_gemm_split3 && S > 1 && gemm_s3tn_supported(M, N, Kt, lda, ldb)) {    // bf16x3 form (gemm_s3tn.hip); S == 1: tiny problems stay here
         int Sx3 = 1;
-        const int rc3 = launch_gemm_s3tn(A, B, scratch, M, N, Kt, lda, ldb, gemm_s3tn_slices(M, N, Kt, S), &Sx3, stream);
+        const int S3 = gemm_s3tn_slices(M, N, Kt, S);
+        const bool cs = colsum_out && colsum_scratch && colsum_done && (size_t)S3 * N <= colsum_scratch_floats &&
+                        ((uintptr_t)colsum_scratch % 16) == 0 && ((uintptr_t)colsum_out % 16) == 0;
+        const int rc3 = launch_gemm_s3tn(A, B, scratch, M, N, Kt, lda, ldb, S3, &Sx3, stream, cs ? colsum_scratch : nullptr);
         if (rc3) return rc3;
         const long long mn4_ = (long long)M * N / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4_ + 255) / 256)), dim3(256), 0, stream, scratch, mn4_, Sx3, C);
         R4D_CHECK_LAUNCH("splitk_reduce");
+        if (cs) {                                                    // the slices' column sums, added in slice order
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, stream, colsum_scratch, (long long)(N / 4), Sx3, colsum_out);
+            R4D_CHECK_LAUNCH("colsum_reduce");
+            *colsum_done = true;
+        }
         return R4D_OK;
     }
     const int kper = cdiv(cdiv(Kt, S), BKT) * BKT;

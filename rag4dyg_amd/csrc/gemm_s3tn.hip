@@ -45,8 +45,11 @@ struct TnShape {
     int kper;              // token rows per slice (multiple of 32)
 };
 
+// `dbp` (nullable): partial column sums of dY per slice, [slices][J] -- the bias gradient db = sum over the token rows of dY falls
+// out of the staging of the dY tiles (the workgroups of the first I tile add the values they stage anyway: 16 adds per k-tile
+// and thread), summed per thread over its tokens in order, then over the 16 threads of a column chunk in order: a fixed order
 __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restrict__ Xg, const float* __restrict__ Yg,
-                                                           float* __restrict__ Cg, const TnShape g) {
+                                                           float* __restrict__ Cg, const TnShape g, float* __restrict__ dbp) {
     constexpr int BI = 128, BJ = 256, BK = 32, WI = 64, WJ = 64, TI = 2, TJ = 2;
     constexpr int A_ROW = BI * 2, B_ROW = BJ * 2;                     // bytes per token row of one plane image
     constexpr int A_PLANE = BK * A_ROW, B_PLANE = BK * B_ROW;         // 8 KB, 16 KB
@@ -76,6 +79,18 @@ __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restri
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xg), 0, (int)((long long)g.M * g.lda * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yg), 0, (int)((long long)g.M * g.ldb * 4), 0x00020000);
     u32x4t ra[2], rb[2][2];
+    const bool do_cs = dbp != nullptr && ti == 0;                     // workgroup-uniform
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    // column sums over the staged dY items of a k-tile that belongs to this slice (the registers hold k-tile KT)
+#define TN_COLSUM(KT)                                                                              \
+    if (do_cs && (KT) < nkt) {                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                            \
+            const f32x4t c0_ = __builtin_bit_cast(f32x4t, rb[r][0]), c1_ = __builtin_bit_cast(f32x4t, rb[r][1]); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { cs[e] += c0_[e]; cs[4 + e] += c1_[e]; } \
+        }                                                                                          \
+    }
 #define TN_LOAD(KT)                                                                                \
     {                                                                                              \
         const int so_a_ = (m_lo + (KT) * BK) * g.lda * 4, so_b_ = (m_lo + (KT) * BK) * g.ldb * 4; \
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restri
 #define TN_ITER(CUR)                                                                               \
     {                                                                                              \
         TN_FRAGS(0, CUR, 0)                                                                        \
+        TN_COLSUM(kt + 1)                                                                          \
         TN_STORE((CUR) ^ 1)                                                                        \
         TN_LOAD(kt + 2)                                                                            \
         TN_FRAGS(1, CUR, 1)                                                                        \
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restri
         __syncthreads();                                                                           \
     }
     TN_LOAD(0)
+    TN_COLSUM(0)
     TN_STORE(0)
     TN_LOAD(1)
     __syncthreads();
@@ -186,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restri
     }
     if (kt < nkt) TN_ITER(0)
 #undef TN_ITER
+#undef TN_COLSUM
 #undef TN_MFMAS
 #undef TN_MFMA
 #undef TN_FRAGS
@@ -194,6 +212,18 @@ __global__ __launch_bounds__(512, 2) void gemm_s3tn_kernel(const float* __restri
 #undef TN_STORE
 #undef TN_SPLIT8
 #undef TN_LOAD
+    if (do_cs) {                                                      // thread (token row t16 = tid >> 5, chunk tid & 31): 16 rows per chunk
+        float* red = reinterpret_cast<float*>(lds);                  // the last iteration's barrier has passed: the stages are free
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 5) * 256 + (tid & 31) * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t16 = 0; t16 < 16; ++t16) sum += red[t16 * 256 + tid];
+            dbp[(size_t)blockIdx.z * g.J + j0 + tid] = sum;
+        }
+    }
     // partial tile of slice z (whole tiles only: I % 128 == 0, J % 256 == 0)
     float* C = Cg + (size_t)blockIdx.z * g.I * g.J;
     const int li = lane & 31, lh = lane >> 5;
@@ -226,7 +256,7 @@ int gemm_s3tn_slices(int I, int J, int M, int max_slices) {
 
 // C (S == 1) or partial [S][I][J] (S > 1) <- X^T . dY; returns the number of slices that hold rows through *slices_out
 int launch_gemm_s3tn(const float* X, const float* dY, float* out, int I, int J, int M, int lda, int ldb, int S, int* slices_out,
-                     hipStream_t stream) {
+                     hipStream_t stream, float* db_partials) {
     R4D_REQUIRE(gemm_s3tn_supported(I, J, M, lda, ldb), "gemm_s3tn: unsupported shape I=%d J=%d M=%d", I, J, M);
     R4D_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_s3tn: 16-byte alignment");
     TnShape sh;
@@ -236,7 +266,7 @@ int launch_gemm_s3tn(const float* X, const float* dY, float* out, int I, int J, 
     *slices_out = Sx;
     ProfScope prof(PK_GEMM_S3TN, 2.0 * (double)I * J * M, stream);
     R4D_BRANCH(S3_TN);
-    hipLaunchKernelGGL(gemm_s3tn_kernel, dim3((I / 128) * (J / 256), 1, Sx), dim3(512), 0, stream, X, dY, out, sh);
+    hipLaunchKernelGGL(gemm_s3tn_kernel, dim3((I / 128) * (J / 256), 1, Sx), dim3(512), 0, stream, X, dY, out, sh, db_partials);
     R4D_CHECK_LAUNCH("gemm_s3tn");
     return R4D_OK;
 }

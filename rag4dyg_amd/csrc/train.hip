@@ -147,9 +147,10 @@ static int bwd_data(const float* dy, const float* w, int M, int K, int N, float*
 // db[N] = column sums of dy
 static int bwd_weight(const float* x, const float* dy, int M, int K, int N, float* dW, float* db, float* skp, float* red,
                       hipStream_t s) {
-    const int rc = launch_gemm_f32_tn(x, dy, dW, K, N, M, K, N, skp, s);
+    bool db_done = false;                                             // the bf16x3 kernel sums dy's columns while it stages them
+    const int rc = launch_gemm_f32_tn(x, dy, dW, K, N, M, K, N, skp, s, db, red, colsum_scratch_floats(M, N), &db_done);
     if (rc) return rc;
-    return db ? launch_colsum(dy, M, N, N, db, red, 0, s) : R4D_OK;
+    return (db && !db_done) ? launch_colsum(dy, M, N, N, db, red, 0, s) : R4D_OK;
 }
 
 // Attention._attn forward over one batch, probabilities kept in P [B*H, T, ld] with EVERY column right of the diagonal zero
