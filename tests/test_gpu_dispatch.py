@@ -35,6 +35,8 @@ def test_every_dispatcher_branch_is_exercised(dev):
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
     lib = _lib.load()
     lib.r4d_dispatch_reset()
+    mode_before = ops.gemm_split3_enabled()                # the matrix below assumes the default (bf16x3) mode; restored at the end
+    ops.set_gemm_split3(True)
     g = torch.Generator().manual_seed(7)
     rnd = lambda *s: torch.randn(*s, generator=g)
 
@@ -145,6 +147,7 @@ def test_every_dispatcher_branch_is_exercised(dev):
         ref = np.array([[len(set(a) & set(b)) / len(set(a) | set(b)) if a and b else 0.0 for b in sets] for a in sets])
         assert np.array_equal(out, ref), vocab
 
+    ops.set_gemm_split3(mode_before)
     hits = branches()
     missed = sorted(n for n, c in hits.items() if c == 0 and not n.startswith("tuning:"))
     print("dispatcher branches exercised:", {n: c for n, c in hits.items() if c})
