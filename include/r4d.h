@@ -29,7 +29,7 @@ extern "C" {
 #define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
 #define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
 
-#define R4D_ABI_VERSION 3
+#define R4D_ABI_VERSION 4
 
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
@@ -79,6 +79,12 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * wT copies, every plane set must be refreshed by the caller after each optimizer step. */
     const uint16_t* c_attn_w3t; const uint16_t* attn_proj_w3t;
     const uint16_t* c_fc_w3t;   const uint16_t* mlp_proj_w3t;
+    /* DECODE only, optional (ABI v4): LayerNorm pre-folded into the two projections that read it (r4d_fold_layernorm_f32 on
+     * c_attn_wT with ln_1, on c_fc_wT with ln_2): *_wTg [out,in] = gain[in] * W^T, *_lnc [2][out] = (sum_in gain W, sum_in shift W).
+     * With them the cached decode step (d in {512, 768}, batch <= 32) evaluates LN(x) W as rstd (x W'^T - mean c1) + c2 without
+     * loading the gain / shift or forming c1 / c2 per launch; NULL = it forms them from ln_1 / ln_2 and *_wT as before. */
+    const float* c_attn_wTg;    const float* c_attn_lnc;
+    const float* c_fc_wTg;      const float* c_fc_lnc;
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
@@ -240,6 +246,11 @@ int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* b
                       int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
 /* 1 (default): the encoder / training-forward GEMMs use the bf16x3 kernel where a layer carries its planes; 0: exact-f32 MFMA
  * kernels everywhere (the planes are ignored).  Process-wide, not thread-safe against concurrent calls. */
+/* Decode-only fold of a LayerNorm into the projection that reads it (ABI v4): wT_d [N,K] (k-contiguous weight), ln_w_d / ln_b_d [K]
+ * -> wTg_d [N,K] = ln_w[k] * wT[n][k] and lnc_d [2][N] = (sum_k ln_w[k] wT[n][k], sum_k ln_b[k] wT[n][k]); the operands of
+ * r4d_gpt2_layer's c_attn_wTg / c_attn_lnc (with ln_1) and c_fc_wTg / c_fc_lnc (with ln_2).  Once per checkpoint. */
+int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* ln_b_d, int32_t N, int32_t K, float* wTg_d,
+                           float* lnc_d, void* stream);
 int r4d_set_gemm_split3(int32_t mode);
 int r4d_get_gemm_split3(void);
 /* Causal multi-head attention on packed c_attn output qkv_d [B,T,3d] -> a_d [B,T,d] (heads merged).

@@ -44,7 +44,7 @@ def _compile(src, force, hdr_m):
 # atomic stores and consume with relaxed agent-scope loads: correct on gfx950 because hipcc lowers those to write-through /
 # L1-bypassing `sc1` memory instructions (MI355X_MICROARCH.md, inter-workgroup visibility).  A toolchain that stopped emitting
 # sc1 would corrupt top-k results and decode projections silently, so the build fails instead.
-HANDOFF_KERNELS = {"topk.hip": ("topk_chunk_kernelIfE", "topk_chunk_kernelIdE"), "gemm_skinny.hip": ("gemm_skinny16_kernelILi2ELb0E", "gemm_skinny16_kernelILi3ELb0E")}
+HANDOFF_KERNELS = {"topk.hip": ("topk_chunk_kernelIfE", "topk_chunk_kernelIdE"), "gemm_skinny.hip": ("gemm_skinny16_kernelILi2ELi0E", "gemm_skinny16_kernelILi3ELi0E")}
 
 
 def check_handoff_lowering(src):
@@ -82,7 +82,9 @@ def build_library(force=False, verbose=True):
     for src, (_o, compiled) in zip(sources(), res):
         if compiled and os.path.basename(src) in HANDOFF_KERNELS:
             check_handoff_lowering(src)
-    if force or any(c for _, c in res) or not os.path.exists(LIB):
+    # (also when an earlier run compiled objects but stopped before the link, e.g. on a failed hand-off check)
+    stale = os.path.exists(LIB) and any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if force or stale or any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -65,7 +65,7 @@ struct ProfScope {
     X(S3_128x256, "gemm_s3:128x256x32") X(S3_PERSISTENT, "gemm_s3:128x256x32 persistent (pipeline across tiles)") X(S3_128x128, "gemm_s3:128x128x32") X(S3_F32B, "gemm_s3:both operands split on the fly (scoring GEMM)") X(S3_TN, "gemm_s3tn:128x256x32 (weight gradients, transposing LDS reads)")      \
     X(F32_128x128, "gemm_f32:128x128") X(F32_128x64, "gemm_f32:128x64") X(F32_64x64, "gemm_f32:64x64")                   \
     X(F32_NT, "gemm_f32:B as [N,K]") X(F32_NN, "gemm_f32:B as [K,N]") X(TN_SPLITK, "gemm_tn:split-K") X(TN_SINGLE, "gemm_tn:one slice") \
-    X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
+    X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_LN_FOLDED, "skinny16:LayerNorm pre-folded into the weight") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
     X(SK16_SPLITK, "skinny16:split-K last-arriver") X(SK8_NG2, "skinny8:ng2") X(SK8_NG3, "skinny8:ng3")                    \
     X(SK8_LN, "tuning:skinny8:+layernorm") X(SK8_SPLITK, "skinny8:split-K + epilogue launch") X(SK_PLAIN, "skinny:plain + epilogue launch") \
     X(ATT_KS32, "attention:key-split hd32") X(ATT_KS64, "attention:key-split hd64") X(ATT_CS96, "attention:column-split hd96") \
@@ -132,7 +132,8 @@ bool gemm_skinny_fuses_ln(int M, int K, int N);       // y = epilogue(LayerNorm(
 void* gemm_skinny_counters(float* scratch, size_t* bytes);
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w = nullptr,
-                       const float* ln_b = nullptr, float ln_eps = 0.f, bool counters_zeroed = false);
+                       const float* ln_b = nullptr, float ln_eps = 0.f, bool counters_zeroed = false, const float* ln_fold = nullptr);
+int launch_fold_layernorm(const float* wT, const float* g, const float* beta, int N, int K, float* wTg, float* lnc, hipStream_t s);
 
 // gemm_s3.hip: C = epilogue(A . W^T + bias) on the bf16 matrix cores at fp32 accuracy (A fp32, split on the fly into three
 // bf16 terms; W given as three pre-split bf16 planes [3][N][K]); K % 32 == 0

@@ -141,6 +141,11 @@ int r4d_abi_version(void) { return R4D_ABI_VERSION; }
 int r4d_build_flags(void) {
     return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4) | (dbgflag_s3() << 5);
 }
+int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* ln_b_d, int32_t N, int32_t K, float* wTg_d,
+                           float* lnc_d, void* stream) {
+    return launch_fold_layernorm(wT_d, ln_w_d, ln_b_d, N, K, wTg_d, lnc_d, (hipStream_t)stream);
+}
+
 int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode != 0; return R4D_OK; }
 int r4d_get_gemm_split3(void) { return g_gemm_split3; }
 int r4d_set_attention_fused(int32_t mode) {
@@ -368,8 +373,11 @@ static int decode_step_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* 
             rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, B, d, cfg->ln_eps, ws.ln, s);
         if (rc) return rc;
         if (fuse_ln && (l > 0 || x_ready))
-            rc = launch_gemm_skinny(ws.x, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, L.ln_1_w,
-                                    L.ln_1_b, cfg->ln_eps, true);
+            rc = (L.c_attn_wTg && L.c_attn_lnc)            // LayerNorm pre-folded into a decode-only copy of the weight
+                     ? launch_gemm_skinny(ws.x, L.c_attn_wTg, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, nullptr, nullptr,
+                                          cfg->ln_eps, true, L.c_attn_lnc)
+                     : launch_gemm_skinny(ws.x, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, sk, s, L.ln_1_w,
+                                          L.ln_1_b, cfg->ln_eps, true);
         else
             rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, B, d, 3 * d, EPI_NONE, ws.qkv, s, sk);
         if (rc) return rc;
@@ -377,8 +385,11 @@ static int decode_step_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* 
             return rc;
         if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, B, d, d, EPI_RESIDUAL, ws.x, s, sk, true))) return rc;
         if (fuse_ln) {
-            rc = launch_gemm_skinny(ws.x, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, sk, s, L.ln_2_w, L.ln_2_b,
-                                    cfg->ln_eps, true);
+            rc = (L.c_fc_wTg && L.c_fc_lnc)
+                     ? launch_gemm_skinny(ws.x, L.c_fc_wTg, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, sk, s, nullptr, nullptr,
+                                          cfg->ln_eps, true, L.c_fc_lnc)
+                     : launch_gemm_skinny(ws.x, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, sk, s, L.ln_2_w, L.ln_2_b,
+                                          cfg->ln_eps, true);
         } else {
             if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, B, d, cfg->ln_eps, ws.ln, s))) return rc;
             rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, B, d, 4 * d, EPI_GELU, ws.fc, s, sk);

@@ -281,7 +281,10 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 
 // grid (ceil(N/16), KS), 512 threads.  KS == 1: y = epilogue(x' . wT^T + bias), x' = LN ? LayerNorm(x) : x.
 // KS > 1 (never with LN): partial[ks][32][N] + counters[tile]; the last arriver writes y.
-template <int NG, bool LN>
+// LN = 2: the LayerNorm is PRE-FOLDED into the operands (r4d_fold_layernorm_f32, once per checkpoint): wT holds g_k W_nk and
+// ln_w points at [2][N] = c1 (sum_k g_k W_nk), c2 (sum_k beta_k W_nk) -- no gain / shift loads, no gain multiply in front of the
+// MFMAs, no c1 / c2 arithmetic; the row statistics still come from the x fragments
+template <int NG, int LN>
 __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* __restrict__ x, const float* __restrict__ wT,
                                                                    int M, int N, int K, const float* __restrict__ bias,
                                                                    const float* __restrict__ resid, int epilogue,
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float xs_all[S8_NW * 32 * LDX];
     __shared__ float red_t[S8_NW * 32 * S16_LDR];
     __shared__ float red_s[LN ? 2 * S8_NW * 32 : 1];   // [0]: piece sums, [1]: centred squares, per (wave, row)
-    __shared__ float red_c[LN ? 2 * S8_NW * 16 : 1];   // c1 / c2 pieces per (wave, column)
+    __shared__ float red_c[LN == 1 ? 2 * S8_NW * 16 : 1];   // c1 / c2 pieces per (wave, column)
     __shared__ unsigned s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n16 = lane & 15, q = lane >> 4;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
     float* xs = xs_all + wid * 32 * LDX;
     const int pr = lane / PPR, pc = lane % PPR;
     // every global load of the kernel up front: weights (HBM latency), x pieces (L2), LayerNorm gain / shift, bias, residual
-    float4 b[NJ], gw[LN ? NJ : 1], gb[LN ? NJ : 1];
+    float4 b[NJ], gw[LN == 1 ? NJ : 1], gb[LN == 1 ? NJ : 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4*>(wrow + 16 * j);
     float4 xv[NPASS];
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
         const int r = min(min(j * RPP + pr, 31), M - 1);
         xv[j] = reinterpret_cast<const float4*>(x + (long long)r * K + k0)[pc];
     }
-    if (LN) {
+    if (LN == 1) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             gw[j] = *reinterpret_cast<const float4*>(ln_w + k0 + 16 * j + 4 * q);
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
     const int enc = min(en, N - 1), emc = min(em, M - 1);
     const bool fused = KS == 1;
     const float bias_n = bias ? bias[enc] : 0.f;
+    const float fc1 = LN == 2 ? ln_w[enc] : 0.f, fc2 = LN == 2 ? ln_w[N + enc] : 0.f;      // folded column constants
     const float res = (fused && epilogue == EPI_RESIDUAL) ? resid[(long long)emc * N + enc] : 0.f;
     if (pr < RPP)
 #pragma unroll
@@ -341,11 +345,11 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float4 g = LN ? gw[j] : make_float4(1.f, 1.f, 1.f, 1.f);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].x * g.x : a[t][j].x, b[j].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].y * g.y : a[t][j].y, b[j].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].z * g.z : a[t][j].z, b[j].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN ? a[t][j].w * g.w : a[t][j].w, b[j].w, acc[t], 0, 0, 0);
+            const float4 g = LN == 1 ? gw[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN == 1 ? a[t][j].x * g.x : a[t][j].x, b[j].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN == 1 ? a[t][j].y * g.y : a[t][j].y, b[j].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN == 1 ? a[t][j].z * g.z : a[t][j].z, b[j].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(LN == 1 ? a[t][j].w * g.w : a[t][j].w, b[j].w, acc[t], 0, 0, 0);
         }
     if (LN) {
         // row statistics from the fragments (lane (n16, q) holds row 16t + n16, k = 16j + 4q + c of this wave's piece) and the
@@ -359,16 +363,18 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
             s_[t] += __shfl_xor(s_[t], 16);
             s_[t] += __shfl_xor(s_[t], 32);
         }
+        if (LN == 1) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            c1 += (gw[j].x * b[j].x + gw[j].y * b[j].y) + (gw[j].z * b[j].z + gw[j].w * b[j].w);
-            c2 += (gb[j].x * b[j].x + gb[j].y * b[j].y) + (gb[j].z * b[j].z + gb[j].w * b[j].w);
+            for (int j = 0; j < NJ; ++j) {
+                c1 += (gw[j].x * b[j].x + gw[j].y * b[j].y) + (gw[j].z * b[j].z + gw[j].w * b[j].w);
+                c2 += (gb[j].x * b[j].x + gb[j].y * b[j].y) + (gb[j].z * b[j].z + gb[j].w * b[j].w);
+            }
+            c1 += __shfl_xor(c1, 16); c1 += __shfl_xor(c1, 32);
+            c2 += __shfl_xor(c2, 16); c2 += __shfl_xor(c2, 32);
         }
-        c1 += __shfl_xor(c1, 16); c1 += __shfl_xor(c1, 32);
-        c2 += __shfl_xor(c2, 16); c2 += __shfl_xor(c2, 32);
         if (q == 0) {
             red_s[wid * 32 + n16] = s_[0]; red_s[wid * 32 + 16 + n16] = s_[1];
-            red_c[wid * 16 + n16] = c1; red_c[S8_NW * 16 + wid * 16 + n16] = c2;
+            if (LN == 1) { red_c[wid * 16 + n16] = c1; red_c[S8_NW * 16 + wid * 16 + n16] = c2; }
         }
         __syncthreads();
 #pragma unroll
@@ -398,11 +404,11 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < S8_NW; ++w) v += red_t[(w * 32 + em) * S16_LDR + (tid & 15)];      // wave order: deterministic
     if (LN) {
-        float mean = 0.f, var = 0.f, c1 = 0.f, c2 = 0.f;
+        float mean = 0.f, var = 0.f, c1 = fc1, c2 = fc2;
 #pragma unroll
         for (int w = 0; w < S8_NW; ++w) {
             mean += red_s[w * 32 + em]; var += red_s[S8_NW * 32 + w * 32 + em];
-            c1 += red_c[w * 16 + (tid & 15)]; c2 += red_c[S8_NW * 16 + w * 16 + (tid & 15)];
+            if (LN == 1) { c1 += red_c[w * 16 + (tid & 15)]; c2 += red_c[S8_NW * 16 + w * 16 + (tid & 15)]; }
         }
         mean /= (float)K;
         v = rsqrtf(var / (float)K + eps) * (v - mean * c1) + c2;
@@ -439,6 +445,30 @@ __global__ __launch_bounds__(64 * S8_NW) void gemm_skinny16_kernel(const float* 
     }
 }
 
+
+// W'[n][k] = g[k] W[n][k];  lnc[n] = sum_k g[k] W[n][k];  lnc[N + n] = sum_k beta[k] W[n][k]   (one wavefront per weight row)
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ wT, const float* __restrict__ g,
+                                                             const float* __restrict__ beta, int N, int K, float* __restrict__ wTg,
+                                                             float* __restrict__ lnc) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float c1 = 0.f, c2 = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = wT[(long long)n * K + k], gw = g[k] * w;
+        wTg[(long long)n * K + k] = gw;
+        c1 += gw; c2 += beta[k] * w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    if (lane == 0) { lnc[n] = c1; lnc[N + n] = c2; }
+}
+int launch_fold_layernorm(const float* wT, const float* g, const float* beta, int N, int K, float* wTg, float* lnc, hipStream_t s) {
+    R4D_REQUIRE(wT && g && beta && wTg && lnc && N >= 1 && K >= 1, "fold_layernorm: bad arguments");
+    hipLaunchKernelGGL(fold_layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, wT, g, beta, N, K, wTg, lnc);
+    R4D_CHECK_LAUNCH("fold_layernorm");
+    return R4D_OK;
+}
+
 static int skinny8_ng(int K) { return K % 768 == 0 ? 3 : (K % 512 == 0 ? 2 : 0); }       // 0: the 4-wave kernel
 
 bool gemm_skinny_fuses_ln(int M, int K, int N) { return gemm_skinny_supported(M, K, N) && (K == 768 || K == 512); }
@@ -449,9 +479,12 @@ bool gemm_skinny_supported(int M, int K, int N) { return M >= 1 && M <= 32 && K 
 
 void* gemm_skinny_counters(float* scratch, size_t* bytes) { *bytes = S16_MAX_TILES * sizeof(unsigned); return scratch; }
 
+// `ln_fold` (nullable): wT is the PRE-FOLDED weight g_k W_nk and ln_fold its [2][N] column constants (launch_fold_layernorm);
+// ln_w / ln_b are then unused
 int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const float* resid, int M, int K, int N,
                        int epilogue, float* y, float* scratch, hipStream_t s, const float* ln_w, const float* ln_b,
-                       float ln_eps, bool counters_zeroed) {
+                       float ln_eps, bool counters_zeroed, const float* ln_fold) {
+    R4D_REQUIRE(!ln_fold || gemm_skinny_fuses_ln(M, K, N), "skinny gemm: no folded LayerNorm for K=%d", K);
     R4D_REQUIRE(gemm_skinny_supported(M, K, N) && scratch, "skinny gemm: unsupported shape M=%d K=%d N=%d", M, K, N);
     R4D_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wT % 16) == 0, "skinny gemm: operands must be 16-byte aligned");
     R4D_REQUIRE(!ln_w || (ln_b && gemm_skinny_fuses_ln(M, K, N)), "skinny gemm: no fused LayerNorm for K=%d", K);
@@ -462,7 +495,7 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
     if (ng && use16 && (K / (S8_NW * 32 * ng) == 1 || cdiv(N, 16) <= S16_MAX_TILES)) {      // 8 waves per 16-row tile of wT
         const int SL = S8_NW * 32 * ng;
         KS = K / SL;
-        R4D_REQUIRE(KS == 1 || !ln_w, "skinny gemm: no fused LayerNorm across k slices");
+        R4D_REQUIRE(KS == 1 || (!ln_w && !ln_fold), "skinny gemm: no fused LayerNorm across k slices");
         unsigned* counters = reinterpret_cast<unsigned*>(scratch);
         float* partial = KS > 1 ? scratch + S16_MAX_TILES : nullptr;
         if (KS > 1 && !counters_zeroed) R4D_HIP(hipMemsetAsync(counters, 0, S16_MAX_TILES * sizeof(unsigned), s));
@@ -470,16 +503,18 @@ int launch_gemm_skinny(const float* x, const float* wT, const float* bias, const
         const dim3 grid(cdiv(N, 16), KS), block(64 * S8_NW);
 #define SK16_(NG_, LN_)                                                                                                    \
     hipLaunchKernelGGL((gemm_skinny16_kernel<NG_, LN_>), grid, block, 0, s, x, wT, M, N, K, bias, resid, epilogue, y, partial, \
-                       counters, ln_w, ln_b, ln_eps)
-        if (ng == 3) { if (ln_w) R4D_BRANCH(SK16_NG3_LN); else R4D_BRANCH(SK16_NG3); }
-        else         { if (ln_w) R4D_BRANCH(SK16_NG2_LN); else R4D_BRANCH(SK16_NG2); }
+                       counters, (LN_) == 2 ? ln_fold : ln_w, ln_b, ln_eps)
+        if (ln_fold) R4D_BRANCH(SK16_LN_FOLDED);
+        else if (ng == 3) { if (ln_w) R4D_BRANCH(SK16_NG3_LN); else R4D_BRANCH(SK16_NG3); }
+        else              { if (ln_w) R4D_BRANCH(SK16_NG2_LN); else R4D_BRANCH(SK16_NG2); }
         if (KS > 1) R4D_BRANCH(SK16_SPLITK);
-        if (ng == 3) { if (ln_w) SK16_(3, true); else SK16_(3, false); }
-        else         { if (ln_w) SK16_(2, true); else SK16_(2, false); }
+        if (ng == 3) { if (ln_fold) SK16_(3, 2); else if (ln_w) SK16_(3, 1); else SK16_(3, 0); }
+        else         { if (ln_fold) SK16_(2, 2); else if (ln_w) SK16_(2, 1); else SK16_(2, 0); }
 #undef SK16_
         R4D_CHECK_LAUNCH("gemm_skinny16");
         return R4D_OK;
     }
+    R4D_REQUIRE(!ln_fold, "skinny gemm: the folded LayerNorm needs the 16-column kernel");
     if (ng) {                                          // 8 waves per 32-row tile of wT
         const int SL = S8_NW * 32 * ng;
         KS = K / SL;

@@ -19,6 +19,10 @@ import torch.nn as nn
 from . import _lib, ops
 
 
+# The cached decode step reads LayerNorm-folded copies of c_attn / c_fc (ops.fold_layernorm, +16 MB per layer at d = 768, made once per
+# checkpoint).  False (or R4D_DECODE_FOLD_LN=0): the step forms the LayerNorm constants per launch from the plain k-contiguous copies.
+FOLD_DECODE_LAYERNORM = os.environ.get("R4D_DECODE_FOLD_LN", "1") != "0"
+
 class GPT2Config:
     """``models/configuration_gpt2.py:120-162`` defaults + the keys the reference adds (``utils/tokenizer.py:21-26,51``)."""
 
@@ -198,7 +202,7 @@ class GPT2Model(_PreTrained):
     # per-object caches and the back-link to an owning LM-head model: never copied or pickled (copy.deepcopy(model) -- the
     # reference's `best_model = copy.deepcopy(model)` -- and torch.save(model) go through __getstate__); an owner re-links
     # its own copy in _LMHeadBase.__setstate__
-    _TRANSIENT = ("_wt_cache", "_w3_cache", "_greedy_decoders", "_lm_head_weight")
+    _TRANSIENT = ("_wt_cache", "_w3_cache", "_fold_cache", "_greedy_decoders", "_lm_head_weight")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -227,7 +231,21 @@ class GPT2Model(_PreTrained):
             cache[key] = ent
         return ent[1].data_ptr()
 
-    def _c_structs(self):
+    def _fold(self, w, ln):
+        """Decode-only (pointer to gain-folded [out,in] copy, pointer to its [2,out] column constants) of a Conv1D weight that
+        reads LayerNorm ``ln`` (``ops.fold_layernorm``), cached until the weight or the LayerNorm changes."""
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        key = id(w)
+        stamp = (w.data_ptr(), w._version, ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version)
+        ent = cache.get(key)
+        if ent is None or ent[0] != stamp:
+            self._wt(w)
+            wT = self._wt_cache[id(w)][1]
+            ent = (stamp, ops.fold_layernorm(wT, ln.weight.detach(), ln.bias.detach()))
+            cache[key] = ent
+        return ent[1][0].data_ptr(), ent[1][1].data_ptr()
+
+    def _c_structs(self, decode=False):
         cfg = self.config
         c = _lib.GPT2ConfigC(cfg.n_layer, cfg.n_head, cfg.n_embd, self.wte.num_embeddings, self.wpe.num_embeddings,
                              cfg.layer_norm_epsilon)
@@ -247,6 +265,9 @@ class GPT2Model(_PreTrained):
                                         self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight),
                                         self._w3(blk.attn.c_attn.weight), self._w3(blk.attn.c_proj.weight),
                                         self._w3(blk.mlp.c_fc.weight), self._w3(blk.mlp.c_proj.weight))
+            if decode and FOLD_DECODE_LAYERNORM and cfg.n_embd in (512, 768):   # the cached decode step's LayerNorm-fused projections (ABI v4)
+                layers[i].c_attn_wTg, layers[i].c_attn_lnc = self._fold(blk.attn.c_attn.weight, blk.ln_1)
+                layers[i].c_fc_wTg, layers[i].c_fc_lnc = self._fold(blk.mlp.c_fc.weight, blk.ln_2)
         head = self.__dict__.get("_lm_head_weight")              # set by an LM-head model whose lm_head is NOT tied to wte
         head = head() if head is not None else None
         w = _lib.GPT2WeightsC(p(self.wte.weight), p(self.wpe.weight), p(self.ln_f.weight), p(self.ln_f.bias), layers,
@@ -417,7 +438,7 @@ class GPT2Model(_PreTrained):
         else:
             inputs_embeds = inputs_embeds.to(device=dev, dtype=torch.float32).contiguous().view(B, d)
         lib = _lib.load()
-        c, w, _keep = self._c_structs()
+        c, w, _keep = self._c_structs(decode=True)
         ws = ops.workspace(lib.r4d_gpt2_decode_workspace_bytes(ctypes.byref(c), B), dev, "gpt2_decode")
         hidden = torch.empty(B, d, dtype=torch.float32, device=dev)
         _lib.check(lib.r4d_gpt2_decode_step_f32(ctypes.byref(c), ctypes.byref(w),
@@ -540,7 +561,7 @@ class GreedyDecoder:
 
     def _steps(self, n):
         lib = _lib.load()
-        c, w, layers = self.tr._c_structs()
+        c, w, layers = self.tr._c_structs(decode=True)
         stream = torch.cuda.current_stream().cuda_stream
         if self.use_graph:
             key = bytes(layers) + bytes((ctypes.c_void_p * 5)(w.wte, w.wpe, w.ln_f_w, w.ln_f_b, w.lm_head))   # every weight pointer baked in

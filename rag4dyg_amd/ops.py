@@ -91,6 +91,18 @@ def split3_planes(w, transposed=False):
     return planes
 
 
+def fold_layernorm(wT, ln_w, ln_b):
+    """Decode-only copy of a projection that reads a LayerNorm: ``wT`` [N,K] (k-contiguous weight), LayerNorm gain / shift [K]
+    -> (``wTg`` [N,K] = gain * wT, ``lnc`` [2,N] = (sum_k gain W, sum_k shift W)): LN(x) W = rstd (x wTg^T - mean c1) + c2."""
+    N, K = wT.shape
+    wTg = torch.empty_like(wT)
+    lnc = torch.empty(2, N, dtype=torch.float32, device=wT.device)
+    check(_lib.load().r4d_fold_layernorm_f32(_dev(wT, torch.float32, "wT"), _dev(ln_w, torch.float32, "ln_w"),
+                                             _dev(ln_b, torch.float32, "ln_b"), N, K, wTg.data_ptr(), lnc.data_ptr(), _stream()),
+          "fold_layernorm")
+    return wTg, lnc
+
+
 def conv1d_s3(x, planes, bias, epilogue="none", residual=None):
     """:func:`conv1d` on the bf16 matrix cores at fp32 accuracy (three-way bf16 split of both operands, six partial
     products, fp32 accumulation); ``planes`` from :func:`split3_planes`."""

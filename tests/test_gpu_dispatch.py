@@ -103,6 +103,16 @@ def test_every_dispatcher_branch_is_exercised(dev):
         pos = torch.full((3,), 20, dtype=torch.int32, device=dev)
         hnew = tr.decode_step(cache, pos, input_ids=ids[:, 20].to(dev))
         assert rel_err(hnew.cpu().numpy(), ref[:, 20].numpy()) < 1e-4, ("decode", H, d)
+        if d in (512, 768):                                  # ... and with the LayerNorm constants formed per launch (no folded copies)
+            from rag4dyg_amd import gpt2 as gpt2_mod
+            fold_before = gpt2_mod.FOLD_DECODE_LAYERNORM
+            gpt2_mod.FOLD_DECODE_LAYERNORM = False
+            try:
+                tr.prefill(cache, input_ids=ids[:, :20].to(dev))
+                h2 = tr.decode_step(cache, pos, input_ids=ids[:, 20].to(dev))
+            finally:
+                gpt2_mod.FOLD_DECODE_LAYERNORM = fold_before
+            assert rel_err(h2.cpu().numpy(), ref[:, 20].numpy()) < 1e-4, ("decode, unfolded LayerNorm", H, d)
 
     # ---- pool scan variants (d), the short-shard form, the tiled-GEMM path (Q > 64), top-k forms, argsort forms
     def scan(Q, N, d, k=5):
