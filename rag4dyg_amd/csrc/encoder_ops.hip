@@ -297,20 +297,29 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const float* __restric
             kr[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ro + 16u * glc, 0, 0);
             vr[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ro + v_off, 0, 0);
         }
+        // the U logits of the trip first (U independent reductions over the group's lanes), ONE new running maximum, then the
+        // weights: the per-key form (maximum, rescale, accumulate, U times in a row) was a chain of U dependent
+        // shuffle-reduce + exp + fma steps behind the loads
+        float sv[U];
+        float mn = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f32x4d k4 = __builtin_bit_cast(f32x4d, kr[u]), v4 = __builtin_bit_cast(f32x4d, vr[u]);
-            const float sv = group_sum((k4.x * q4.x + k4.y * q4.y) + (k4.z * q4.z + k4.w * q4.w)) / scale;
-            if (t0 + u * NGRP + grp < p) {
-                const float mn = fmaxf(m, sv);
-                const float corr = __expf(m - mn), e = __expf(sv - mn);
-                l = l * corr + e;
-                acc.x = acc.x * corr + e * v4.x;
-                acc.y = acc.y * corr + e * v4.y;
-                acc.z = acc.z * corr + e * v4.z;
-                acc.w = acc.w * corr + e * v4.w;
-                m = mn;
+            const f32x4d k4 = __builtin_bit_cast(f32x4d, kr[u]);
+            const float dot = group_sum((k4.x * q4.x + k4.y * q4.y) + (k4.z * q4.z + k4.w * q4.w)) / scale;
+            sv[u] = (t0 + u * NGRP + grp < p) ? dot : -INFINITY;
+            mn = fmaxf(mn, sv[u]);
+        }
+        if (mn != -INFINITY) {                         // group-uniform: at least one key so far
+            const float corr = __expf(m - mn);         // m == -inf: 0
+            l *= corr; acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4d v4 = __builtin_bit_cast(f32x4d, vr[u]);
+                const float e = __expf(sv[u] - mn);    // keys past p: exp(-inf) == 0
+                l += e;
+                acc.x += e * v4.x; acc.y += e * v4.y; acc.z += e * v4.z; acc.w += e * v4.w;
             }
+            m = mn;
         }
     }
     pacc[grp][gl] = acc;
