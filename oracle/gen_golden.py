@@ -342,6 +342,52 @@ def _import_utils_model():
     return um
 
 
+# fusion_mlp + greedy loop around the reference's own ``utils.model.fusion_mlp`` (used by g7 and g12)
+def _run_fusion(out, um, tag, L, H, d, V, pad_id, eos_id, sources, queries, idxs, m, n_layers, topk, seed, n_gen=11):
+    from oracle import generator_ref
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
+    model = _ref_model("rag", L, H, d, V, 1024, sd)
+    mlp = model.get_mlp(512, m, n_layers)
+    mlp.load_state_dict(generator_ref.make_mlp_state(seed + 1, 512, m, n_layers))
+    args = types.SimpleNamespace(device="cpu", n_embed=d, m=m)
+    tok = types.SimpleNamespace(pad_token_id=pad_id)
+    ds = types.SimpleNamespace(retrieval_sources=sources)
+    gen, first_logits, step_top = [], [], []
+    with torch.no_grad():
+        for q, ix in zip(queries, idxs):
+            toks = list(q)
+            ids_sim = torch.tensor(ix, dtype=torch.long)
+            g_, tops = [], []
+            while True:                       # Evaluation_generator.py:153-175, val mode, around the reference fusion_mlp
+                logits = um.fusion_mlp(args, model, tok, ds, torch.tensor([toks]), ids_sim, m, top_k=topk)
+                last = logits[0, -1, :]
+                if not g_:
+                    first_logits.append(last.numpy().copy())
+                nxt = int(torch.argmax(last).item())
+                tv, ti = torch.topk(last, 2)
+                tops.append([float(tv[0]), float(tv[1])])
+                toks.append(nxt); g_.append(nxt)
+                if len(g_) > n_gen - 1 or nxt == eos_id:
+                    break
+            gen.append(g_); step_top.append(tops)
+        # batched call (B > 1, equal lengths): the flat `view` reshapes mix the batch dimension exactly as upstream
+        same = [q for q in queries if len(q) == len(queries[0])][:2]
+        if len(same) == 2:
+            bl = um.fusion_mlp(args, model, tok, ds, torch.tensor(same), torch.tensor(idxs[:2], dtype=torch.long), m, top_k=topk)
+            out[tag + "_batch2_last"] = bl[:, -1, :64].numpy()
+    used = sorted({int(i) for ix in idxs for i in ix[:topk]})
+    sf, so = _ragged([sources[i] for i in used])
+    qf, qo = _ragged(queries); gf, go = _ragged(gen)
+    tt = np.full((len(gen), n_gen, 2), np.nan, np.float32)
+    for i, tps in enumerate(step_top):
+        tt[i, :len(tps)] = np.asarray(tps, np.float32)
+    out.update({tag + "_cfg": np.array([L, H, d, V, pad_id, eos_id, m, n_layers, topk, seed]),
+                tag + "_src_ids": np.asarray(used, np.int64), tag + "_src_flat": sf, tag + "_src_off": so,
+                tag + "_q_flat": qf, tag + "_q_off": qo, tag + "_idxs": np.asarray(idxs, np.int64),
+                tag + "_gen_flat": gf, tag + "_gen_off": go, tag + "_first_logits": np.asarray(first_logits[:2]),
+                tag + "_step_top2": tt})
+
+
 def g7_generator():
     """RAG generator side, from the reference's own code on CPU:
     Evaluation metrics of both ``utils/Evaluation_*.py``, ``MLP_custom`` vectors, ``fusion_mlp`` logits and the greedy
@@ -386,48 +432,8 @@ def g7_generator():
             out[f"mlp{n_layers}_cfg"] = np.array([512, m, n_layers, 900 + n_layers])
 
     # ---- (c) fusion_mlp + greedy loop, tiny and reddit (BASELINE config 5) shapes
-    def run_fusion(tag, L, H, d, V, pad_id, eos_id, sources, queries, idxs, m, n_layers, topk, seed, n_gen=11):
-        sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
-        model = _ref_model("rag", L, H, d, V, 1024, sd)
-        mlp = model.get_mlp(512, m, n_layers)
-        mlp.load_state_dict(generator_ref.make_mlp_state(seed + 1, 512, m, n_layers))
-        args = types.SimpleNamespace(device="cpu", n_embed=d, m=m)
-        tok = types.SimpleNamespace(pad_token_id=pad_id)
-        ds = types.SimpleNamespace(retrieval_sources=sources)
-        gen, first_logits, step_top = [], [], []
-        with torch.no_grad():
-            for q, ix in zip(queries, idxs):
-                toks = list(q)
-                ids_sim = torch.tensor(ix, dtype=torch.long)
-                g_, tops = [], []
-                while True:                       # Evaluation_generator.py:153-175, val mode, around the reference fusion_mlp
-                    logits = um.fusion_mlp(args, model, tok, ds, torch.tensor([toks]), ids_sim, m, top_k=topk)
-                    last = logits[0, -1, :]
-                    if not g_:
-                        first_logits.append(last.numpy().copy())
-                    nxt = int(torch.argmax(last).item())
-                    tv, ti = torch.topk(last, 2)
-                    tops.append([float(tv[0]), float(tv[1])])
-                    toks.append(nxt); g_.append(nxt)
-                    if len(g_) > n_gen - 1 or nxt == eos_id:
-                        break
-                gen.append(g_); step_top.append(tops)
-            # batched call (B > 1, equal lengths): the flat `view` reshapes mix the batch dimension exactly as upstream
-            same = [q for q in queries if len(q) == len(queries[0])][:2]
-            if len(same) == 2:
-                bl = um.fusion_mlp(args, model, tok, ds, torch.tensor(same), torch.tensor(idxs[:2], dtype=torch.long), m, top_k=topk)
-                out[tag + "_batch2_last"] = bl[:, -1, :64].numpy()
-        used = sorted({int(i) for ix in idxs for i in ix[:topk]})
-        sf, so = _ragged([sources[i] for i in used])
-        qf, qo = _ragged(queries); gf, go = _ragged(gen)
-        tt = np.full((len(gen), n_gen, 2), np.nan, np.float32)
-        for i, tps in enumerate(step_top):
-            tt[i, :len(tps)] = np.asarray(tps, np.float32)
-        out.update({tag + "_cfg": np.array([L, H, d, V, pad_id, eos_id, m, n_layers, topk, seed]),
-                    tag + "_src_ids": np.asarray(used, np.int64), tag + "_src_flat": sf, tag + "_src_off": so,
-                    tag + "_q_flat": qf, tag + "_q_off": qo, tag + "_idxs": np.asarray(idxs, np.int64),
-                    tag + "_gen_flat": gf, tag + "_gen_off": go, tag + "_first_logits": np.asarray(first_logits[:2]),
-                    tag + "_step_top2": tt})
+    def run_fusion(*a, **k):
+        _run_fusion(out, um, *a, **k)
 
     rng = np.random.default_rng(5)
     V, pad, eos = 79, 78, 60
@@ -649,24 +655,33 @@ def g10_trained(tag="small", weights=None, device_npz=None):
     own trainer on the real UCI_13/12 data (GPU box: ``python tools/g10_trained.py <tag> L H d epochs lr`` -> gpurun_out/g10/
     <tag>_weights.npz, the reference script's recipe for the full-size run); here the SAME tensors are loaded into the
     reference model on CPU and the hot path is run with the reference's own modules (as g4 does).
-      tag == "small" (L2 H2 d128, 2.8 MB): weights + reference outputs are committed as tests/golden/g10_trained_small.npz;
+      tag == "small" (L2 H2 d128, 2.8 MB, ALL 28 tensors of the L2 model -- round 3's file had lost both c_attn.bias): weights +
+        reference outputs are committed as tests/golden/g10_trained_small.npz.  With no ``weights`` argument the weights are
+        read back from that committed file, so ``python oracle/gen_golden.py g10`` regenerates it bit for bit like every other
+        group; pass gpurun_out/g10/small_weights.npz to commit a NEW checkpoint.  The same call writes G11
+        (tests/golden/g11_stress_small.npz): the reference's outputs for ``gpt2_ref.stress_transform`` of those weights --
+        trained-GPT-2 statistics (outlier LayerNorm gains, offset residual rows, massive-activation channels);
       any other tag (the full-size L4 H2 d512 checkpoint, 56 MB: not committed): the reference outputs are compared with the
       device outputs the GPU run dumped next to the weights and a report goes to profiles/r03_trained_parity_<tag>.json."""
     print(f"G10 trained weights [{tag}]")
     import json
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    weights = weights or os.path.join(here, "gpurun_out", "g10", f"{tag}_weights.npz")
+    if weights is None and tag == "small":
+        w = np.load(os.path.join(GOLD, "g10_trained_small.npz"))
+        sd = {k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith("w:")}
+    else:
+        weights = weights or os.path.join(here, "gpurun_out", "g10", f"{tag}_weights.npz")
+        w = np.load(weights)
+        sd = {k: torch.from_numpy(w[k]) for k in w.files}
     device_npz = device_npz or os.path.join(here, "gpurun_out", "g10", f"{tag}_device.npz")
-    w = np.load(weights)
-    sd = {k: torch.from_numpy(w[k]) for k in w.files}
     d = sd["transformer.wte.weight"].shape[1]
     V = sd["transformer.wte.weight"].shape[0]
     L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer.h."))
     H = 2
     n_pos = sd["transformer.wpe.weight"].shape[0]
+    assert len(sd) == 12 * L + 4, f"{len(sd)} tensors for an L{L} model: expected {12 * L + 4} (wte, wpe, ln_f x2, 12 per block)"
     if "lm_head.weight" not in sd:
         sd["lm_head.weight"] = sd["transformer.wte.weight"]
-    m = _ref_model("rag", L, H, d, V, n_pos, sd)
     g6 = np.load(os.path.join(GOLD, "g6_uci_tokens.npz"))
     pad = int(g6["pad_id"])
 
@@ -679,13 +694,17 @@ def g10_trained(tag="small", weights=None, device_npz=None):
         for s in range(0, len(examples), 32):
             ch = [torch.tensor(e, dtype=torch.long) for e in examples[s:s + 32]]
             yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=pad)
-    with torch.no_grad():
-        pe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool[:NP])], dim=0)
-        qe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(test)], dim=0)
-        qn = qe / qe.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
-        pn = pe / pe.norm(dim=1, keepdim=True)
-        S = ((torch.matmul(qn, pn.t()) + 1) / 2).numpy()
-    top10 = np.argsort(-S, axis=1, kind="stable")[:, :10].astype(np.int32)
+
+    def hot_path(state):
+        m = _ref_model("rag", L, H, d, V, n_pos, state)
+        with torch.no_grad():
+            pe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool[:NP])], dim=0)
+            qe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(test)], dim=0)
+            qn = qe / qe.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
+            pn = pe / pe.norm(dim=1, keepdim=True)
+            S = ((torch.matmul(qn, pn.t()) + 1) / 2).numpy()
+        return pe, qe, S, np.argsort(-S, axis=1, kind="stable")[:, :10].astype(np.int32)
+    pe, qe, S, top10 = hot_path(sd)
     stats = {"max_abs_weight": float(max(v.abs().max() for v in sd.values())),
              "ln_gain_range": [float(min(v.min() for k, v in sd.items() if "ln_" in k and k.endswith("weight"))),
                                float(max(v.max() for k, v in sd.items() if "ln_" in k and k.endswith("weight")))],
@@ -695,6 +714,20 @@ def g10_trained(tag="small", weights=None, device_npz=None):
               pool_emb=pe.numpy(), query_emb=qe.numpy(), scores=S, top10_stable=top10,
               **{"w:" + k: v.numpy() for k, v in sd.items() if k != "lm_head.weight"})
         print("   ", stats)
+        # ---- G11: the same checkpoint with trained-GPT-2 statistics (oracle/gpt2_ref.py:stress_transform), reference outputs only
+        st = gpt2_ref.stress_transform(sd)
+        pe2, qe2, S2, top2 = hot_path(st)
+        ids0 = next(batches(test))
+        with torch.no_grad():
+            m2 = _ref_model("gpt2", L, H, d, V, n_pos, st, output_hidden_states=True)
+            hs = m2(ids0)[2]
+        ratio = [float((h.mean(-1).abs() / h.std(-1)).median()) for h in hs[:-1]]
+        sig = np.array([float(st[k].double().abs().sum()) for k in sorted(st) if k != "lm_head.weight"])
+        _save("g11_stress_small", n_layer=np.array(L), n_head=np.array(H), pool_rows=np.array(NP), pool_emb=pe2.numpy(),
+              query_emb=qe2.numpy(), scores=S2, top10_stable=top2, weight_abs_sums=sig,
+              residual_mean_over_std=np.array(ratio), residual_absmax=np.array([float(h.abs().max()) for h in hs[:-1]]))
+        print("    G11 stress: residual |row mean| / std per layer", [round(r, 2) for r in ratio], "query emb absmax",
+              float(qe2.abs().max()), "score range", float(S2.min()), float(S2.max()))
         return
     dv = np.load(device_npz)
     rep = {"checkpoint": f"tools/g10_trained.py {tag}: {L} layers, {H} heads, d {d}, vocab {V}; the reference recipe "
@@ -721,15 +754,162 @@ def g10_trained(tag="small", weights=None, device_npz=None):
     print(json.dumps(rep, indent=1))
 
 
+# --------------------------------------------------------------------------- G12
+def _regenerated_dataset_cwd(pairs):
+    """A scratch cwd holding ``resources/<ds>/<t>/*.link_prediction`` + ``vocabs/<ds>/<t>/vocab.json`` REGENERATED by the
+    reference's own ``csv2resources.py`` (run unmodified as a child process, cwd-relative ``../all_data`` -> a symlink to the
+    reference's ``all_data``) from ``all_data/<ds>/<t>/ml_<ds>.csv`` -- the reference ships no ``resources/`` for wikiv2 /
+    reddit (SURVEY ground facts).  Row order inside one second depends on the installed pandas' ``sort_values``,
+    so the ids committed by g12 ARE the fixture; the csv is not re-read on the GPU box."""
+    import subprocess
+    root = tempfile.mkdtemp(prefix="r4d_g12_")
+    os.symlink(os.path.join(REF, "all_data"), os.path.join(root, "all_data"))
+    work = os.path.join(root, "work")
+    os.makedirs(os.path.join(work, "tokenizers"))
+    for ds, ts in pairs:
+        r = subprocess.run([sys.executable, os.path.join(REF, "csv2resources.py"), ds, str(ts)], cwd=work, capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        if r.returncode != 0:
+            # reddit/11: the reference's own script raises at csv2resources.py:186 (`int(NaN)`: a validation user without any
+            # history row) AFTER writing the complete train file (10,527 lines, :117-164) and the first 1,285 val lines, and BEFORE
+            # the test files and vocab.json (:211-231).  Nothing is patched: the train file and the val lines it did write are
+            # used as they are, and the vocabulary of :211-231 ({str(id): rank among the sorted ids of u and i}) is written by
+            # the harness from the same csv.
+            assert ds == "reddit" and "cannot convert float NaN to integer" in r.stderr, r.stderr[-2000:]
+            import json
+            import pandas as pd
+            data = pd.read_csv(os.path.join(REF, "all_data", ds, str(ts), f"ml_{ds}.csv"), index_col=0)
+            ids = sorted(set(list(data["u"]) + list(data["i"])))
+            with open(os.path.join(work, "vocabs", ds, str(ts), "vocab.json"), "w") as f:
+                json.dump({str(i): ind for ind, i in enumerate(ids)}, f, indent=4)
+    os.chdir(work)
+    return work
+
+
+def g12_real_wikiv2_reddit():
+    """REAL-DATA fixtures for BASELINE configs 4 and 5.
+    wikiv2/15 (config 4: L2 H6 d768, block 512): the reference tokenizer + dataset classes on the regenerated files -> ids of the
+    8,556 pool histories, the 593 test and 868 val queries (two pool sequences exceed 512 tokens: the left-truncation case);
+    the reference model (seeded weights loaded into it, as g4) over the WHOLE pool and all test queries -> first / last two pool
+    batches, every pool norm, the float64 column sum, 64 full query rows + every query norm, the scores against the first 512
+    pool rows, and the stable top-32 (index, score) of every query over the full pool (a full [593, 8556] score matrix would be
+    20 MB; the top-32 lets the test price any mismatching rank in REFERENCE scores).
+    reddit/11 (config 5 inputs: L2 H8 d512, generator tokenizer without [MASK]): ids of the 10,527 training lines (the
+    generator's ``retrieval_sources``) and of the 1,285 validation queries the reference's script writes before it raises on
+    this csv (``_regenerated_dataset_cwd``; the test files are never written) via ``TextIndexScoreDataset``'s own encode calls;
+    ``fusion_mlp`` + the greedy loop on six REAL queries with seven real demonstrations each (``fmlp_reddit_real``, g7's recipe)."""
+    print("G12 real wikiv2 / reddit")
+    import time
+    _regenerated_dataset_cwd([("wikiv2", 15), ("reddit", 11)])
+    import dataloader.retriever as dr
+    tok = _ref_tokenizer("wikiv2", 15)
+    base = "resources/wikiv2/15/"
+    args = types.SimpleNamespace()
+    pool_ds = dr.LineByLineTextDatasetHistory(tok, args, base + "train.link_prediction", block_size=512)
+    test_ds = dr.LineByLineTextDataset(tok, args, base + "test.link_prediction", block_size=512)
+    val_ds = dr.LineByLineTextDataset(tok, args, base + "val.link_prediction", block_size=512)
+    with open(base + "train.link_prediction") as f:
+        raw_len = [len(ln.split("<|pre|>")[0].split()) for ln in f.read().splitlines() if ln.strip()]
+    long_rows = [i for i, n in enumerate(raw_len) if n > 512]
+    assert len(pool_ds.examples) == 8556 and len(test_ds.examples) == 593 and len(val_ds.examples) == 868 and len(tok) == 8814
+    assert len(long_rows) >= 1 and all(len(pool_ds.examples[i]) == 512 for i in long_rows)
+    pf, po = _ragged(pool_ds.examples); tf, to = _ragged(test_ds.examples); vf, vo = _ragged(val_ds.examples)
+    names = ["<|endoftext|>", "<|history|>", "<|endofhistory|>", "<|pre|>", "<|endofpre|>", "<|time0|>", "<|time15|>", "[PAD]", "[MASK]"]
+    with open(base + "train.link_prediction") as f:
+        hist = [ln.split("<|pre|>")[0] for ln in f.read().splitlines() if ln.strip()]
+    full = [tok(hist[i])["input_ids"] for i in long_rows]           # the same tokenizer WITHOUT max_length: what truncation cut from
+    assert all(full[j][-512:] == pool_ds.examples[i] for j, i in enumerate(long_rows))
+    lf, lo = _ragged(full)
+    import json
+    vocab = json.load(open("vocabs/wikiv2/15/vocab.json"))
+    vk = np.asarray([int(k_) for k_, _v in sorted(vocab.items(), key=lambda kv: kv[1])], np.int64)
+    assert sorted(vocab.values()) == list(range(len(vocab)))
+    _save("g6_wikiv2_tokens", pool_flat=pf, pool_off=po, test_flat=tf, test_off=to, val_flat=vf, val_off=vo,
+          vocab_keys=vk, truncated_full_flat=lf, truncated_full_off=lo,
+          truncated_rows=np.asarray(long_rows, np.int64), truncated_raw_len=np.asarray([raw_len[i] for i in long_rows], np.int64),
+          special_names=np.array(names), special_ids=np.array([tok.convert_tokens_to_ids(t_) for t_ in names]),
+          len_tok=np.array(len(tok)), vocab_size=np.array(tok.vocab_size), pad_id=np.array(tok.pad_token_id))
+    L, H, d, V = 2, 6, 768, len(tok)
+    sd = gpt2_ref.make_state_dict(L, d, V, seed=2027, random_affine=True)
+    m = _ref_model("rag", L, H, d, V, 1024, sd)
+
+    def batches(examples):          # dataloader/retriever.py:153-166 around the reference model (as g4)
+        for s_ in range(0, len(examples), 32):
+            ch = [torch.tensor(e, dtype=torch.long) for e in examples[s_:s_ + 32]]
+            yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=tok.pad_token_id)
+    t0 = time.time()
+    with torch.no_grad():
+        pool = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool_ds.examples)], dim=0)
+        q = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(test_ds.examples)], dim=0)
+        qn = q / q.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
+        pn = pool / pool.norm(dim=1, keepdim=True)
+        S = ((torch.matmul(qn, pn.t()) + 1) / 2).numpy()
+    print(f"    reference encode + score of 8,556 + 593 sequences: {time.time() - t0:.0f} s")
+    order = np.argsort(-S, axis=1, kind="stable")[:, :32]
+    lb = [i // 32 for i in long_rows]                               # the batches holding a truncated sequence
+    _save("g12_wikiv2_retrieval", seed=np.array(2027), cfg=np.array([L, H, d, V]), pool_emb_head=pool[:64].numpy(),
+          pool_emb_tail=pool[-(len(pool) - (len(pool) - 1) // 32 * 32 + 32):].numpy(),
+          pool_emb_norms=pool.norm(dim=1).numpy(), pool_emb_colsum=pool.double().sum(0).numpy(),
+          pool_emb_truncated_batches=np.concatenate([pool[b * 32:b * 32 + 32].numpy() for b in lb]),
+          truncated_batches=np.asarray(lb, np.int64), query_emb_head=q[:64].numpy(), query_emb_norms=q.norm(dim=1).numpy(),
+          scores_first512=S[:, :512].copy(), top32_idx=order.astype(np.int32), top32_scores=np.take_along_axis(S, order, axis=1),
+          score_row_sums=S.astype(np.float64).sum(1))
+
+    # ---- reddit / 11 (BASELINE config 5 inputs), generator flavour
+    from models import GPT2Config
+    import models.modeling_rag as mr
+    from transformers import PreTrainedTokenizerFast
+    from utils.tokenizer_generator import get_model_tokenizer as get_gen
+    import dataloader.generator as dg
+    um = _import_utils_model()
+    a = types.SimpleNamespace(model_type="gpt2", config_name=None, model_name_or_path=None, cache_dir=None, n_head=2, n_layer=1,
+                              n_embed=16, timestamp="11", dataset="reddit", device="cpu", node_feat_file=None)
+    _, rtok, _, _ = get_gen(a, {"gpt2": (GPT2Config, mr.GPT2LMHeadModel, PreTrainedTokenizerFast)})
+    if not hasattr(rtok, "batch_encode_plus"):
+        type(rtok).batch_encode_plus = lambda self, lines, **kw: self(lines, **kw)
+    assert len(rtok) == 11919
+    rbase = "resources/reddit/11/"
+    rng = np.random.default_rng(12)
+    n_test = sum(1 for ln in open(rbase + "val.link_prediction") if ln.strip())   # the val lines the script wrote before it raised
+    assert n_test == 1285 and sum(1 for ln in open(rbase + "train.link_prediction") if ln.strip()) == 10527
+    idx_rows = [rng.permutation(10527)[:20].tolist() for _ in range(n_test)]     # a stand-in retrieval ranking (no retriever output is shipped)
+    with open("g12_idx.txt", "w") as f:
+        f.write("\n".join(" ".join(map(str, r)) for r in idx_rows) + "\n")
+    with open("g12_score.txt", "w") as f:
+        f.write("\n".join(" ".join("%.4f" % (1 - 0.01 * j) for j in range(20)) for _ in idx_rows) + "\n")
+    ds = dg.TextIndexScoreDataset(rtok, types.SimpleNamespace(train_data_file=rbase + "train.link_prediction"),
+                                  rbase + "val.link_prediction", "g12_idx.txt", "g12_score.txt", block_size=1024)
+    assert len(ds.retrieval_sources) == 10527
+    sf, so = _ragged(ds.retrieval_sources); qf, qo = _ragged(ds.text)
+    rnames = ["<|endoftext|>", "<|history|>", "<|endofhistory|>", "<|pre|>", "<|endofpre|>", "<|time0|>", "<|time11|>", "[PAD]"]
+    rvocab = json.load(open("vocabs/reddit/11/vocab.json"))
+    rvk = np.asarray([int(k_) for k_, _v in sorted(rvocab.items(), key=lambda kv: kv[1])], np.int64)
+    _save("g6_reddit_tokens", vocab_keys=rvk, source_flat=sf, source_off=so, val_flat=qf, val_off=qo, egos=np.asarray(ds.egolist, np.int64),
+          special_names=np.array(rnames), special_ids=np.array([rtok.convert_tokens_to_ids(t_) for t_ in rnames]),
+          len_tok=np.array(len(rtok)), vocab_size=np.array(rtok.vocab_size), pad_id=np.array(rtok.pad_token_id))
+    out = {}
+    lens = np.array([len(t_) for t_ in ds.text])
+    pick = [int(i) for i in np.argsort(lens, kind="stable")[[len(lens) // 10, len(lens) // 4, len(lens) // 2, len(lens) // 2 + 1,
+                                                              3 * len(lens) // 4, 9 * len(lens) // 10]]]
+    # demonstrations short enough that query + 7 demos stay inside n_positions (utils/model.py pads demos to the longest of the 7)
+    short = [i for i, s_ in enumerate(ds.retrieval_sources) if len(s_) <= 120]
+    idxs = [[short[j] for j in rng.permutation(len(short))[:7]] for _ in pick]
+    _run_fusion(out, um, "fmlp_reddit_real", 2, 8, 512, len(rtok), rtok.pad_token_id, rtok.convert_tokens_to_ids("<|endoftext|>"),
+                ds.retrieval_sources, [ds.text[i] for i in pick], idxs, 1, 1, 7, 330)
+    out["fmlp_reddit_real_query_rows"] = np.asarray(pick, np.int64)
+    _save("g12_reddit_generator", **out)
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "g10":                   # g10 <tag> [weights.npz] [device.npz]
+    if len(sys.argv) > 2 and sys.argv[1] == "g10":                   # g10 <tag> [weights.npz] [device.npz]
         torch.set_num_threads(os.cpu_count() or 1)
         _install_stubs()
         _scratch_cwd()
         g10_trained(*sys.argv[2:5])
         return
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
-              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g8b": g8b_lr_schedule, "g9": g9_query_times}
+              "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g8b": g8b_lr_schedule, "g9": g9_query_times,
+              "g10": g10_trained, "g12": g12_real_wikiv2_reddit}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

@@ -192,3 +192,38 @@ def greedy_decode(sd, n_head, indexed_tokens, eos_id, mode="val", max_len=1024, 
         if nxt == eos_id:
             break
     return toks
+
+
+def stress_transform(sd):
+    """TRAINED-GPT-2 STATISTICS on top of a checkpoint (fixture G11): a deterministic edit of a
+    reference-layout state dict that gives it the features large trained GPT-2s show and an N(0, 0.02) initialisation does
+    not -- a handful of LayerNorm gains 6-10x the rest, two `wte` outlier channels and a `wpe` offset in EVERY channel (residual
+    rows whose mean is many times their spread: the LayerNorm variance is a small difference of large numbers), one output
+    column of a `c_proj` of every block 20x (a massive-activation channel written into the residual stream) and a `c_attn`
+    query/key bias that sharpens the softmax.  Returns a new dict (tensors cloned); the tied `lm_head.weight` follows `wte`.
+    Nothing here comes from the reference: it is an input generator, applied identically before the reference model
+    (oracle/gen_golden.py g11) and the HIP path (tests) load the weights."""
+    out = {k: v.clone() for k, v in sd.items() if k != "lm_head.weight"}
+    d = out["transformer.wte.weight"].shape[1]
+    n = n_layers_of(out)
+
+    def ch(*frac):                                      # channel picks that scale with d (d 128 -> e.g. 3, 17, 64, 101)
+        return sorted({int(f * d) % d for f in frac})
+    for i in range(n):
+        p = f"transformer.h.{i}."
+        out[p + "ln_1.weight"][ch(0.025, 0.135, 0.5, 0.79)] *= 8.0
+        out[p + "ln_2.weight"][ch(0.04, 0.31, 0.6)] *= 6.0
+        out[p + "mlp.c_proj.weight"][:, ch(0.09 + 0.2 * i)] *= 20.0
+        out[p + "attn.c_proj.weight"][:, ch(0.55 + 0.1 * i)] *= 20.0
+        b = out[p + "attn.c_attn.bias"]
+        b[ch(0.07)[0]] += 2.0                           # one query channel ...
+        b[d + ch(0.07)[0]] += 2.0                       # ... and the matching key channel
+    out["transformer.ln_f.weight"][ch(0.017, 0.26, 0.7)] *= 10.0
+    out["transformer.wte.weight"][:, ch(0.055, 0.39)] += 0.3
+    out["transformer.wpe.weight"] += 0.25
+    if "lm_head.weight" in sd and sd["lm_head.weight"].data_ptr() != sd["transformer.wte.weight"].data_ptr() \
+            and not torch.equal(sd["lm_head.weight"], sd["transformer.wte.weight"]):
+        out["lm_head.weight"] = sd["lm_head.weight"].clone()            # an untied head stays as it is
+    else:
+        out["lm_head.weight"] = out["transformer.wte.weight"]
+    return out

@@ -165,6 +165,17 @@ class _PreTrained(nn.Module):
         return model
 
 
+# Parameters written through RAW POINTERS (``r4d_adamw_step_f32``: training.AdamW.step) do not bump torch's in-place version
+# counter, which is what the derived-weight caches below are keyed on.  Every such writer calls ``note_raw_parameter_write()``;
+# the generation is part of every cache stamp, so transposed copies, bf16x3 planes and LayerNorm-folded decode weights of ALL
+# models are rebuilt on their next use (evaluation between optimizer steps used stale planes).
+_RAW_WRITE_GENERATION = [0]
+
+
+def note_raw_parameter_write():
+    _RAW_WRITE_GENERATION[0] += 1
+
+
 class GPT2Model(_PreTrained):
     """``models/modeling_gpt2.py:328-509``."""
 
@@ -213,8 +224,9 @@ class GPT2Model(_PreTrained):
         cache = self.__dict__.setdefault("_wt_cache", {})
         key = id(w)
         ent = cache.get(key)
-        if ent is None or ent[0] != (w.data_ptr(), w._version):
-            ent = ((w.data_ptr(), w._version), w.detach().t().contiguous())
+        stamp = (w.data_ptr(), w._version, _RAW_WRITE_GENERATION[0])
+        if ent is None or ent[0] != stamp:
+            ent = (stamp, w.detach().t().contiguous())
             cache[key] = ent
         return ent[1].data_ptr()
 
@@ -226,8 +238,9 @@ class GPT2Model(_PreTrained):
         cache = self.__dict__.setdefault("_w3_cache", {})
         key = id(w)
         ent = cache.get(key)
-        if ent is None or ent[0] != (w.data_ptr(), w._version):
-            ent = ((w.data_ptr(), w._version), ops.split3_planes(w.detach()))
+        stamp = (w.data_ptr(), w._version, _RAW_WRITE_GENERATION[0])
+        if ent is None or ent[0] != stamp:
+            ent = (stamp, ops.split3_planes(w.detach()))
             cache[key] = ent
         return ent[1].data_ptr()
 
@@ -236,7 +249,8 @@ class GPT2Model(_PreTrained):
         reads LayerNorm ``ln`` (``ops.fold_layernorm``), cached until the weight or the LayerNorm changes."""
         cache = self.__dict__.setdefault("_fold_cache", {})
         key = id(w)
-        stamp = (w.data_ptr(), w._version, ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version)
+        stamp = (w.data_ptr(), w._version, ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version,
+                 _RAW_WRITE_GENERATION[0])
         ent = cache.get(key)
         if ent is None or ent[0] != stamp:
             self._wt(w)

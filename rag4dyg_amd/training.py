@@ -117,6 +117,7 @@ def training_step_forward(args, model, batch, all_query_time):
 import ctypes                                                                   # noqa: E402
 
 from . import _lib, ops                                                         # noqa: E402
+from .gpt2 import note_raw_parameter_write                                     # noqa: E402
 
 _LAYER_PARAMS = (("ln_1_w", "ln_1.weight"), ("ln_1_b", "ln_1.bias"), ("c_attn_w", "attn.c_attn.weight"),
                  ("c_attn_b", "attn.c_attn.bias"), ("attn_proj_w", "attn.c_proj.weight"), ("attn_proj_b", "attn.c_proj.bias"),
@@ -327,6 +328,7 @@ class AdamW:
                                               p.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                               float(self.wd[n]), self.t, self.sumsq.data_ptr() if max_grad_norm else None,
                                               float(max_grad_norm or 0.0), stream), "adamw")
+        note_raw_parameter_write()        # the kernels wrote the parameters behind torch's version counters: derived copies are stale
 
     def grad_norm(self):
         return float(self.sumsq[0].sqrt().item())
@@ -371,7 +373,8 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, micro_
         trainer.all_reduce_mean()
         optimizer.step(getattr(args, "max_grad_norm", 0.0))
         trainer.refresh_transposed()
-        model.transformer.__dict__.pop("_wt_cache", None)        # transposed weight copies of the inference path are stale now
+        for c in ("_wt_cache", "_w3_cache", "_fold_cache"):       # the inference path's derived weights are stale now (also
+            model.transformer.__dict__.pop(c, None)               # guarded by gpt2.note_raw_parameter_write in AdamW.step)
     if not sync:
         return dict(loss=loss, cl_loss=cl, aug_loss=au, stepped=stepped)
     return dict(loss=float(loss.item()), cl_loss=float(cl.item()), aug_loss=float(au.item()), stepped=stepped)

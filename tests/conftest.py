@@ -70,3 +70,15 @@ def assert_tokens_equal_or_tie(got, want, logits_at, what="", rel_gap=2e-6):
     print(f"[tie] {what}: step {i} device {got[i]} vs oracle {want[i]}: logit gap {gap:.3e} (max|logit| {scale:.3e})")
     assert gap <= rel_gap * scale, f"{what}: step {i} differs at a logit gap of {gap:.3e} (> {rel_gap} * {scale:.3e})"
     return 0
+
+
+def load_state_dict_checked(model, sd):
+    """``load_state_dict(strict=False)`` with the ONLY tolerated gaps spelled out: the causal-mask buffers ``*.attn.bias`` /
+    ``*.attn.masked_bias`` (not parameters; ``.attn.bias`` with the leading dot, so ``attn.c_attn.bias`` does not match) and the
+    tied ``lm_head.weight``.  Anything else missing or unexpected fails the test (a fixture that had lost
+    both ``c_attn.bias`` tensors loaded silently)."""
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if not (k.endswith(".attn.bias") or k.endswith(".attn.masked_bias") or k == "lm_head.weight")]
+    assert not unexpected, f"unexpected keys: {unexpected}"
+    assert not bad, f"missing keys: {bad}"
+    return model

@@ -41,15 +41,16 @@ def _rag_model(sd, L, H, d, V, dev):
     return m
 
 
-@pytest.mark.parametrize("tag", ["fmlp_tiny", "fmlp_reddit"])
+@pytest.mark.parametrize("tag", ["fmlp_tiny", "fmlp_reddit", "fmlp_reddit_real"])
 def test_fusion_mlp_logits_and_greedy_ids_equal_reference(dev, tag):
     """utils/model.py:105-164 + Evaluation_generator.py:153-175 as the REFERENCE computed them on CPU: first-step logits
     within 1e-4 (element-wise), generated ids identical for the reference-structured loop (batch 1, full forward per
     token) AND for the batched key/value-cached decode.  fmlp_reddit = BASELINE config 5 shape (L2 H8 d512 V11919, pool
-    10,527, top-7)."""
+    10,527, top-7) on synthetic ids; fmlp_reddit_real = the same shape on REAL reddit/11 ids (g12: the training lines the
+    reference's csv2resources.py regenerates as demonstrations, six of the validation queries it writes)."""
     from oracle import generator_ref, gpt2_ref
     from rag4dyg_amd import generator, ops
-    g = load_golden("g7_generator")
+    g = load_golden("g12_reddit_generator" if tag.endswith("_real") else "g7_generator")
     L, H, d, V, pad, eos, m, nl, topk, seed = (int(x) for x in g[tag + "_cfg"])
     sd = gpt2_ref.make_state_dict(L, d, V, n_positions=1024, seed=seed, random_affine=True)
     model = _rag_model(sd, L, H, d, V, dev)

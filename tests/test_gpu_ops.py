@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import elementwise_err, load_golden, rel_err
+from conftest import elementwise_err, load_golden, load_state_dict_checked, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -27,8 +27,7 @@ def build_model(sd, L, H, d, V, P, dev, flavour="rag"):
     cfg = GPT2Config(vocab_size=V, n_positions=P, n_ctx=P, n_embd=d, n_layer=L, n_head=H)
     cls = GPT2LMHeadModelRAG if flavour == "rag" else GPT2LMHeadModel
     m = cls(cfg)
-    missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and all(k.endswith("attn.bias") for k in missing)
+    load_state_dict_checked(m, sd)
     m.tie_weights()
     return m.to(dev).eval()
 

@@ -203,6 +203,68 @@ def test_training_step_parameter_update_equals_oracle_adamw(dev):
     assert "_wt_cache" not in m.transformer.__dict__                         # stale transposed copies dropped
 
 
+@pytest.mark.parametrize("via_step", [True, False])
+def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step):
+    """``r4d_adamw_step_f32`` writes the parameters through raw pointers, so torch's version counters do not
+    move and the inference path's derived weights (transposed copies, bf16x3 planes -- default ON --, LayerNorm-folded decode
+    weights) would stay at the values of the first validation.  Encode, take one optimizer step with a LARGE learning rate
+    (through ``training_step`` and through a bare ``AdamW.step``), then the model's encode -- and one cached decode step -- must equal
+    the same calls on a fresh copy of the updated weights, with the bf16x3 GEMMs on."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd import ops, training
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    g = load_golden("g8_training_step")
+    tag = "ts_tiny"
+    _L, _H, _d, V0, _pad, B, seed = (int(x) for x in g[tag + "_cfg"])
+    L, H, d, V = 2, 2, 512, V0                                     # d 512: the decode step's LayerNorm-folded projections exist
+    eta, gamma, alpha, temp, lam = (float(x) for x in g[tag + "_hyper"])
+    cfg = GPT2Config(vocab_size=V, n_positions=128, n_ctx=128, n_embd=d, n_layer=L, n_head=H)
+    cfg.eta, cfg.gamma = eta, gamma
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=128, seed=seed, random_affine=True)
+    m = GPT2LMHeadModelRAG(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    was = ops.gemm_split3_enabled()
+    ops.set_gemm_split3(True)
+    try:
+        T = torch.from_numpy
+        idx = T(g[tag + "_idx"])
+        ids = T(g[tag + "_anchor"]).to(dev)
+        kv = m.transformer.new_kv_cache(ids.shape[0], 64, dev)
+        pos0 = torch.full((ids.shape[0],), ids.shape[1], dtype=torch.int32, device=dev)
+        before = m.transformer.encode(ids, want_hidden=False, want_meanpool=True)["meanpool"].clone()
+        m.transformer.prefill(kv, input_ids=ids)
+        m.transformer.decode_step(kv, pos0, input_ids=ids[:, -1])             # builds the folded decode weights
+        trainer = training.EncoderTrainer(m)
+        opt = training.AdamW(trainer.params, trainer.grads, lr=0.05, eps=1e-8, weight_decay=0.0)
+        args = types.SimpleNamespace(device=dev, temperature=temp, lambda_decay=lam, alpha=alpha, per_gpu_train_batch_size=B,
+                                     max_grad_norm=0.0, gradient_accumulation_steps=1)
+        batch = (T(g[tag + "_anchor"]), T(g[tag + "_pos"]), T(g[tag + "_neg"]), idx[:, 0:1], idx[:, 1:2], idx[:, 2:3])
+        random.seed(seed)
+        if via_step:
+            training.training_step(args, m, trainer, opt, batch, T(g[tag + "_times"]))
+        else:
+            emb = trainer.forward([ids])
+            trainer.backward(torch.ones_like(emb))
+            opt.step(0.0)
+        after = m.transformer.encode(ids, want_hidden=False, want_meanpool=True)["meanpool"]
+        h_last = m.transformer.prefill(kv, input_ids=ids)
+        dec = m.transformer.decode_step(kv, pos0, input_ids=ids[:, -1])
+        fresh = GPT2LMHeadModelRAG(cfg)
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, strict=False)
+        fresh = fresh.to(dev).eval()
+        want = fresh.transformer.encode(ids, want_hidden=False, want_meanpool=True)["meanpool"]
+        kv2 = fresh.transformer.new_kv_cache(ids.shape[0], 64, dev)
+        fresh.transformer.prefill(kv2, input_ids=ids)
+        want_dec = fresh.transformer.decode_step(kv2, pos0, input_ids=ids[:, -1])
+    finally:
+        ops.set_gemm_split3(was)
+    moved = (after - before).abs().max().item() / before.abs().max().item()
+    assert moved > 1e-2, f"the step did not move the embeddings ({moved:.2e}): the test would prove nothing"
+    assert torch.equal(after, want), f"stale derived weights after the optimizer step: {(after - want).abs().max().item():.3e}"
+    assert torch.equal(dec, want_dec), f"stale folded decode weights: {(dec - want_dec).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("L,H,d,V,B,Ts", [(2, 6, 768, 300, 4, (37, 50, 23)),      # wikiv2 script shape (head_dim 128)
                                            (3, 2, 256, 200, 5, (21, 33, 40)),      # hepth script shape (head_dim 128, d = 256)
                                            (1, 8, 512, 500, 3, (130, 9, 64)),      # reddit shape (head_dim 64), one batch > 128 positions

@@ -299,6 +299,43 @@ def test_tokenizer_on_shipped_hepth_and_dialog_files_matches_reference_ids(ds, t
         assert np.array_equal(np.cumsum([0] + [len(x) for x in ids]), g[split + "_off"])
 
 
+def test_tokenizer_and_datasets_on_regenerated_wikiv2_and_reddit_match_reference_ids(tmp_path):
+    """BASELINE configs 4 / 5 on their own data (gen_golden g12).  The text files the reference's csv2resources.py regenerates do
+    not travel; the fixture holds the reference tokenizer's ids and the vocabulary keys, so the files are REBUILT here by decoding
+    those ids (the two wikiv2 histories longer than block_size from their untruncated ids) and pushed through this build's
+    tokenizer + dataset classes: same ids, same left-truncation to the last 512 tokens, same special-token layout."""
+    import json
+    from rag4dyg_amd.dataloader import LineByLineTextDataset, LineByLineTextDatasetHistory
+    from rag4dyg_amd.tokenizer import build_tokenizer
+    for ds, ts, with_mask, splits in (("wikiv2", 15, True, (("pool", True), ("test", False), ("val", False))),
+                                      ("reddit", 11, False, (("source", False), ("val", False)))):
+        g = dict(load_golden(f"g6_{ds}_tokens"))                      # (an NpzFile decompresses an array on EVERY access)
+        os.makedirs(tmp_path / "vocabs" / ds / str(ts))
+        json.dump({str(int(k)): i for i, k in enumerate(g["vocab_keys"])}, open(tmp_path / "vocabs" / ds / str(ts) / "vocab.json", "w"))
+        tok, _ = build_tokenizer(ds, ts, with_mask=with_mask, root=str(tmp_path))
+        assert len(tok) == int(g["len_tok"]) and tok.vocab_size == int(g["vocab_size"]) and tok.pad_token_id == int(g["pad_id"])
+        for name, want in zip(g["special_names"], g["special_ids"]):
+            assert tok.convert_tokens_to_ids(str(name)) == int(want), name
+        for key, hist in splits:
+            seqs = [g[key + "_flat"][a:b].tolist() for a, b in zip(g[key + "_off"][:-1], g[key + "_off"][1:])]
+            block = 512 if ds == "wikiv2" else 1024
+            if key == "pool":                                             # the histories that truncation cut: rebuild the FULL line
+                for j, r in enumerate(g["truncated_rows"]):
+                    full = g["truncated_full_flat"][g["truncated_full_off"][j]:g["truncated_full_off"][j + 1]].tolist()
+                    assert len(full) == int(g["truncated_raw_len"][j]) > 512 and full[-512:] == seqs[int(r)]
+                    seqs[int(r)] = full
+            lines = [tok.decode(s_) + (" <|pre|> <|time%d|> 0 <|endofpre|> <|endoftext|>" % ts if hist else "") for s_ in seqs]
+            path = tmp_path / f"{ds}_{key}.txt"
+            path.write_text("\n".join(lines) + "\n")
+            cls = LineByLineTextDatasetHistory if hist else LineByLineTextDataset
+            got = cls(tok, None, str(path), block_size=block).examples
+            assert len(got) == len(seqs)
+            assert np.array_equal(np.concatenate([np.asarray(x) for x in got]), g[key + "_flat"]), (ds, key)
+            assert np.array_equal(np.cumsum([0] + [len(x) for x in got]), g[key + "_off"])
+        if ds == "wikiv2":
+            assert max(len(x) for x in got) <= 512 and len(g["truncated_rows"]) == 2
+
+
 # ------------------------------------------------------------------------------------------- data / parsing / synth
 def test_dataset_classes_and_eval_batching(tmp_path):
     from types import SimpleNamespace
@@ -455,8 +492,9 @@ print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_topk_world_size_2_gloo(tmp_path, world):
+    """world 8 = the north-star node: 200 rows are 7 batch-aligned units, so one of the eight ranks owns an EMPTY shard."""
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     port = str(29600 + world + os.getpid() % 200)
