@@ -281,7 +281,7 @@ def main():
                          "as one fused launch sequence")
     ap.add_argument("--query-batches", type=int, default=256,
                     help="distinct synthetic query batches cycled over the steps (256 x 32 = the 8192 queries of SURVEY 8d)")
-    ap.add_argument("--gemm", default="split3", choices=["split3", "f32"],
+    ap.add_argument("--gemm", default="split3", choices=["f16x2", "split3", "f32"],
                     help="split3 (default): the encoder GEMMs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, six "
                          "products, fp32 accumulate; acceptance table: profiles/r03_s3_acceptance.md); f32: the exact-f32 MFMA kernels")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -320,7 +320,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     _lib.load()
-    ops.set_gemm_split3(args.gemm == "split3")
+    ops.set_gemm_mode({"f16x2": "f16x2", "split3": "bf16x3", "f32": "f32"}[args.gemm])
 
     shape = synth.SHAPES[args.shape]
     model = build_model(shape, device)

@@ -29,7 +29,7 @@ extern "C" {
 #define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
 #define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
 
-#define R4D_ABI_VERSION 4
+#define R4D_ABI_VERSION 5
 
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
@@ -85,6 +85,12 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * loading the gain / shift or forming c1 / c2 per launch; NULL = it forms them from ln_1 / ln_2 and *_wT as before. */
     const float* c_attn_wTg;    const float* c_attn_lnc;
     const float* c_fc_wTg;      const float* c_fc_lnc;
+    /* OPTIONAL f16x2 planes of the four weights (ABI v5; r4d_split2_planes_f16: uint16 [2][out][in], hi and 2^11-scaled lo
+     * as fp16), made once per checkpoint; NULL = not provided.  With them and r4d_set_gemm_split3(2) the four Conv1D GEMMs of a
+     * block run on the fp16 matrix cores with THREE products per fp32 product at fp32 accuracy (r4d_conv1d_h2_f32; csrc/gemm_h2.hip
+     * for the error analysis and the operand range: |activation| < 2^18, |weight| < 6e4). */
+    const uint16_t* c_attn_h2;  const uint16_t* attn_proj_h2;
+    const uint16_t* c_fc_h2;    const uint16_t* mlp_proj_h2;
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {
@@ -244,8 +250,24 @@ int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d /* opt
 int r4d_split3_planes_bf16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream);
 int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d,
                       int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
-/* 1 (default): the encoder / training-forward GEMMs use the bf16x3 kernel where a layer carries its planes; 0: exact-f32 MFMA
- * kernels everywhere (the planes are ignored).  Process-wide, not thread-safe against concurrent calls. */
+/*
+ * The same Conv1D on the FP16 matrix cores at fp32 accuracy with THREE products per fp32 product ("f16x2", ABI v5;
+ * csrc/gemm_h2.hip): x = hi + 2^-11 lo' with hi = RN16(x), lo' = RN16((x - hi) 2^11) (the second term stays a normal fp16
+ * number over the whole range), a.b = hi.hi + 2^-11 (lo'.hi + hi.lo') in two fp32 accumulator sets joined once; half the
+ * matrix-pipe cycles of bf16x3 at an error against float64 no larger than bf16x3's or the exact-f32 MFMA's (acceptance table
+ * in profiles/).  Operand range: |x| < 2^18 for the activation (pre-scaled by 2^-2 inside the kernel; full precision for elements >= 2.4e-4,
+ * an absolute floor of 6e-11 below), |w| < 6e4 for the
+ * weight; beyond it the result is inf / NaN, not a silently wrong number.
+ * r4d_split2_planes_f16: w_d fp32 [K,N] (transposed != 0: [N,K]) -> planes_d fp16 [2][N][K] (4 * N * K bytes), once per checkpoint.
+ * r4d_conv1d_h2_f32: y = epilogue(x[M,K] @ W + bias), K % 32 == 0; epilogue as r4d_conv1d_f32.
+ */
+int r4d_split2_planes_f16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream);
+int r4d_conv1d_h2_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d,
+                      int32_t M, int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream);
+/* Conv1D arithmetic of the encoder / training-forward GEMMs.  1 (default): bf16x3 where a layer carries its planes; 2: f16x2
+ * where it carries those planes (bf16x3 where it only has the bf16 ones; the training GEMMs stay bf16x3); 0: exact-f32 MFMA
+ * kernels everywhere (planes ignored).  PROCESS-WIDE (one process drives one device; ranks of a sharded job must agree, or the
+ * merged shards differ from the one-GPU result in the last bits), not thread-safe against concurrent calls. */
 /* Decode-only fold of a LayerNorm into the projection that reads it (ABI v4): wT_d [N,K] (k-contiguous weight), ln_w_d / ln_b_d [K]
  * -> wTg_d [N,K] = ln_w[k] * wT[n][k] and lnc_d [2][N] = (sum_k ln_w[k] wT[n][k], sum_k ln_b[k] wT[n][k]); the operands of
  * r4d_gpt2_layer's c_attn_wTg / c_attn_lnc (with ln_1) and c_fc_wTg / c_fc_lnc (with ln_2).  Once per checkpoint. */

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: tools/ A/B tuning only
 
-R4D_ABI_VERSION = 4
+R4D_ABI_VERSION = 5
 
 
 class R4DError(RuntimeError):
@@ -27,7 +27,8 @@ class GPT2LayerC(Structure):
                                          "c_attn_wT", "attn_proj_wT", "c_fc_wT", "mlp_proj_wT",
                                          "c_attn_w3", "attn_proj_w3", "c_fc_w3", "mlp_proj_w3",
                                          "c_attn_w3t", "attn_proj_w3t", "c_fc_w3t", "mlp_proj_w3t",
-                                         "c_attn_wTg", "c_attn_lnc", "c_fc_wTg", "c_fc_lnc")]
+                                         "c_attn_wTg", "c_attn_lnc", "c_fc_wTg", "c_fc_lnc",
+                                         "c_attn_h2", "attn_proj_h2", "c_fc_h2", "mlp_proj_h2")]
 
 
 class GreedyStateC(Structure):
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "r4d_conv1d_f32": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_split3_planes_bf16": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_conv1d_s3_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_split2_planes_f16": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "r4d_conv1d_h2_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_fold_layernorm_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "r4d_set_gemm_split3": (c_int32, [c_int32]),
     "r4d_get_gemm_split3": (c_int32, []),

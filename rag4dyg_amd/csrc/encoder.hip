@@ -15,14 +15,23 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int g_gemm_split3 = 1;                // r4d_set_gemm_split3
+int g_gemm_split3 = 1;                // r4d_set_gemm_split3: 0 exact f32, 1 bf16x3, 2 f16x2
 
 int conv1d(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K,
            int N, int epilogue, float* y, hipStream_t s, float* skinny_scratch, bool sk_counters_zeroed,
-           const unsigned short* w3) {
+           const unsigned short* w3, const unsigned short* w2h) {
     if (skinny_scratch && wT && gemm_skinny_supported(M, K, N))        // decode step: a weight stream, not a tiled GEMM
         return launch_gemm_skinny(x, wT, bias, resid, M, K, N, epilogue, y, skinny_scratch, s, nullptr, nullptr, 0.f,
                                   sk_counters_zeroed);
+    // f16x2 planes present and selected: fp16 matrix cores, three products per fp32 product, fp32 accuracy (gemm_h2.hip).
+    // NOT gated on M, like the bf16x3 branch below
+    if (w2h && g_gemm_split3 == 2 && epilogue <= EPI_RESIDUAL && gemm_h2_supported(M, K, N)) {
+        S3Args a;
+        memset(&a, 0, sizeof(a));
+        a.A = x; a.planes = w2h; a.C = y; a.bias = bias; a.resid = resid;
+        a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
+        return launch_gemm_h2(a, s);
+    }
     // bf16x3 planes present: bf16 matrix cores at fp32 accuracy.  NOT gated on M: a row's result must not depend on how many
     // other rows share the call (fused multi-batch encode == one call per batch, bit for bit)
     if (w3 && g_gemm_split3 && gemm_s3_supported(M, K, N)) {
@@ -139,14 +148,14 @@ extern "C" {
 
 int r4d_abi_version(void) { return R4D_ABI_VERSION; }
 int r4d_build_flags(void) {
-    return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4) | (dbgflag_s3() << 5);
+    return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4) | (dbgflag_s3() << 5) | (dbgflag_h2() << 6);
 }
 int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* ln_b_d, int32_t N, int32_t K, float* wTg_d,
                            float* lnc_d, void* stream) {
     return launch_fold_layernorm(wT_d, ln_w_d, ln_b_d, N, K, wTg_d, lnc_d, (hipStream_t)stream);
 }
 
-int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode != 0; return R4D_OK; }
+int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode == 2 ? 2 : (mode != 0); return R4D_OK; }
 int r4d_get_gemm_split3(void) { return g_gemm_split3; }
 int r4d_set_attention_fused(int32_t mode) {
     // mode 2: fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning); 1: fused (column-split there)
@@ -233,7 +242,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             return R4D_ERR_HIP;
         }
         float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2))) return rc;
         bool fused_done = false;
         if (g_attention_fused != 0) {                    // all batches of the call in ceil(n/16) fused launches
             fused_done = true;
@@ -258,10 +267,10 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
                 if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
             }
         }
-        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.attn_proj_w3))) return rc;
+        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.attn_proj_w3, L.attn_proj_h2))) return rc;
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
-        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s, nullptr, false, L.c_fc_w3))) return rc;
-        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.mlp_proj_w3))) return rc;
+        if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s, nullptr, false, L.c_fc_w3, L.c_fc_h2))) return rc;
+        if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.mlp_proj_w3, L.mlp_proj_h2))) return rc;
     }
     size_t part0 = 0;                                                   // scratch offset of the launch's first batch
     for (int g0 = 0; g0 < n_groups; g0 += ATT_MAXG) {

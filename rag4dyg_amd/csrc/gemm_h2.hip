@@ -1,0 +1,495 @@
+// "f16x2" GEMM: C[M,N] = epilogue(A[M,K] . W^T + bias) on the fp16 matrix cores at fp32 accuracy, THREE matrix instructions per
+// fp32 product (gemm_s3.hip's bf16x3 form needs six).
+//
+// Every fp32 operand x is written as  x = hi + 2^-11 lo' + e  with hi = RN16(x), lo' = RN16((x - hi) 2^11)  (fp16, round to
+// nearest even; x - hi is exact in fp32 and at most 2^-11 |x|, so (x - hi) 2^11 <= |x| never overflows and is a NORMAL fp16
+// number down to |x - hi| = 3e-8: the second term keeps its 11 significant bits over the whole range instead of sinking into
+// fp16's subnormals) and |e| <= 2^-22 |x|, 2^-24 |x| in the mean -- the unit roundoff of fp32 itself.  A product a.b is
+//     hi_a hi_b  +  2^-11 (lo'_a hi_b + hi_a lo'_b)          (dropped: 2^-22 lo'_a lo'_b <= 2^-22 |a b|)
+// evaluated as three v_mfma_f32_32x32x16_f16 with fp32 accumulators: the first term into one accumulator set, the two cross
+// terms (which carry the factor 2^11) into a SECOND set, joined once at the end as acc0 + 2^-11 acc1 (one rounding; the power
+// of two is exact).  fp16 x fp16 is exact in fp32, so the only roundings are the fp32 accumulations -- three per 16 products
+// here, six with bf16x3, eight with the exact-f32 instruction (v_mfma_f32_32x32x2_f32: one per 2 products): measured against
+// float64 (tools/s3_acceptance.py, profiles/r04_h2_acceptance.md) the error is no larger than either of them.
+// Range: fp16 tops out at 65504 and its normal numbers end at 6.1e-5.  Activations are pre-scaled by 2^-2 (exact; undone in the
+// epilogue): the A operand may reach 2^18 = 2.6e5 before hi overflows to inf (and the result to NaN: loud, not silent), and
+// every element of magnitude >= 2.4e-4 keeps the full two-term precision; below that hi is an fp16 subnormal and the element's
+// ABSOLUTE error stops shrinking at 6e-11 (2^-36 x 4) -- fp32's own roundoff for anything in the same dot product that is
+// larger than 1e-3.  A tensor whose rows are ALL smaller than that (tools/h2_check.py, "tiny 1e-4": error 1e-6 instead of
+// 3e-7) is outside the range this form is meant for; bf16x3 (gemm_s3.hip) has fp32's full exponent range.  The static weights
+// are checked when their planes are made (|w| < 6e4, ops.split2_planes) and keep the bf16x3 planes otherwise.
+//
+// Operands: A is the fp32 activation [M,K], split on the fly while its tile is staged; W is a STATIC weight, split once per
+// checkpoint into two k-contiguous fp16 planes [2][N][K] (r4d_split2_planes_f16).  Tile structure, LDS image (64-byte rows,
+// 16-byte chunk index XOR (row >> 2) & 3), buffer loads, register-staged pipeline and the pinned MFMA / DS / VMEM interleaving
+// are those of gemm_s3.hip with two planes per operand instead of three: a stage of the 128 x 256 tile is 48 KB, so THREE
+// stages fit (144 KB) where bf16x3 had room for two.
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+#ifndef H2_DBG
+#define H2_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_h2.hip H2_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 5 the epilogue, bit 6 the MFMAs
+#endif
+
+namespace r4d {
+
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+typedef float f32x4h __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+
+constexpr float H2_A_PRESCALE = 0.25f;        // 2^-2 on the activation operand (exact), undone in the epilogue
+constexpr float H2_A_UNSCALE = 4.0f;
+constexpr float H2_LO_SCALE = 2048.0f;        // 2^11 on the second term of BOTH operands
+constexpr float H2_LO_UNSCALE = 1.0f / 2048.0f;
+
+// two fp32 -> packed (hi, hi), (lo', lo') of x * PRE
+template <bool PRESCALE>
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+    f32x2h v = {x0, x1};
+    if (PRESCALE) v = v * H2_A_PRESCALE;
+    const f16x2h hh = __builtin_convertvector(v, f16x2h);            // v_cvt_pk_f16_f32: RNE
+    const f32x2h hf = __builtin_convertvector(hh, f32x2h);
+    const f32x2h r = (v - hf) * H2_LO_SCALE;                          // exact
+    const f16x2h ll = __builtin_convertvector(r, f16x2h);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+__device__ __forceinline__ f32x2h gelu_new_h2(f32x2h x) {            // the epilogue of gemm_s3.hip / gemm_f32_kc.hip, same instructions
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    const f32x2h a = x * x * k1 + k0;
+    const f32x2h w = x * a;
+    f32x2h e;
+    e.x = __builtin_amdgcn_exp2f(w.x); e.y = __builtin_amdgcn_exp2f(w.y);
+    e = e + 1.0f;
+    f32x2h r;
+    r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y);
+    return x * r;
+}
+__device__ __forceinline__ float gelu_new_h2_1(float x) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
+}
+
+struct H2Shape {
+    int M, N, K, lda, ldc, ldr;
+    int plane_bytes;          // N * K * 2: distance between the two fp16 planes of W
+};
+
+// ---------------------------------------------------------------------------------------------- weight planes
+// w element (n, k) at w[k * ld_k + n * ld_n]  (reference Conv1D layout [K,N]: ld_k = N, ld_n = 1; a [N,K] copy: 1, K)
+__global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restrict__ w, int N, int K, long long ld_k,
+                                                            long long ld_n, unsigned short* __restrict__ planes) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool n_fast = ld_n == 1;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n_fast ? n0 + tx : n0 + r, k = n_fast ? k0 + r : k0 + tx;
+        const float v = (n < N && k < K) ? w[(long long)k * ld_k + (long long)n * ld_n] : 0.f;
+        if (n_fast) tile[tx][r] = v; else tile[r][tx] = v;            // tile[n][k]
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {                                // write along k
+        const int n = n0 + r, k = k0 + tx;
+        if (n >= N || k >= K) continue;
+        unsigned h, l;
+        split2_pair<false>(tile[r][tx], 0.f, h, l);
+        const size_t o = (size_t)n * K + k, P = (size_t)N * K;
+        planes[o] = (unsigned short)(h & 0xffffu);
+        planes[P + o] = (unsigned short)(l & 0xffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the GEMM
+// BF32: the second operand is NOT pre-split -- Bp points at fp32 rows [N][K] that are split on the fly like A, without the
+// activation pre-scale (the normalised pool of the retrieval scoring GEMM: |x| <= 1)
+template <int BM, int BN, int WGM, int WGN, int EPI, bool BF32 = false>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kernel(
+    const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
+    const float* __restrict__ biasg, const float* __restrict__ residg, const H2Shape g) {
+    constexpr int BK = 32;
+    constexpr int NTHREADS = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int NIA = BM * 4 / NTHREADS, NIB = BN * 4 / NTHREADS;   // (row, 8-k chunk) items per thread
+    constexpr int A_PLANE = BM * 4, B_PLANE = BN * 4;                 // uint4 units (a row = 4 chunks of 16 bytes)
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    constexpr int NBUF = 3;                                           // LDS stages (48 KB each at 128 x 256)
+    static_assert(NIA >= 1 && NIB >= 1 && NIA <= 2 && NIB <= 2 && TM >= 1 && TN >= 1, "tile");
+    __shared__ u32x4h lds[NBUF * STAGE];
+
+    // XCD-aware grouped tile order (gemm_f32_kc.hip)
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (bid % per_group) % gsz, tile_n = (bid % per_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = g.K / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int a_off[NIA], b_off[NIB], a_dst[NIA], b_dst[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
+        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + c * 8) * 4;
+        a_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
+        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * (BF32 ? 4 : 2);
+        b_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Bp), 0, BF32 ? (int)((long long)g.N * g.K * 4) : 2 * g.plane_bytes, 0x00020000);
+
+    u32x4h ra[NIA][2], rb[NIB][2];                       // BF32: rb[..][0..1] = the 8 fp32 of the item; else the two planes' chunks
+#define H2_LOAD(KT)                                                                                \
+    {                                                                                              \
+        const int kt_ = min((KT), nkt - 1);                                                        \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
+            ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
+            ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
+            if (BF32) {                                                                            \
+                rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 4), 0); \
+                rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i] + 16, kt_ * (BK * 4), 0); \
+            } else {                                                                               \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                      \
+                    rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define H2_STORE(STG)                                                                              \
+    {                                                                                              \
+        u32x4h* sa_ = lds + (STG) * STAGE;                                                         \
+        u32x4h* sb_ = sa_ + 2 * A_PLANE;                                                           \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
+            u32x4h h_, l_;                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+                /* (cast the WHOLE vector: __builtin_bit_cast on an ext-vector element reads element 0) */ \
+                const f32x4h src_ = __builtin_bit_cast(f32x4h, ra[i][q >> 1]);                     \
+                unsigned hh_, ll_;                                                                 \
+                split2_pair<true>(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, ll_);             \
+                h_[q] = hh_; l_[q] = ll_;                                                          \
+            }                                                                                      \
+            sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = l_;                                      \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
+            if (BF32) {                                                                            \
+                u32x4h h_, l_;                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
+                    const f32x4h src_ = __builtin_bit_cast(f32x4h, rb[i][q >> 1]);                 \
+                    unsigned hh_, ll_;                                                             \
+                    split2_pair<false>(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, ll_);        \
+                    h_[q] = hh_; l_[q] = ll_;                                                      \
+                }                                                                                  \
+                sb_[b_dst[i]] = h_; sb_[B_PLANE + b_dst[i]] = l_;                                  \
+            } else {                                                                               \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[i][p]; \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    // fragment addresses: lane (li, lh), k-step s -> chunk 2s + lh of row li (+ 32 per tile)
+    const int fq = (li >> 2) & 3;
+    const int f_off0 = li * 4 + ((0 + lh) ^ fq), f_off1 = li * 4 + ((2 + lh) ^ fq);
+    const int fa_base = wm * WM * 4, fb_base = 2 * A_PLANE + wn * WN * 4;
+
+    f32x16h acc0[TM][TN], acc1[TM][TN];                  // hi.hi  /  the two cross terms (factor 2^11)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    // the W fragment goes in as the instruction's FIRST operand, the activation fragment as its second: the accumulator then
+    // holds C^T tiles -- lane = row m of C, registers = 16 columns n in four runs of four consecutive ones ((r & 3) + 8 (r >> 2) +
+    // 4 (lane >> 5)) -- and the epilogue stores 16 bytes per lane and instruction instead of 4 (a quarter of the store instructions:
+    // the epilogue of a K = 512 tile was a quarter of its time and store-ISSUE bound)
+#define H2_MFMA(ACC, A_, B_, I_, J_) \
+    if (!(H2_DBG & 64)) ACC[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8h, B_), __builtin_bit_cast(f16x8h, A_), ACC[I_][J_], 0, 0, 0); \
+    else { asm volatile("" :: "v"(A_), "v"(B_)); }
+    u32x4h fa[2][TM][2], fb[2][TN][2];                   // two fragment sets: the reads of k-step s+1 travel under the MFMAs of k-step s
+#define H2_FRAGS(SET, STG, S)                                                                      \
+    {                                                                                              \
+        const u32x4h* st_ = lds + (STG) * STAGE;                                                   \
+        const int fo_ = (S) ? f_off1 : f_off0;                                                     \
+        /* in the order the MFMAs want them: lo(A) . hi(B) first */                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = (H2_DBG & 1) ? dbg_frag : st_[fa_base + 1 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = (H2_DBG & 1) ? dbg_frag : st_[fb_base + 0 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = (H2_DBG & 1) ? dbg_frag : st_[fa_base + 0 * A_PLANE + i * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = (H2_DBG & 1) ? dbg_frag : st_[fb_base + 1 * B_PLANE + j * 128 + fo_]; \
+    }
+    /* consecutive MFMAs go to different accumulators; the two writes of one acc1 tile are TM TN instructions apart */
+#define H2_MFMAS(SET)                                                                              \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) H2_MFMA(acc1, fa[SET][i][1], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) H2_MFMA(acc0, fa[SET][i][0], fb[SET][j][0], i, j); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) H2_MFMA(acc1, fa[SET][i][0], fb[SET][j][1], i, j); \
+    }
+
+    u32x4h dbg_frag = {(unsigned)tid, 0x3c003c00u, 0x3c003c00u, (unsigned)lane};   // (ablation builds only)
+    if (H2_DBG & 1) asm volatile("" : "+v"(dbg_frag));
+    // prologue: k-tiles 0 and 1 into stages 0 and 1, k-tile 2 into the staging registers, k-step 0 of k-tile 0 into fragment set 0
+    H2_LOAD(0)
+    H2_STORE(0)
+    H2_LOAD(1)
+    H2_STORE(1)
+    H2_LOAD(2)
+    __syncthreads();
+    H2_FRAGS(0, 0, 0)
+
+    // Three LDS stages, ONE barrier per k-tile, every fragment read under MFMAs.  Iteration kt enters with fragment set 0 = k-step 0
+    // of stage CUR = kt % 3 and the staging registers = k-tile kt + 2 (requested during iteration kt - 1):
+    //   k-step 0's MFMAs with, between them, the reads of k-step 1 (set 1), the split of the staged A elements and the LDS stores
+    //   of k-tile kt + 2 into stage WR = (kt + 2) % 3 -- read last in iteration kt - 1, every wave is past that barrier;
+    //   k-step 1's MFMAs with the global loads of k-tile kt + 3 and the reads of k-step 0 of stage NXT = (kt + 1) % 3 (set 0
+    //   again) -- stored during iteration kt - 1, i.e. in front of the same barrier;
+    //   barrier.
+    constexpr int NMF = 3 * TM * TN, NFR = 2 * (TM + TN), NDW = 2 * (NIA + NIB), NVM = 2 * NIA + 2 * NIB;
+    static_assert(NMF >= NFR && NMF >= NVM && NMF >= NDW, "interleave");
+#define H2_ITER(CUR, NXT, WR)                                                                      \
+    {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(H2_DBG & 2)) H2_STORE(WR)                                                            \
+        H2_FRAGS(1, CUR, 1)                                                                        \
+        H2_MFMAS(0)                                                                                \
+        _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                     \
+            if (m_ >= NMF - NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(H2_DBG & 8)) H2_LOAD(kt + 3)                                                         \
+        H2_FRAGS(0, NXT, 0)                                                                        \
+        H2_MFMAS(1)                                                                                \
+        _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            if (m_ < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
+            if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(H2_DBG & 4)) __syncthreads();                                                        \
+    }
+    // (past the last k-tile the loads are clamped to it and the stores / reads touch stages nobody consumes: harmless, and the
+    //  loop body stays free of conditions)
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 3) {                                   // compile-time stages
+        H2_ITER(0, 1, 2)
+        { ++kt; H2_ITER(1, 2, 0) }
+        { ++kt; H2_ITER(2, 0, 1) }
+        kt -= 2;
+    }
+    if (kt < nkt) {                                                   // kt is a multiple of 3 here: one or two k-tiles left
+        H2_ITER(0, 1, 2)
+        if (kt + 1 < nkt) { ++kt; H2_ITER(1, 2, 0) }
+    }
+#undef H2_ITER
+#undef H2_FRAGS
+#undef H2_MFMAS
+#undef H2_MFMA
+#undef H2_STORE
+#undef H2_LOAD
+
+#if H2_DBG & 32
+    {   // ablation: no epilogue at all (one conditional store keeps the accumulators alive)
+        float ssum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ssum += acc0[i][j][r] + acc1[i][j][r];
+        if (ssum == 12345.678f) Cg[0] = ssum;
+        return;
+    }
+#endif
+    // epilogue.  Accumulator tile (i, j) holds C^T: this lane's row is m = m0 + wm WM + 32 i + (lane & 31), register r its column
+    // n = n0 + wn WN + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): four 16-byte runs.  value = (acc0 + 2^-11 acc1) * unscale
+    constexpr float UNS = BF32 ? 1.0f : H2_A_UNSCALE;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    float* __restrict__ C = Cg;
+    const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
+    if (interior) {
+        const int lane_c = ((wm * WM + li) * g.ldc + wn * WN + 4 * lh) * 4;
+        const int lane_r = ((wm * WM + li) * g.ldr + wn * WN + 4 * lh) * 4;
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Ag), 0,
+            EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4h bias4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bias4[q] = biasg ? *reinterpret_cast<const f32x4h*>(biasg + n0 + wn * WN + j * 32 + 8 * q + 4 * lh) : f32x4h{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4h res[4];
+                if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        res[q] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, lane_r, ((i * 32) * g.ldr + j * 32 + 8 * q) * 4, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4h b4 = bias4[q];
+                    float c0 = __builtin_fmaf(acc1[i][j][4 * q + 0], H2_LO_UNSCALE, acc0[i][j][4 * q + 0]) * UNS + b4.x;
+                    float c1 = __builtin_fmaf(acc1[i][j][4 * q + 1], H2_LO_UNSCALE, acc0[i][j][4 * q + 1]) * UNS + b4.y;
+                    float c2 = __builtin_fmaf(acc1[i][j][4 * q + 2], H2_LO_UNSCALE, acc0[i][j][4 * q + 2]) * UNS + b4.z;
+                    float c3 = __builtin_fmaf(acc1[i][j][4 * q + 3], H2_LO_UNSCALE, acc0[i][j][4 * q + 3]) * UNS + b4.w;
+                    // keep the four scalar: left to the vectoriser this became v_pk_fma_f32 with an SGPR-pair multiplier, whose HIGH half
+                    // came out wrong in lanes 12-15 of every 16 on gfx950 (ROCm 7.2; tools/h2_check.py caught it, wait states did not help)
+                    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                    f32x4h v = {c0, c1, c2, c3};
+                    if (EPI == EPI_GELU) {
+                        const f32x2h lo2 = gelu_new_h2(f32x2h{v.x, v.y}), hi2 = gelu_new_h2(f32x2h{v.z, v.w});
+                        v = f32x4h{lo2.x, lo2.y, hi2.x, hi2.y};
+                    } else if (EPI == EPI_RESIDUAL) {
+                        v = v + res[q];
+                    } else if (EPI == EPI_HALF_PLUS) {
+                        v = (v + 1.0f) / 2.0f;                                                       // train_retriever.py:438
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, v), c_rsrc, lane_c, ((i * 32) * g.ldc + j * 32 + 8 * q) * 4, 0);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                                   // edge tiles: clamped reads, guarded stores
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * WM + i * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = n0 + wn * WN + j * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                const int colc = min(col, g.N - 1);
+                float v = __builtin_fmaf(acc1[i][j][r], H2_LO_UNSCALE, acc0[i][j][r]) * UNS + (biasg ? biasg[colc] : 0.f);
+                if (EPI == EPI_GELU) v = gelu_new_h2_1(v);
+                else if (EPI == EPI_RESIDUAL) v += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
+                else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+                if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <int BM, int BN, int WGM, int WGN>
+static int launch_h2(const S3Args& a, int cls, hipStream_t stream) {
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
+    H2Shape sh;
+    sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.lda = a.lda; sh.ldc = a.ldc; sh.ldr = a.ldr; sh.plane_bytes = a.N * a.K * 2;
+#define H2_LAUNCH_(E)                                                                              \
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WGM, WGN, E>), dim3(tiles), dim3(64 * WGM * WGN), 0, stream, a.A, \
+                       a.planes, a.C, a.bias, a.resid, sh)
+    switch (a.epilogue) {
+        case EPI_NONE: H2_LAUNCH_(EPI_NONE); break;
+        case EPI_GELU: H2_LAUNCH_(EPI_GELU); break;
+        case EPI_RESIDUAL: H2_LAUNCH_(EPI_RESIDUAL); break;
+        default: set_error("gemm_h2: epilogue %d has no instantiation", a.epilogue); return R4D_ERR_INVALID;
+    }
+#undef H2_LAUNCH_
+    R4D_CHECK_LAUNCH("gemm_h2");
+    return R4D_OK;
+}
+
+bool gemm_h2_supported(int M, int K, int N) {
+    return M >= 1 && K >= 32 && K % 32 == 0 && N >= 1 && (long long)N * K * 4 < (1ll << 31) && (long long)M * K < (1ll << 29) &&
+           128ll * N < (1ll << 29);
+}
+
+int launch_gemm_h2(const S3Args& a, hipStream_t stream) {
+    R4D_REQUIRE(a.A && a.planes && a.C, "gemm_h2: null pointer");
+    R4D_REQUIRE(gemm_h2_supported(a.M, a.K, a.N), "gemm_h2: unsupported shape M=%d K=%d N=%d (K %% 32 == 0 wanted)", a.M, a.K, a.N);
+    R4D_REQUIRE(a.lda % 4 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_h2: alignment");
+    R4D_REQUIRE(a.epilogue != EPI_RESIDUAL || a.resid, "gemm_h2: the residual epilogue needs the second buffer");
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("R4D_GEMM_H2_TILE"); forced = e ? atoi(e) : -1; }
+    int t = forced;
+    if (t < 0 || t > 1) {                                             // fewest tile waves; the wide tile wins ties
+        const long long b0 = (long long)cdiv(a.M, 128) * cdiv(a.N, 256), b1 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        const double c0 = (double)((b0 + 255) / 256) * 128 * 256, c1 = (double)((b1 + 255) / 256) * 128 * 128 / 0.9;
+        t = c1 < c0 ? 1 : 0;
+    }
+    if (t == 0) { R4D_BRANCH(H2_128x256); return launch_h2<128, 256, 2, 4>(a, PK_GEMM_H2_128x256, stream); }
+    R4D_BRANCH(H2_128x128);
+    return launch_h2<128, 128, 2, 4>(a, PK_GEMM_H2_128x128, stream);
+}
+
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T) with BOTH operands fp32 and split on the fly (the retrieval scoring GEMM at Q > 64:
+// A = normalised queries, B = the normalised pool shard); epilogue EPI_NONE or EPI_HALF_PLUS
+bool gemm_h2_f32b_supported(int M, int K, int N) {
+    return gemm_h2_supported(M, K, N) && (long long)N * K * 4 < (1ll << 31);
+}
+int launch_gemm_h2_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream) {
+    R4D_REQUIRE(A && B && C && gemm_h2_f32b_supported(M, K, N), "gemm_h2_f32b: unsupported shape M=%d K=%d N=%d", M, K, N);
+    R4D_REQUIRE(lda % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_h2_f32b: alignment");
+    R4D_BRANCH(H2_F32B);
+    const int tiles = cdiv(M, 128) * cdiv(N, 256);
+    ProfScope prof(PK_GEMM_H2_128x256, 2.0 * (double)M * N * K, stream);
+    H2Shape sh;
+    sh.M = M; sh.N = N; sh.K = K; sh.lda = lda; sh.ldc = ldc; sh.ldr = ldc; sh.plane_bytes = 0;
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(B);
+    if (epilogue == EPI_HALF_PLUS)
+        hipLaunchKernelGGL((gemm_h2_kernel<128, 256, 2, 4, EPI_HALF_PLUS, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
+    else if (epilogue == EPI_NONE)
+        hipLaunchKernelGGL((gemm_h2_kernel<128, 256, 2, 4, EPI_NONE, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
+    else { set_error("gemm_h2_f32b: epilogue %d has no instantiation", epilogue); return R4D_ERR_INVALID; }
+    R4D_CHECK_LAUNCH("gemm_h2_f32b");
+    return R4D_OK;
+}
+
+int launch_split2_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s) {
+    R4D_REQUIRE(w && planes && N >= 1 && K >= 1, "split2_planes: bad arguments");
+    R4D_REQUIRE(ld_n == 1 || ld_k == 1, "split2_planes: one of the two strides must be 1");
+    hipLaunchKernelGGL(split2_planes_kernel, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(256), 0, s, w, N, K, ld_k, ld_n, planes);
+    R4D_CHECK_LAUNCH("split2_planes");
+    return R4D_OK;
+}
+
+int dbgflag_h2() { return H2_DBG != 0; }
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" {
+
+int r4d_split2_planes_f16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream) {
+    // transposed == 0: w_d is the reference Conv1D layout [K,N] (in, out); != 0: w_d is [N,K]
+    return launch_split2_planes(w_d, N, K, transposed ? 1 : N, transposed ? K : 1, planes_d, (hipStream_t)stream);
+}
+
+int r4d_conv1d_h2_f32(const float* x_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d, int32_t M,
+                      int32_t K, int32_t N, int32_t epilogue, float* y_d, void* stream) {
+    R4D_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv1d_h2: epilogue %d not in {0,1,2}", epilogue);
+    S3Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = x_d; a.planes = planes_d; a.C = y_d; a.bias = bias_d; a.resid = residual_d;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
+    return launch_gemm_h2(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -213,7 +213,7 @@ class GPT2Model(_PreTrained):
     # per-object caches and the back-link to an owning LM-head model: never copied or pickled (copy.deepcopy(model) -- the
     # reference's `best_model = copy.deepcopy(model)` -- and torch.save(model) go through __getstate__); an owner re-links
     # its own copy in _LMHeadBase.__setstate__
-    _TRANSIENT = ("_wt_cache", "_w3_cache", "_fold_cache", "_greedy_decoders", "_lm_head_weight")
+    _TRANSIENT = ("_wt_cache", "_w3_cache", "_h2_cache", "_fold_cache", "_greedy_decoders", "_lm_head_weight")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -243,6 +243,20 @@ class GPT2Model(_PreTrained):
             ent = (stamp, ops.split3_planes(w.detach()))
             cache[key] = ent
         return ent[1].data_ptr()
+
+    def _h2(self, w):
+        """f16x2 planes [2,out,in] of a static Conv1D weight (``ops.split2_planes``), cached like ``_wt``; None unless
+        ``ops.gemm_mode() == "f16x2"``, and for a weight outside the fp16 range or a shape without a kernel."""
+        if ops.gemm_mode() != "f16x2" or w.shape[0] % 32 != 0:
+            return None
+        cache = self.__dict__.setdefault("_h2_cache", {})
+        key = id(w)
+        ent = cache.get(key)
+        stamp = (w.data_ptr(), w._version, _RAW_WRITE_GENERATION[0])
+        if ent is None or ent[0] != stamp:
+            ent = (stamp, ops.split2_planes(w.detach()))
+            cache[key] = ent
+        return ent[1].data_ptr() if ent[1] is not None else None
 
     def _fold(self, w, ln):
         """Decode-only (pointer to gain-folded [out,in] copy, pointer to its [2,out] column constants) of a Conv1D weight that
@@ -279,6 +293,8 @@ class GPT2Model(_PreTrained):
                                         self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight),
                                         self._w3(blk.attn.c_attn.weight), self._w3(blk.attn.c_proj.weight),
                                         self._w3(blk.mlp.c_fc.weight), self._w3(blk.mlp.c_proj.weight))
+            layers[i].c_attn_h2, layers[i].attn_proj_h2 = self._h2(blk.attn.c_attn.weight), self._h2(blk.attn.c_proj.weight)
+            layers[i].c_fc_h2, layers[i].mlp_proj_h2 = self._h2(blk.mlp.c_fc.weight), self._h2(blk.mlp.c_proj.weight)
             if decode and FOLD_DECODE_LAYERNORM and cfg.n_embd in (512, 768):   # the cached decode step's LayerNorm-fused projections (ABI v4)
                 layers[i].c_attn_wTg, layers[i].c_attn_lnc = self._fold(blk.attn.c_attn.weight, blk.ln_1)
                 layers[i].c_fc_wTg, layers[i].c_fc_lnc = self._fold(blk.mlp.c_fc.weight, blk.ln_2)

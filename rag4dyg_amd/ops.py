@@ -59,23 +59,83 @@ def conv1d(x, w, bias, epilogue="none", residual=None, w_t=None):
     return y
 
 
-_SPLIT3 = None
+_GEMM_MODES = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+_GEMM_MODE = None
+DEFAULT_GEMM_MODE = "bf16x3"
+
+
+def gemm_mode():
+    """Arithmetic of the encoder's Conv1D GEMMs: ``"f16x2"`` -- fp16 matrix cores, two fp16 terms per operand,
+    three products per fp32 product; ``"bf16x3"`` -- bf16 matrix cores, three bf16 terms, six products; ``"f32"`` -- the
+    exact-f32 MFMA kernels.  All three at fp32 accuracy (error against float64 no larger than the exact-f32 kernel's).
+    Default ``DEFAULT_GEMM_MODE``; ``R4D_GEMM_MODE=f32|bf16x3|f16x2`` (or the older ``R4D_GEMM_SPLIT3=0`` for f32) and
+    :func:`set_gemm_mode` select another.  Process-wide: the ranks of a sharded job must agree."""
+    global _GEMM_MODE
+    if _GEMM_MODE is None:
+        import os
+        m = os.environ.get("R4D_GEMM_MODE")
+        if m is None:
+            m = "f32" if os.environ.get("R4D_GEMM_SPLIT3", "1") == "0" else DEFAULT_GEMM_MODE
+        set_gemm_mode(m)
+    return _GEMM_MODE
+
+
+def set_gemm_mode(mode):
+    global _GEMM_MODE
+    if mode not in _GEMM_MODES:
+        raise ValueError(f"gemm mode {mode!r}: one of {sorted(_GEMM_MODES)}")
+    _GEMM_MODE = mode
+    check(_lib.load().r4d_set_gemm_split3(_GEMM_MODES[mode]), "set_gemm_split3")
 
 
 def gemm_split3_enabled():
-    """True when the encoder GEMMs run on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, DESIGN.md 4);
-    default on, ``R4D_GEMM_SPLIT3=0`` or :func:`set_gemm_split3` select the exact-f32 MFMA kernels."""
-    global _SPLIT3
-    if _SPLIT3 is None:
-        import os
-        set_gemm_split3(os.environ.get("R4D_GEMM_SPLIT3", "1") != "0")
-    return _SPLIT3
+    """True unless the exact-f32 MFMA kernels are selected (``gemm_mode() != "f32"``): the bf16x3 planes are in use (also in
+    "f16x2" mode, for the training GEMMs and for layers without fp16 planes)."""
+    return gemm_mode() != "f32"
 
 
 def set_gemm_split3(on):
-    global _SPLIT3
-    _SPLIT3 = bool(on)
-    check(_lib.load().r4d_set_gemm_split3(int(_SPLIT3)), "set_gemm_split3")
+    """Older switch: True -> the default split mode ("bf16x3" unless the process selected "f16x2"), False -> "f32"."""
+    if not on:
+        set_gemm_mode("f32")
+    elif gemm_mode() == "f32":
+        import os
+        m = os.environ.get("R4D_GEMM_MODE", DEFAULT_GEMM_MODE)
+        set_gemm_mode(m if m != "f32" else DEFAULT_GEMM_MODE)
+
+
+H2_MAX_WEIGHT = 6.0e4          # fp16 tops out at 65504: a weight beyond this keeps the bf16x3 planes
+
+
+def split2_planes(w, transposed=False):
+    """Static Conv1D weight [K,N] (``transposed``: an [N,K] copy) -> its two k-contiguous fp16 planes (hi, 2^11-scaled lo), a
+    uint16 tensor [2,N,K] (fp16 bit patterns): the operand format of :func:`conv1d_h2`.  None when the weight exceeds the fp16
+    range (one host read of the tensor's maximum, once per checkpoint)."""
+    if transposed:
+        N, K = w.shape
+    else:
+        K, N = w.shape
+    amax = float(w.detach().abs().max())
+    if not (amax < H2_MAX_WEIGHT):
+        return None
+    planes = torch.empty(2, N, K, dtype=torch.int16, device=w.device)
+    check(_lib.load().r4d_split2_planes_f16(_dev(w, torch.float32, "w"), K, N, int(bool(transposed)), planes.data_ptr(),
+                                            _stream()), "split2_planes")
+    return planes
+
+
+def conv1d_h2(x, planes, bias, epilogue="none", residual=None):
+    """:func:`conv1d` on the fp16 matrix cores at fp32 accuracy (two fp16 terms per operand, three partial products, two fp32
+    accumulator sets); ``planes`` from :func:`split2_planes`.  |x| < 2^18."""
+    _, N, K = planes.shape
+    M = x.numel() // K
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
+    rp = _dev(residual, torch.float32, "residual") if residual is not None else None
+    bp = _dev(bias, torch.float32, "bias") if bias is not None else None
+    check(_lib.load().r4d_conv1d_h2_f32(_dev(x, torch.float32, "x"), _dev(planes, torch.int16, "planes"), bp, rp, M, K, N, epi,
+                                        y.data_ptr(), _stream()), "conv1d_h2")
+    return y
 
 
 def split3_planes(w, transposed=False):

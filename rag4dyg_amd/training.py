@@ -373,7 +373,7 @@ def training_step(args, model, trainer, optimizer, batch, all_query_time, micro_
         trainer.all_reduce_mean()
         optimizer.step(getattr(args, "max_grad_norm", 0.0))
         trainer.refresh_transposed()
-        for c in ("_wt_cache", "_w3_cache", "_fold_cache"):       # the inference path's derived weights are stale now (also
+        for c in ("_wt_cache", "_w3_cache", "_h2_cache", "_fold_cache"):       # the inference path's derived weights are stale now (also
             model.transformer.__dict__.pop(c, None)               # guarded by gpt2.note_raw_parameter_write in AdamW.step)
     if not sync:
         return dict(loss=loss, cl_loss=cl, aug_loss=au, stepped=stepped)

@@ -35,8 +35,9 @@ def child():
         r = torch.randn(M, N, device=dev, generator=g) if epi == "residual" else None
         wt = w.t().contiguous()
         planes = ops.split3_planes(w)
+        planes2 = ops.split2_planes(w)
         if os.environ.get("S3_TIME_ONLY"):                     # ablated builds (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): timing only
-            fn = lambda: ops.conv1d_s3(x, planes, b, epi, r)
+            fn = (lambda: ops.conv1d_h2(x, planes2, b, epi, r)) if os.environ.get("S3_BENCH_KIND") == "h2" else (lambda: ops.conv1d_s3(x, planes, b, epi, r))
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -58,7 +59,8 @@ def child():
         elif epi == "residual":
             ref = ref + r[:rows].double()
         out = {}
-        for name, fn in (("s3", lambda: ops.conv1d_s3(x, planes, b, epi, r)), ("f32", lambda: ops.conv1d(x, w, b, epi, r, wt))):
+        for name, fn in (("h2", lambda: ops.conv1d_h2(x, planes2, b, epi, r)), ("s3", lambda: ops.conv1d_s3(x, planes, b, epi, r)),
+                         ("f32", lambda: ops.conv1d(x, w, b, epi, r, wt))):
             y = fn()
             d = (y[:rows].double() - ref).abs()
             out[name + "_maxnorm"] = float(d.max() / ref.abs().max())
@@ -79,6 +81,8 @@ def child():
         if K <= 4096:                                          # the planes are an exact split: hi + mid + lo == w
             p = planes.view(torch.bfloat16).float()
             out["planes_exact"] = bool(torch.equal(p[0].double() + p[1].double() + p[2].double(), wt.double()))
+            p2 = planes2.view(torch.float16).double()
+            out["h2_planes_relerr"] = float(((p2[0] + p2[1] / 2048.0 - wt.double()).abs() / wt.double().abs().clamp_min(1e-30)).max())
         print(json.dumps({"tile": tile, "M": M, "K": K, "N": N, "epi": epi, **out}), flush=True)
 
 
