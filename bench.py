@@ -40,6 +40,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: dense bf16 matrix peak (the 2:1-sparsity figure is not used)
 # the bf16x3 GEMM spends SIX bf16 products per fp32 product: its ceiling in fp32-equivalent flop is the bf16 peak / 6
 PEAK_S3_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+# the f16x2 GEMM spends THREE fp16 products per fp32 product (same dense peak as bf16): fp16 peak / 3
+PEAK_H2_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)
+DTYPES = {"f16x2": "f32 (f16x2 operands: two fp16 terms, three products, f32 accumulate)",
+          "bf16x3": "f32 (bf16x3 operands, f32 accumulate)", "f32": "f32"}
 PEAK_HBM_GBS = 8000.0
 QB = 32                          # per_gpu_eval_batch_size, utils/args_parser_retriever.py:225
 
@@ -52,7 +56,7 @@ def build_model(shape, device):
 
 
 def mfma_peak(kernel):
-    return PEAK_S3_TFLOPS if kernel.startswith("gemm_s3") else PEAK_F32_MFMA_TFLOPS
+    return PEAK_H2_TFLOPS if kernel.startswith("gemm_h2") else PEAK_S3_TFLOPS if kernel.startswith("gemm_s3") else PEAK_F32_MFMA_TFLOPS
 
 
 def f_enc(shape, B, T):
@@ -130,7 +134,8 @@ def verify_one_gpu(kept, first_batches, last_out, model, q_batches, index, k):
     """N = 1, after the timed region: the LAST timed step's ranked top-k against the oracle's stable top-k of the same
     queries (the CPU baseline computes them anyway): fraction of rows whose whole list is identical and the largest ORACLE
     score gap at any mismatching position (tests/conftest.rank_mismatch_report semantics; pass = gap <= 2e-6); plus the two
-    device scoring paths against each other: the HBM-bound scan (32 queries per call) and the MFMA-bound GEMM (256 per call)."""
+    ways of batching the queries into scoring calls against each other (32 per call, all 256 in one call): ONE scoring arithmetic,
+    the same bits."""
     S = np.concatenate([kept[b][0] for b in first_batches]).astype(np.float64)
     ref_idx = np.concatenate([np.asarray(kept[b][1]) for b in first_batches]).astype(np.int64)
     got_idx = last_out[1].cpu().numpy()
@@ -152,8 +157,8 @@ def verify_one_gpu(kept, first_batches, last_out, model, q_batches, index, k):
             "max_oracle_score_gap_at_mismatch": gap, "pass": bool(gap <= 2e-6),
             "max_abs_score_err_vs_oracle": float(np.abs(got_val - ref_val).max()),
             "timed_step_equals_recomputation": bool(torch.equal(i_gemm, last_out[1]) and torch.equal(v_gemm, last_out[0])),
-            "scan_path_rows_identical_to_gemm_path": round(float((i_scan == i_gemm).all(dim=1).float().mean()), 4),
-            "scan_vs_gemm_max_abs_score_diff": scan_gap}
+            "rows_identical_across_query_batchings": round(float((i_scan == i_gemm).all(dim=1).float().mean()), 4),
+            "max_abs_score_diff_across_query_batchings": scan_gap}
 
 
 def verify_sharded(world, rank, device, index, last_out, model, q_batches, args, G, k, gather, elapsed_local):
@@ -266,6 +271,30 @@ def scan_q32(index, shape, k, device, reps=50):
                          "traffic": traffic}}
 
 
+def scan_q32_shard8(index, shape, k, device):
+    """N = 1 only: the north-star PARTITION on the one GPU the driver has.  The resident pool cut into the eight batch-aligned
+    shards an 8-GPU run would hold (``dist.shard_bounds``): the scan + top-k of shard 0 timed exactly like ``scan_q32`` (the
+    12,512-row size the north star's "40 % of the HBM roofline" is quoted for), and the eight per-shard top-k lists (each found
+    with its global offset) merged by the HIP merge and compared with the one-GPU top-k -- the data path of N = 8 minus the
+    all-gather."""
+    import types
+    from rag4dyg_amd.dist import shard_bounds
+    n = int(index.pool_hat.shape[0])
+    bounds = shard_bounds(n, 8)
+    s0, e0 = bounds[0]
+    out = scan_q32(types.SimpleNamespace(pool_hat=index.pool_hat[s0:e0], index_offset=index.index_offset + s0), shape, k, device)
+    q = ops.normalize_rows(torch.randn(QB, shape.n_embd, generator=torch.Generator().manual_seed(6)).to(device))
+    v1, i1, _ = ops.score_topk(q, index.pool_hat, k, index.index_offset)
+    cv, ci = [], []
+    for s_, e_ in bounds:
+        v_, i_, _ = ops.score_topk(q, index.pool_hat[s_:e_], k, index.index_offset + s_)
+        cv.append(v_); ci.append(i_)
+    mv, mi = ops.merge_topk(torch.stack(cv), torch.stack(ci))
+    out["shard_rows"] = [e_ - s_ for s_, e_ in bounds]
+    out["eight_shard_merge_equals_one_gpu"] = bool(torch.equal(mi, i1) and torch.equal(mv, v1))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,9 +310,11 @@ def main():
                          "as one fused launch sequence")
     ap.add_argument("--query-batches", type=int, default=256,
                     help="distinct synthetic query batches cycled over the steps (256 x 32 = the 8192 queries of SURVEY 8d)")
-    ap.add_argument("--gemm", default="split3", choices=["f16x2", "split3", "f32"],
-                    help="split3 (default): the encoder GEMMs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, six "
-                         "products, fp32 accumulate; acceptance table: profiles/r03_s3_acceptance.md); f32: the exact-f32 MFMA kernels")
+    ap.add_argument("--gemm", default="f16x2", choices=["f16x2", "split3", "f32"],
+                    help="arithmetic of the encoder's Conv1D GEMMs, all at fp32 accuracy (error against float64 no larger than the "
+                         "exact-f32 kernel's: profiles/r04_h2_acceptance.md).  f16x2 (default): fp16 matrix cores, two fp16 terms per "
+                         "operand, three products; split3: bf16 matrix cores, three bf16 terms, six products; f32: the exact-f32 MFMA "
+                         "kernels.  The line of a split mode carries the other modes' runs in extras (exact_f32, bf16x3)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (the metric's form): every rank encodes --batches-per-step batches per step; strong: the SAME "
                          "64 batches (2048 queries) per step split over the ranks, so total work is fixed as N grows")
@@ -463,7 +494,7 @@ def main():
         dom = max(prof, key=lambda n: prof[n]["ms"])
         v = prof[dom]
         traffic, util = None, None
-        sfx = "" if ops.gemm_split3_enabled() else "_f32"           # the exact-f32 run has its own PMC pass
+        sfx = {"f16x2": "_f16x2", "bf16x3": "", "f32": "_f32"}[ops.gemm_mode()]     # every arithmetic has its own PMC pass
         tf = os.path.join(REPO, "profiles", f"pmc_traffic_{args.shape}{sfx}.json")
         if not os.path.exists(tf):
             tf = os.path.join(REPO, "profiles", f"pmc_traffic{sfx}.json")
@@ -472,7 +503,7 @@ def main():
             meta = pmc.get("_workload", {})
             if (meta.get("shape") == args.shape and meta.get("batches_per_step") == G and meta.get("n_gpus", 1) == world
                     and meta.get("pool_rows_per_gpu") == P and meta.get("source_sha") == source_sha()
-                    and meta.get("gemm", "f32") == ("split3" if ops.gemm_split3_enabled() else "f32")):
+                    and meta.get("gemm", "f32") == {"f16x2": "f16x2", "bf16x3": "split3", "f32": "f32"}[ops.gemm_mode()]):
                 traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
                 util = pmc.get(dom, {}).get("mfma_pipe_util")
         if dom.startswith(("gemm", "attn")):
@@ -482,6 +513,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
                     "flop_per_launch": v["work"] / v["launches"]}
+            if dom.startswith("gemm_h2"):
+                roof["peak_note"] = ("fp32-equivalent flop; f16x2: three v_mfma_f32_32x32x16_f16 products per fp32 product, so the "
+                                     "ceiling is the dense fp16 MFMA peak (2500 TFLOP/s) / 3")
+                roof["x_exact_f32_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
             if dom.startswith("gemm_s3"):
                 roof["peak_note"] = ("fp32-equivalent flop; bf16x3: six v_mfma_f32_32x32x16_bf16 products per fp32 product, "
                                      "so the ceiling is the dense bf16 MFMA peak (2500 TFLOP/s) / 6")
@@ -502,20 +537,26 @@ def main():
     if not args.no_roofline:
         roofline, kernels = roofline_run()
 
-    # --- N = 1: the same timed region once more on the exact-f32 MFMA kernels (the line the bf16x3 headline is read against)
-    exact = None
-    if world == 1 and args.gemm == "split3" and not args.no_exact_f32:
-        ops.set_gemm_split3(False)
-        model.transformer.__dict__.pop("_w3_cache", None)
-        out_f, el_f, _ = timed_run()
-        roof_f, kern_f = roofline_run() if not args.no_roofline else (None, {})
-        same = (out_f[1] == out[1]).all(dim=1).float().mean()
-        exact = {"dtype": "f32", "value": round(QB * G * args.steps / el_f, 2), "unit": "query-seqs/s",
-                 "ms_per_step": round(1e3 * el_f / args.steps, 4), "roofline": roof_f,
-                 "dominant_kernel_share": kern_f.get(roof_f["kernel"], {}).get("share") if roof_f else None,
-                 "top10_rows_identical_to_split3": round(float(same), 4),
-                 "max_abs_score_diff_vs_split3": float((out_f[0] - out[0]).abs().max())}
-        ops.set_gemm_split3(True)
+    # --- N = 1: the same timed region once more on every OTHER arithmetic (the lines the headline is read against): the exact-f32
+    # MFMA kernels always, bf16x3 as well when the headline is f16x2
+    exact = other_s3 = None
+    if world == 1 and args.gemm != "f32" and not args.no_exact_f32:
+        head_mode = ops.gemm_mode()
+        for mode in (["bf16x3"] if args.gemm == "f16x2" else []) + ["f32"]:
+            ops.set_gemm_mode(mode)
+            out_f, el_f, _ = timed_run()
+            roof_f, kern_f = roofline_run() if not args.no_roofline else (None, {})
+            same = (out_f[1] == out[1]).all(dim=1).float().mean()
+            rec = {"dtype": DTYPES[mode], "value": round(QB * G * args.steps / el_f, 2), "unit": "query-seqs/s",
+                   "ms_per_step": round(1e3 * el_f / args.steps, 4), "roofline": roof_f,
+                   "dominant_kernel_share": kern_f.get(roof_f["kernel"], {}).get("share") if roof_f else None,
+                   "top10_rows_identical_to_headline": round(float(same), 4),
+                   "max_abs_score_diff_vs_headline": float((out_f[0] - out[0]).abs().max())}
+            if mode == "f32":
+                exact = rec
+            else:
+                other_s3 = rec
+        ops.set_gemm_mode(head_mode)
 
     # --- N > 1: correctness bit + load spread, outside the timed region (never allowed to lose the run)
     verify = None
@@ -524,9 +565,11 @@ def main():
             verify = verify_sharded(world, rank, device, index, out, model, q_batches, args, G, k, gather, elapsed_local)
         except Exception as e:                                       # noqa: BLE001
             verify = {"error": f"{type(e).__name__}: {e}"}
-    scan = None
+    scan = scan8 = None
     if rank == 0 and not args.no_roofline:
         scan = scan_q32(index, shape, k, device)
+        if world == 1 and int(index.pool_hat.shape[0]) >= 8 * 64:
+            scan8 = scan_q32_shard8(index, shape, k, device)
     # --- SURVEY 8d's second, "length-bucketed" run (N = 1): the SAME queries sorted by length before they are cut into
     # batches of 32, so a batch pads to similar lengths.  NOT parity-comparable with the reference (an embedding is a mean
     # over its batch's padded positions) and never the headline value: it shows what the reference's file-order batching costs.
@@ -577,7 +620,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32 (bf16x3 operands, f32 accumulate)" if args.gemm == "split3" else "f32", "data": "synthetic",
+            "dtype": DTYPES[ops.gemm_mode()], "data": "synthetic",
             "config": {"workload": f"{shape.name}-shape synthetic sequences, SimpleDyG GPT-2 L{shape.n_layer} H{shape.n_head} "
                                    f"d{shape.n_embd} V{shape.vocab} random-init fp32 weights and activations; per rank and step {G} reference query batches of {QB} "
                                    f"(each padded to its own batch max, mean T={np.mean(Ts):.0f}; one fused launch sequence) "
@@ -591,7 +634,7 @@ def main():
                                        "async, consumed one step later (3-stage pipeline)" if pipe is not None else "synchronous")},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "extras": {"source_sha": source_sha(), "gemm": args.gemm, "exact_f32": exact, "scan_q32": scan, "verify": verify,
+            "extras": {"source_sha": source_sha(), "gemm": args.gemm, "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "verify": verify,
                        "length_bucketed": bucketed,
                        "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),

@@ -44,7 +44,12 @@ def _compile(src, force, hdr_m):
 # atomic stores and consume with relaxed agent-scope loads: correct on gfx950 because hipcc lowers those to write-through /
 # L1-bypassing `sc1` memory instructions (MI355X_MICROARCH.md, inter-workgroup visibility).  A toolchain that stopped emitting
 # sc1 would corrupt top-k results and decode projections silently, so the build fails instead.
-HANDOFF_KERNELS = {"topk.hip": ("topk_chunk_kernelIfE", "topk_chunk_kernelIdE"), "gemm_skinny.hip": ("gemm_skinny16_kernelILi2ELi0E", "gemm_skinny16_kernelILi3ELi0E")}
+# kernel -> (publish stores, consume loads) its source has: topk publishes TWO arrays (values, indices) from two places (winners,
+# padding) and consumes both; the skinny GEMM publishes its partial tile in two places and consumes it in one.  EVERY one of them
+# must come out as an sc1 instruction -- "some sc1 somewhere in the kernel" let a toolchain pass that lowered only one of the two
+# arrays
+HANDOFF_KERNELS = {"topk.hip": {"topk_chunk_kernelIfE": (4, 2), "topk_chunk_kernelIdE": (4, 2)},
+                   "gemm_skinny.hip": {"gemm_skinny16_kernelILi2ELi0E": (2, 1), "gemm_skinny16_kernelILi3ELi0E": (2, 1)}}
 
 
 def check_handoff_lowering(src):
@@ -58,7 +63,7 @@ def check_handoff_lowering(src):
         if r.returncode != 0:
             raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
         text = open(asm).read()
-    for name in names:
+    for name, (want_st, want_ld) in names.items():
         m = re.search(r"^(_ZN3r4d\d+" + re.escape(name) + r"[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
         if not m:
             raise RuntimeError(f"hand-off check: kernel {name} not found in the assembly of {src}")
@@ -67,8 +72,8 @@ def check_handoff_lowering(src):
         loads_sc1 = [ln for ln in re.findall(r"global_load_dword(?:x2)? [^\n]*", body) if " sc1" in ln]
         stores_sc1 = [ln for ln in stores if " sc1" in ln]
         ticket = re.findall(r"global_atomic_add[^\n]*", body)
-        if not ticket or len(stores_sc1) < 2 or len(loads_sc1) < 1:
-            raise RuntimeError(f"hand-off check FAILED for {name}: {len(stores_sc1)} sc1 stores, {len(loads_sc1)} sc1 loads, "
+        if not ticket or len(stores_sc1) < want_st or len(loads_sc1) < want_ld:
+            raise RuntimeError(f"hand-off check FAILED for {name}: {len(stores_sc1)} sc1 stores (want {want_st}), {len(loads_sc1)} sc1 loads (want {want_ld}), "
                                f"{len(ticket)} ticket atomics -- the relaxed agent-scope publish / consume of {os.path.basename(src)} "
                                "is no longer lowered to write-through / L1-bypassing instructions; use release / acquire there")
 

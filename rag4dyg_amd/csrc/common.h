@@ -63,7 +63,7 @@ struct ProfScope {
     X(KC_128x128x16, "gemm_kc:128x128x16") X(KC_128x64x16, "gemm_kc:128x64x16") X(KC_64x64x32, "gemm_kc:64x64x32")       \
     X(KC_128x128x32, "tuning:gemm_kc:128x128x32") X(KC_ROWSPLIT, "gemm_kc:row-split (two launches)")                      \
     X(S3_128x256, "gemm_s3:128x256x32") X(S3_PERSISTENT, "gemm_s3:128x256x32 persistent (pipeline across tiles)") X(S3_128x128, "gemm_s3:128x128x32") X(S3_F32B, "gemm_s3:both operands split on the fly (scoring GEMM)") X(S3_TN, "gemm_s3tn:128x256x32 (weight gradients, transposing LDS reads)")      \
-    X(H2_128x256, "gemm_h2:128x256x32 (f16x2)") X(H2_128x128, "gemm_h2:128x128x32 (f16x2)") X(H2_F32B, "gemm_h2:both operands split on the fly (scoring GEMM)") \
+    X(H2_128x256, "gemm_h2:128x256x32 (f16x2)") X(H2_128x128, "gemm_h2:128x128x32 (f16x2)") \
     X(F32_128x128, "gemm_f32:128x128") X(F32_128x64, "gemm_f32:128x64") X(F32_64x64, "gemm_f32:64x64")                   \
     X(F32_NT, "gemm_f32:B as [N,K]") X(F32_NN, "gemm_f32:B as [K,N]") X(TN_SPLITK, "gemm_tn:split-K") X(TN_SINGLE, "gemm_tn:one slice") \
     X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_LN_FOLDED, "skinny16:LayerNorm pre-folded into the weight") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
@@ -151,8 +151,6 @@ int launch_gemm_s3_f32b(const float* A, const float* B, float* C, int M, int N, 
 // gemm_h2.hip: the same contract on the fp16 matrix cores, two fp16 terms per operand and THREE products (planes [2][N][K])
 bool gemm_h2_supported(int M, int K, int N);
 int launch_gemm_h2(const S3Args& a, hipStream_t stream);
-bool gemm_h2_f32b_supported(int M, int K, int N);
-int launch_gemm_h2_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream);
 int launch_split2_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s);
 extern int g_gemm_split3;             // Conv1D arithmetic (r4d_set_gemm_split3): 0 exact-f32 MFMA, 1 bf16x3 planes, 2 f16x2 planes (bf16x3 where a layer carries no f16 planes)
 // Conv1D dispatch shared by the encoder and the training forward (encoder.hip): skinny weight stream (decode), bf16x3 planes,

@@ -218,12 +218,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    // the W fragment goes in as the instruction's FIRST operand, the activation fragment as its second: the accumulator then
-    // holds C^T tiles -- lane = row m of C, registers = 16 columns n in four runs of four consecutive ones ((r & 3) + 8 (r >> 2) +
-    // 4 (lane >> 5)) -- and the epilogue stores 16 bytes per lane and instruction instead of 4 (a quarter of the store instructions:
-    // the epilogue of a K = 512 tile was a quarter of its time and store-ISSUE bound)
 #define H2_MFMA(ACC, A_, B_, I_, J_) \
-    if (!(H2_DBG & 64)) ACC[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8h, B_), __builtin_bit_cast(f16x8h, A_), ACC[I_][J_], 0, 0, 0); \
+    if (!(H2_DBG & 64)) ACC[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8h, A_), __builtin_bit_cast(f16x8h, B_), ACC[I_][J_], 0, 0, 0); \
     else { asm volatile("" :: "v"(A_), "v"(B_)); }
     u32x4h fa[2][TM][2], fb[2][TN][2];                   // two fragment sets: the reads of k-step s+1 travel under the MFMAs of k-step s
 #define H2_FRAGS(SET, STG, S)                                                                      \
@@ -321,16 +317,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
         return;
     }
 #endif
-    // epilogue.  Accumulator tile (i, j) holds C^T: this lane's row is m = m0 + wm WM + 32 i + (lane & 31), register r its column
-    // n = n0 + wn WN + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): four 16-byte runs.  value = (acc0 + 2^-11 acc1) * unscale
+    // epilogue: gemm_s3.hip's (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), instruction for instruction, on
+    // value = (acc0 + 2^-11 acc1) * unscale.  A form with the operands of the MFMA swapped -- the accumulator then holds C^T and a
+    // lane stores 16 bytes per instruction, a quarter of the store instructions -- was built in round 4 and REMOVED: no faster
+    // (c_attn 442 vs 430 us) and its GELU variant gave run-to-run different values in lanes 12-15 / 28-31 of each half-wave at some
+    // shapes (scalar or packed arithmetic, with or without wait states; tools/h2_check.py now repeats every launch three times).
     constexpr float UNS = BF32 ? 1.0f : H2_A_UNSCALE;
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_sched_barrier(0);
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
     if (interior) {
-        const int lane_c = ((wm * WM + li) * g.ldc + wn * WN + 4 * lh) * 4;
-        const int lane_r = ((wm * WM + li) * g.ldr + wn * WN + 4 * lh) * 4;
+        const int lane_c = ((wm * WM + 4 * lh) * g.ldc + wn * WN + li) * 4;
+        const int lane_r = ((wm * WM + 4 * lh) * g.ldr + wn * WN + li) * 4;
         const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             C + (long long)m0 * g.ldc + n0, 0, ((BM - 1) * g.ldc + BN) * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -338,38 +335,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
             EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            f32x4h bias4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                bias4[q] = biasg ? *reinterpret_cast<const f32x4h*>(biasg + n0 + wn * WN + j * 32 + 8 * q + 4 * lh) : f32x4h{0.f, 0.f, 0.f, 0.f};
+            const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                f32x4h res[4];
+                float res[16];
                 if (EPI == EPI_RESIDUAL) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        res[q] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, lane_r, ((i * 32) * g.ldr + j * 32 + 8 * q) * 4, 0));
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4h b4 = bias4[q];
-                    float c0 = __builtin_fmaf(acc1[i][j][4 * q + 0], H2_LO_UNSCALE, acc0[i][j][4 * q + 0]) * UNS + b4.x;
-                    float c1 = __builtin_fmaf(acc1[i][j][4 * q + 1], H2_LO_UNSCALE, acc0[i][j][4 * q + 1]) * UNS + b4.y;
-                    float c2 = __builtin_fmaf(acc1[i][j][4 * q + 2], H2_LO_UNSCALE, acc0[i][j][4 * q + 2]) * UNS + b4.z;
-                    float c3 = __builtin_fmaf(acc1[i][j][4 * q + 3], H2_LO_UNSCALE, acc0[i][j][4 * q + 3]) * UNS + b4.w;
-                    // keep the four scalar: left to the vectoriser this became v_pk_fma_f32 with an SGPR-pair multiplier, whose HIGH half
-                    // came out wrong in lanes 12-15 of every 16 on gfx950 (ROCm 7.2; tools/h2_check.py caught it, wait states did not help)
-                    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-                    f32x4h v = {c0, c1, c2, c3};
-                    if (EPI == EPI_GELU) {
-                        const f32x2h lo2 = gelu_new_h2(f32x2h{v.x, v.y}), hi2 = gelu_new_h2(f32x2h{v.z, v.w});
-                        v = f32x4h{lo2.x, lo2.y, hi2.x, hi2.y};
-                    } else if (EPI == EPI_RESIDUAL) {
-                        v = v + res[q];
-                    } else if (EPI == EPI_HALF_PLUS) {
-                        v = (v + 1.0f) / 2.0f;                                                       // train_retriever.py:438
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    f32x2h v2 = {__builtin_fmaf(acc1[i][j][r2], H2_LO_UNSCALE, acc0[i][j][r2]) * UNS + bias,
+                                 __builtin_fmaf(acc1[i][j][r2 + 1], H2_LO_UNSCALE, acc0[i][j][r2 + 1]) * UNS + bias};
+                    if (EPI == EPI_GELU) v2 = gelu_new_h2(v2);
+                    else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
+                    else if (EPI == EPI_HALF_PLUS) { v2.x = (v2.x + 1.0f) / 2.0f; v2.y = (v2.y + 1.0f) / 2.0f; }     // train_retriever.py:438
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = r2 + h2;
+                        const float v = h2 ? v2.y : v2.x;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
+                                                              ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, v), c_rsrc, lane_c, ((i * 32) * g.ldc + j * 32 + 8 * q) * 4, 0);
                 }
             }
         }
@@ -377,18 +366,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {                                   // edge tiles: clamped reads, guarded stores
+        const int col = n0 + wn * WN + j * 32 + li;
+        const bool col_ok = col < g.N;
+        const int colc = min(col, g.N - 1);
+        const float bias = biasg ? biasg[colc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * WM + i * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int col = n0 + wn * WN + j * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                const int colc = min(col, g.N - 1);
-                float v = __builtin_fmaf(acc1[i][j][r], H2_LO_UNSCALE, acc0[i][j][r]) * UNS + (biasg ? biasg[colc] : 0.f);
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = __builtin_fmaf(acc1[i][j][r], H2_LO_UNSCALE, acc0[i][j][r]) * UNS + bias;
                 if (EPI == EPI_GELU) v = gelu_new_h2_1(v);
                 else if (EPI == EPI_RESIDUAL) v += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
                 else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
-                if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = v;
+                if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
         }
     }
@@ -436,29 +427,6 @@ int launch_gemm_h2(const S3Args& a, hipStream_t stream) {
     if (t == 0) { R4D_BRANCH(H2_128x256); return launch_h2<128, 256, 2, 4>(a, PK_GEMM_H2_128x256, stream); }
     R4D_BRANCH(H2_128x128);
     return launch_h2<128, 128, 2, 4>(a, PK_GEMM_H2_128x128, stream);
-}
-
-// C[M,N] = epilogue(A[M,K] . B[N,K]^T) with BOTH operands fp32 and split on the fly (the retrieval scoring GEMM at Q > 64:
-// A = normalised queries, B = the normalised pool shard); epilogue EPI_NONE or EPI_HALF_PLUS
-bool gemm_h2_f32b_supported(int M, int K, int N) {
-    return gemm_h2_supported(M, K, N) && (long long)N * K * 4 < (1ll << 31);
-}
-int launch_gemm_h2_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream) {
-    R4D_REQUIRE(A && B && C && gemm_h2_f32b_supported(M, K, N), "gemm_h2_f32b: unsupported shape M=%d K=%d N=%d", M, K, N);
-    R4D_REQUIRE(lda % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_h2_f32b: alignment");
-    R4D_BRANCH(H2_F32B);
-    const int tiles = cdiv(M, 128) * cdiv(N, 256);
-    ProfScope prof(PK_GEMM_H2_128x256, 2.0 * (double)M * N * K, stream);
-    H2Shape sh;
-    sh.M = M; sh.N = N; sh.K = K; sh.lda = lda; sh.ldc = ldc; sh.ldr = ldc; sh.plane_bytes = 0;
-    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(B);
-    if (epilogue == EPI_HALF_PLUS)
-        hipLaunchKernelGGL((gemm_h2_kernel<128, 256, 2, 4, EPI_HALF_PLUS, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
-    else if (epilogue == EPI_NONE)
-        hipLaunchKernelGGL((gemm_h2_kernel<128, 256, 2, 4, EPI_NONE, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
-    else { set_error("gemm_h2_f32b: epilogue %d has no instantiation", epilogue); return R4D_ERR_INVALID; }
-    R4D_CHECK_LAUNCH("gemm_h2_f32b");
-    return R4D_OK;
 }
 
 int launch_split2_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s) {

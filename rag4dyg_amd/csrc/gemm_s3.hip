@@ -742,7 +742,18 @@ static int s3_launch_tile(const S3Args& a, int t, hipStream_t stream) {
     // with the RESIDUAL epilogue the persistent form is SLOWER (K 512 N 512: 189 -> 227 us, K 2048 N 512: 625 -> 700 us, static and
     // dynamic tile hand-out alike), so those launches keep one launch slot per tile (pers == 2 forces it for them too)
     const bool loads_in_epilogue = a.epilogue == EPI_RESIDUAL || a.epilogue == EPI_GELU_GRAD;     // (GELU_GRAD: 57.6 vs 57.9 ms per training step)
-    if (t == 0 && pers && (pers == 2 || !loads_in_epilogue) && (a.K / 32) % 2 == 0 && cdiv(a.M, 128) * cdiv(a.N, 256) > 256) {
+    // The persistent form draws its tiles from ticket counters in one of 64 process-wide slots, chosen round-robin at LAUNCH time
+    // (g_s3p_slots): two launches must never share a slot while both run.  Eager launches on up to 64 streams cannot (a slot comes
+    // round again only after 63 later launches have been issued behind it); a launch CAPTURED into a graph would bake its slot in
+    // and could be replayed beside an eager launch that drew the same one -- both would skip tiles, silently -- so a
+    // capturing stream takes the one-workgroup-per-tile form, which keeps no state.
+    bool capturing = false;
+    if (t == 0 && pers) {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cst) != hipSuccess) { (void)hipGetLastError(); cst = hipStreamCaptureStatusNone; }
+        capturing = cst != hipStreamCaptureStatusNone;
+    }
+    if (t == 0 && pers && !capturing && (pers == 2 || !loads_in_epilogue) && (a.K / 32) % 2 == 0 && cdiv(a.M, 128) * cdiv(a.N, 256) > 256) {
         R4D_BRANCH(S3_PERSISTENT);
         return launch_s3p(a, stream);
     }

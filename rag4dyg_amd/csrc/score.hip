@@ -902,7 +902,15 @@ int r4d_score_topk_f32(const float* q_hat_d, const float* pool_hat_d, int32_t Q,
     char* ws = (char*)workspace_d + skip;                                        // starts with the top-k ticket counters
     int rc = 1;
     bool zeroed = false;
-    if (Q <= 64) {                                                               // HBM-bound regime: stream the pool once
+    // ONE scoring arithmetic: whenever d has a scan variant EVERY call goes through the scan kernels, 32 queries
+    // per block of grid.y -- a (query, pool row) score is its own fixed chain of products and sums, independent of which block or
+    // call the query sits in, so scores and top-k do not depend on how queries are batched into calls (Q = 1, 32, 33, 65, 256:
+    // tests/test_gpu_ops.py).  Beyond one block the pool is re-read from the Infinity Cache / L2, once per block; the tiled GEMM
+    // below (another summation order: 2 of 256 top-10 lists differed inside the 2e-6 band) serves the other d only --
+    // R4D_SCORE_GEMM=1 restores it for Q > 64 (tuning aid).
+    static int gemm_route = -1;
+    if (gemm_route < 0) { const char* e = getenv("R4D_SCORE_GEMM"); gemm_route = e ? atoi(e) : 0; }
+    if (Q <= 64 || !gemm_route) {
         rc = launch_pool_scan(q_hat_d, pool_hat_d, Q, N, d, scores, (unsigned*)ws, Q, s);
         zeroed = rc == R4D_OK;
     }

@@ -92,7 +92,7 @@ static TrainLayout layout(const r4d_gpt2_config* cfg, const TrainGroup* gs, int 
     const size_t cs = colsum_scratch_floats((long long)t.M, 4 * t.d);
     if (cs > red) red = cs;
     t.red = take(red);
-    t.emb_acc = take((size_t)cfg->vocab * d * 2);
+    t.emb_acc = take((size_t)cfg->vocab * d * 2 + 2);   // + one 64-bit poison word behind the table
     t.total = off;
     return t;
 }
@@ -424,7 +424,7 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
         return rc;
     // deterministic sums (train_ops.hip): tokens through a 64-bit fixed-point table, positions as ordered column sums
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + t.emb_acc);
-    R4D_HIP(hipMemsetAsync(acc, 0, (size_t)cfg->vocab * d * sizeof(unsigned long long), s));
+    R4D_HIP(hipMemsetAsync(acc, 0, ((size_t)cfg->vocab * d + 1) * sizeof(unsigned long long), s));       // table + poison word
     R4D_HIP(hipMemsetAsync(gr->wpe, 0, (size_t)cfg->n_positions * d * sizeof(float), s));
     for (const TrainGroup& G : gs)
         if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, G.B, G.T, d, cfg->vocab, acc, gr->wpe, 0, s))) return rc;

@@ -218,7 +218,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 //   * dwte: which rows share a token is data dependent, so the contributions are added as 64-bit FIXED-POINT integers
 //     (value * 2^44, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
 //     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 5.7e-14, range +-5.2e5.
+//     A NON-FINITE contribution, or one beyond +-2^17 (no sum of 2^3 .. 2^5 such terms can wrap the 64 bits unnoticed), has
+//     no fixed-point image: it sets the POISON word behind the table and the conversion then writes NaN into the whole
+//     gradient -- a diverged step stays as loud as with float atomics (NaN gradient norm, NaN parameters after the clip)
+//     instead of turning into a finite, wrong update.  Contributions below 1e-10 lose relative precision (the
+//     resolution is absolute); the training configurations of the reference's scripts sit eight orders above that.
 constexpr double EMB_FIX = 17592186044416.0;            // 2^44
+constexpr float EMB_MAX_ABS = 131072.0f;                // 2^17
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                                             long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -226,10 +232,14 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const long long id = ids[row];
     if (id < 0 || id >= vocab) return;
+    bool poison = false;
     for (int c = lane; c < d; c += 64) {
-        const long long q = __double2ll_rn((double)dx[row * d + c] * EMB_FIX);
+        const float g = dx[row * d + c];
+        if (!(fabsf(g) <= EMB_MAX_ABS)) { poison = true; continue; }              // NaN, Inf or out of range
+        const long long q = __double2ll_rn((double)g * EMB_FIX);
         atomicAdd(acc_wte + id * d + c, (unsigned long long)q);
     }
+    if (__ballot(poison) != 0ull && lane == 0) atomicOr(acc_wte + (long long)vocab * d, 1ull);
 }
 // dwpe[t, c] (+)= sum over the B sequences of dx[b * T + t, c], b ascending; `first`: overwrite instead of add
 __global__ __launch_bounds__(256) void wpe_bwd_kernel(const float* __restrict__ dx, int B, int T, int d, int first, float* __restrict__ dwpe) {
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void wpe_bwd_kernel(const float* __restrict__ 
 }
 __global__ __launch_bounds__(256) void embedding_fix_to_f32_kernel(const unsigned long long* __restrict__ acc, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / EMB_FIX));
+    if (i < n) out[i] = acc[n] ? __builtin_nanf("") : (float)((double)(long long)acc[i] * (1.0 / EMB_FIX));     // acc[n]: the poison word
 }
 
 // dh[row, :] = d_pool[seq(row), :] / T   (torch.mean(h, dim=1) backward, train_retriever.py:181-183)

@@ -285,16 +285,16 @@ class GPT2Model(_PreTrained):
                                     "(call model.to('cuda'); there is no CPU fallback)")
             return t.data_ptr()
         for i, blk in enumerate(self.h):
+            ws4 = (blk.attn.c_attn.weight, blk.attn.c_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight)
+            h2 = [self._h2(w) for w in ws4]                                       # f16x2 mode only (None otherwise / out of fp16 range)
+            w3 = [self._w3(w) if h is None else None for w, h in zip(ws4, h2)]    # bf16x3 planes: that mode, or the f16x2 fallback
             layers[i] = _lib.GPT2LayerC(p(blk.ln_1.weight), p(blk.ln_1.bias), p(blk.attn.c_attn.weight),
                                         p(blk.attn.c_attn.bias), p(blk.attn.c_proj.weight), p(blk.attn.c_proj.bias),
                                         p(blk.ln_2.weight), p(blk.ln_2.bias), p(blk.mlp.c_fc.weight),
                                         p(blk.mlp.c_fc.bias), p(blk.mlp.c_proj.weight), p(blk.mlp.c_proj.bias),
                                         self._wt(blk.attn.c_attn.weight), self._wt(blk.attn.c_proj.weight),
-                                        self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight),
-                                        self._w3(blk.attn.c_attn.weight), self._w3(blk.attn.c_proj.weight),
-                                        self._w3(blk.mlp.c_fc.weight), self._w3(blk.mlp.c_proj.weight))
-            layers[i].c_attn_h2, layers[i].attn_proj_h2 = self._h2(blk.attn.c_attn.weight), self._h2(blk.attn.c_proj.weight)
-            layers[i].c_fc_h2, layers[i].mlp_proj_h2 = self._h2(blk.mlp.c_fc.weight), self._h2(blk.mlp.c_proj.weight)
+                                        self._wt(blk.mlp.c_fc.weight), self._wt(blk.mlp.c_proj.weight), *w3)
+            layers[i].c_attn_h2, layers[i].attn_proj_h2, layers[i].c_fc_h2, layers[i].mlp_proj_h2 = h2
             if decode and FOLD_DECODE_LAYERNORM and cfg.n_embd in (512, 768):   # the cached decode step's LayerNorm-fused projections (ABI v4)
                 layers[i].c_attn_wTg, layers[i].c_attn_lnc = self._fold(blk.attn.c_attn.weight, blk.ln_1)
                 layers[i].c_fc_wTg, layers[i].c_fc_lnc = self._fold(blk.mlp.c_fc.weight, blk.ln_2)

@@ -61,7 +61,7 @@ def conv1d(x, w, bias, epilogue="none", residual=None, w_t=None):
 
 _GEMM_MODES = {"f32": 0, "bf16x3": 1, "f16x2": 2}
 _GEMM_MODE = None
-DEFAULT_GEMM_MODE = "bf16x3"
+DEFAULT_GEMM_MODE = "f16x2"
 
 
 def gemm_mode():

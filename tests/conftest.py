@@ -82,3 +82,17 @@ def load_state_dict_checked(model, sd):
     assert not unexpected, f"unexpected keys: {unexpected}"
     assert not bad, f"missing keys: {bad}"
     return model
+
+
+GEMM_MODES = ["f16x2", "bf16x3", "f32"]
+
+
+@pytest.fixture(params=GEMM_MODES)
+def gemm_mode(request):
+    """Every arithmetic of the encoder's Conv1D GEMMs (``ops.gemm_mode``): fp16 matrix cores / two terms / three products,
+    bf16 matrix cores / three terms / six products, exact-f32 MFMA.  Restores the process default afterwards."""
+    from rag4dyg_amd import ops
+    was = ops.gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(was)

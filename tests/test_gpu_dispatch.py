@@ -35,8 +35,8 @@ def test_every_dispatcher_branch_is_exercised(dev):
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
     lib = _lib.load()
     lib.r4d_dispatch_reset()
-    mode_before = ops.gemm_split3_enabled()                # the matrix below assumes the default (bf16x3) mode; restored at the end
-    ops.set_gemm_split3(True)
+    mode_before = ops.gemm_mode()                          # the matrix below assumes the bf16x3 mode; restored at the end
+    ops.set_gemm_mode("bf16x3")
     g = torch.Generator().manual_seed(7)
     rnd = lambda *s: torch.randn(*s, generator=g)
 
@@ -45,7 +45,9 @@ def test_every_dispatcher_branch_is_exercised(dev):
         x, w, b = rnd(M, K).to(dev), (rnd(K, N) * 0.05).to(dev), rnd(N).to(dev)
         rows = min(M, 256)
         ref = (x[:rows].double() @ w.double() + b.double()).cpu().numpy()
-        if planes:
+        if planes == "h2":
+            y = ops.conv1d_h2(x, ops.split2_planes(w), b)
+        elif planes:
             y = ops.conv1d_s3(x, ops.split3_planes(w), b)
         else:
             y = ops.conv1d(x, w, b, "none", None, w.t().contiguous() if wt else None)
@@ -58,6 +60,8 @@ def test_every_dispatcher_branch_is_exercised(dev):
     conv_check(4096, 512, 1536, wt=False, planes=True)       # gemm_s3 128 x 256
     conv_check(40000, 64, 1536, wt=False, planes=True)       # > 256 tiles, even k-tile count: the persistent form
     conv_check(4096, 512, 128, wt=False, planes=True)        # gemm_s3 128 x 128 (one column tile of 128)
+    conv_check(4096, 512, 1536, wt=False, planes="h2")       # gemm_h2 128 x 256
+    conv_check(4096, 512, 128, wt=False, planes="h2")        # gemm_h2 128 x 128
     h = rnd(9, 48).to(dev)                                    # B as [N,K] with K % 32 != 0: reference-layout kernel, NT form
     wte = rnd(50, 48).to(dev)
     assert rel_err(ops.lm_logits(h, wte).cpu().numpy(), (h.double() @ wte.double().t()).cpu().numpy()) < 2e-6
@@ -127,14 +131,15 @@ def test_every_dispatcher_branch_is_exercised(dev):
     scan(32, 12500, 512)         # short shard (<= 64 rows per CU): LDS-DMA staged form
     scan(32, 20000, 512)         # 65-96 rows per CU: even row ranges, two tiles in flight, register-staged
     scan(32, 40000, 768)         # long shard: round-robin tiles
-    ops.set_gemm_split3(False)   # the exact-f32 form of the scan (bench.py --gemm f32)
+    ops.set_gemm_mode("f32")     # the exact-f32 form of the scan (bench.py --gemm f32)
     try:
         scan(32, 12500, 512)
         scan(32, 700, 256)
     finally:
-        ops.set_gemm_split3(True)
-    scan(80, 3000, 512)          # Q > 64: tiled GEMM + (x+1)/2 epilogue
-    scan(7, 300, 96)             # no scan variant for d = 96: tiled GEMM
+        ops.set_gemm_mode("bf16x3")
+    scan(80, 3000, 512)          # Q > 64: the scan again, three blocks of 32 queries (one scoring arithmetic)
+    scan(7, 300, 96)             # no scan variant for d = 96: tiled GEMM, bf16x3 operands split on the fly
+    scan(7, 300, 80)             # ... and d % 32 != 0: the exact-f32 tiled GEMM
     for rows, n, k, dt in ((3, 900, 7, torch.float32), (2, 100000, 10, torch.float32), (2, 300000, 64, torch.float32),
                            (3, 5000, 10, torch.float64)):
         S = torch.rand(rows, n, generator=g, dtype=dt).to(dev)
@@ -157,7 +162,7 @@ def test_every_dispatcher_branch_is_exercised(dev):
         ref = np.array([[len(set(a) & set(b)) / len(set(a) | set(b)) if a and b else 0.0 for b in sets] for a in sets])
         assert np.array_equal(out, ref), vocab
 
-    ops.set_gemm_split3(mode_before)
+    ops.set_gemm_mode(mode_before)
     hits = branches()
     missed = sorted(n for n, c in hits.items() if c == 0 and not n.startswith("tuning:"))
     print("dispatcher branches exercised:", {n: c for n, c in hits.items() if c})

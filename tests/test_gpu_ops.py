@@ -62,6 +62,40 @@ def test_conv1d_all_epilogues(dev, M, K, N):
         assert rel_err(ops.conv1d(xd, wd, bd, "residual", rd, w_t=wt).cpu().numpy(), (ref + r).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(45, 96, 80), (4096, 512, 1536), (333, 2048, 512), (130, 64, 256), (1, 64, 64), (129, 32, 257), (1000, 768, 2304)])
+def test_conv1d_f16x2_all_epilogues_tiles_and_range(dev, M, K, N):
+    """``r4d_conv1d_h2_f32`` (csrc/gemm_h2.hip: fp16 matrix cores, two fp16 terms per operand, three products) against the
+    oracle at the exact-f32 kernels' bound, every epilogue, interior and edge tiles of both tile shapes, one and two k-tiles --
+    and its error against float64 beside the bf16x3 and exact-f32 kernels' on the same inputs: not larger (x 1.25 + 2e-8 for
+    the noise of a maximum), including activations of 3e4 and an outlier channel x 500."""
+    from rag4dyg_amd import ops
+    from oracle import gpt2_ref
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) * 0.05
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    ref = gpt2_ref.conv1d(x, w, b)
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    p2, p3 = ops.split2_planes(wd), ops.split3_planes(wd)
+    hi, lo = p2.view(torch.float16)[0].double(), p2.view(torch.float16)[1].double()
+    # the planes ARE the split: |w - (hi + 2^-11 lo')| <= 2^-22 |w|, with the absolute floor 2^-36 where hi is an fp16 subnormal (|w| < 6.1e-5)
+    assert ((hi + lo / 2048.0 - wd.t().double()).abs() <= 2.0 ** -22 * wd.t().double().abs() + 2.0 ** -36).all()
+    assert rel_err(ops.conv1d_h2(xd, p2, bd).cpu().numpy(), ref.numpy()) < 1e-5
+    yg = ops.conv1d_h2(xd, p2, bd, "gelu")
+    assert rel_err(yg.cpu().numpy(), gpt2_ref.gelu_new(ref).numpy()) < 1e-5
+    assert all(torch.equal(yg, ops.conv1d_h2(xd, p2, bd, "gelu")) for _ in range(3))      # run to run the same bits
+    assert rel_err(ops.conv1d_h2(xd, p2, bd, "residual", rd).cpu().numpy(), (ref + r).numpy()) < 1e-5
+    assert rel_err(ops.conv1d_h2(xd, p2, None).cpu().numpy(), (ref - b).numpy()) < 1e-5
+    for kind, xs in (("N(0,1)", xd), ("3e4", xd * 3e4), ("outlier", torch.cat([xd[:, :3], xd[:, 3:4] * 500, xd[:, 4:]], dim=1))):
+        ref64 = xs.double() @ wd.double() + bd.double()
+        err = {n: float((y.double() - ref64).abs().max() / ref64.abs().max()) for n, y in
+               (("f16x2", ops.conv1d_h2(xs, p2, bd)), ("bf16x3", ops.conv1d_s3(xs, p3, bd)), ("f32", ops.conv1d(xs, wd, bd, w_t=wd.t().contiguous())))}
+        assert err["f16x2"] <= 1.25 * max(err["bf16x3"], err["f32"]) + 2e-8, (kind, err)
+    assert ops.split2_planes(wd * 4e6) is None                         # a weight beyond the fp16 range keeps the bf16x3 planes
+    assert not torch.isfinite(ops.conv1d_h2(xd * 1e7, p2, bd)).all() or M * K < 64     # beyond 2^18: inf / NaN, never a quiet wrong number
+
+
 def test_conv1d_k_contiguous_tiles(dev):
     """Every auto-selectable tile of the k-contiguous GEMM is exercised (checked through the launch profiler) and
     agrees with the oracle on ragged M / N."""
@@ -324,7 +358,7 @@ def test_lm_logits_odd_vocab(dev):
 
 
 # ----------------------------------------------------------------------------------------- encoder
-def test_encoder_g1_every_layer(dev):
+def test_encoder_g1_every_layer(dev, gemm_mode):
     from oracle import gpt2_ref
     g = load_golden("g1_tiny_forward")
     L, H, d, V, P, seed = (int(x) for x in g["cfg"])
@@ -351,7 +385,7 @@ def test_encoder_g1_every_layer(dev):
 
 
 @pytest.mark.parametrize("name", ["cfg1_simpledyg", "cfg2_uci", "cfg4_wikiv2", "hepth"])
-def test_encoder_g3_config_shapes(dev, name):
+def test_encoder_g3_config_shapes(dev, name, gemm_mode):
     from oracle import gpt2_ref
     g = load_golden("g3_" + name)
     L, H, d, V, B, T, seed = (int(x) for x in g["cfg"])
@@ -362,7 +396,7 @@ def test_encoder_g3_config_shapes(dev, name):
     h = r["hidden"].cpu()
     assert rel_err(h[:, g["rows"].tolist(), :].numpy(), g["hidden_rows"]) < TOL
     ew = elementwise_err(h[:, g["rows"].tolist(), :].numpy(), g["hidden_rows"])     # hidden states BEFORE pooling, element-wise
-    print(f"{name}: hidden max-norm err {rel_err(h[:, g['rows'].tolist(), :].numpy(), g['hidden_rows']):.2e}, element-wise ratio {ew:.3f}")
+    print(f"{name} ({gemm_mode}): hidden max-norm err {rel_err(h[:, g['rows'].tolist(), :].numpy(), g['hidden_rows']):.2e}, element-wise ratio {ew:.3f}")
     assert ew < 1, ew
     assert rel_err(r["meanpool"].cpu().numpy(), g["meanpool"]) < TOL
     assert abs(h.double().abs().sum().item() / float(g["hidden_abs_sum"]) - 1) < 1e-5
@@ -375,7 +409,7 @@ def test_encoder_g3_config_shapes(dev, name):
         assert rel_err(logits[:, [0, T - 1], :256].cpu().numpy(), g["logits_rows"]) < TOL
 
 
-def test_fused_groups_equal_one_batch_per_call(dev):
+def test_fused_groups_equal_one_batch_per_call(dev, gemm_mode):
     """r4d_gpt2_encode_groups_f32 == r4d_gpt2_encode_f32 per batch, bit for bit (batches keep their own padding)."""
     from oracle import gpt2_ref
     sd = gpt2_ref.make_state_dict(2, 128, 50, n_positions=64, seed=5, random_affine=True)
@@ -451,6 +485,26 @@ def test_score_topk_every_scan_variant(dev, d):
         assert np.array_equal(idx.cpu().numpy(), ei + 7) and np.array_equal(vals.cpu().numpy(), ev), (d, Q, N)
         v2, i2, _ = ops.score_topk(qh, ph, k, index_offset=7, want_scores=False)        # the no-score-output form: same selection
         assert np.array_equal(i2.cpu().numpy(), ei + 7) and np.array_equal(v2.cpu().numpy(), ev), (d, Q, N)
+
+
+@pytest.mark.parametrize("N,d", [(700, 256), (12500, 512), (40000, 512), (3000, 768)])
+def test_scores_and_topk_do_not_depend_on_query_batching(dev, N, d):
+    """ONE scoring arithmetic: the same 256 queries scored in calls of 1, 32, 33, 64, 65 and 256 queries give
+    the same bits -- score rows and top-10 (values and indices) -- for every scan form (round-robin tiles, LDS-DMA short shard,
+    LDS-DMA ring).  Before round 4 calls of more than 64 queries took a tiled GEMM with another summation order."""
+    from rag4dyg_amd import ops
+    g = torch.Generator().manual_seed(N + d)
+    q = ops.normalize_rows(torch.randn(256, d, generator=g).to(dev))
+    p = torch.randn(N, d, generator=g)
+    p[N // 2] = p[5]                                                   # an exact tie across tiles
+    p = ops.normalize_rows(p.to(dev))
+    v_all, i_all, s_all = ops.score_topk(q, p, 10, 7, want_scores=True)
+    for qb in (1, 32, 33, 64, 65):
+        for j0 in (0, 97):
+            v, i, sc = ops.score_topk(q[j0:j0 + qb].contiguous(), p, 10, 7, want_scores=True)
+            assert torch.equal(sc, s_all[j0:j0 + qb]) and torch.equal(v, v_all[j0:j0 + qb]) and torch.equal(i, i_all[j0:j0 + qb]), (N, d, qb, j0)
+    ref = ((q.double() @ p.double().t() + 1) / 2)
+    assert float((s_all.double() - ref).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("d", [256, 384, 512, 768, 1024])

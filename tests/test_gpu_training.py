@@ -203,6 +203,33 @@ def test_training_step_parameter_update_equals_oracle_adamw(dev):
     assert "_wt_cache" not in m.transformer.__dict__                         # stale transposed copies dropped
 
 
+def test_non_finite_gradient_stays_loud_in_the_deterministic_embedding_sum(dev):
+    """the token-embedding gradient is a 64-bit fixed-point sum (bit-reproducible); a NaN / Inf contribution has no
+    fixed-point image and used to become 0 or a saturated integer -- a finite, WRONG gradient.  Now it poisons the table: the whole
+    wte gradient (and with it the gradient norm the clip uses) is NaN, as with the float atomics of a framework backward."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd import training
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    L, H, d, V = 1, 2, 64, 50
+    cfg = GPT2Config(vocab_size=V, n_positions=64, n_ctx=64, n_embd=d, n_layer=L, n_head=H)
+    m = GPT2LMHeadModelRAG(cfg)
+    m.load_state_dict(gpt2_ref.make_state_dict(L, d, V, n_positions=64, seed=1, random_affine=True), strict=False)
+    m = m.to(dev).eval()
+    ids = torch.randint(0, V, (4, 9), generator=torch.Generator().manual_seed(0)).to(dev)
+    trainer = training.EncoderTrainer(m)
+    emb = trainer.forward([ids])
+    good = trainer.backward(torch.ones_like(emb))["transformer.wte.weight"].clone()
+    assert torch.isfinite(good).all() and good.abs().max() > 0
+    trainer.forward([ids])
+    bad_in = torch.ones_like(emb)
+    bad_in[2, 5] = float("inf")
+    bad = trainer.backward(bad_in)["transformer.wte.weight"]
+    assert torch.isnan(bad).all()
+    opt = training.AdamW(trainer.params, trainer.grads, lr=1e-3, flat_grads=trainer.flat_grads)
+    opt.sumsq.zero_()
+    assert not np.isfinite(float(trainer.flat_grads.double().pow(2).sum().sqrt()))
+
+
 @pytest.mark.parametrize("via_step", [True, False])
 def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step):
     """``r4d_adamw_step_f32`` writes the parameters through raw pointers, so torch's version counters do not

@@ -14,9 +14,9 @@ from rag4dyg_amd import ops                                   # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(3)
 bad = 0
-for M, K, N in ((45, 96, 80), (128, 32, 256), (129, 64, 257), (1000, 512, 1536), (4096, 512, 512), (700, 2048, 512), (333, 768, 2304)):
+for M, K, N in ((45, 96, 80), (128, 32, 256), (129, 64, 257), (1000, 512, 1536), (4096, 512, 512), (4096, 512, 1536), (700, 2048, 512), (333, 768, 2304)):
     for epi in ("none", "gelu", "residual"):
-        for kind, scale in (("N(0,1)", 1.0), ("tiny 1e-4", 1e-4), ("large 3e4", 3e4), ("outlier", 1.0)):
+        for kind, scale in (("N(0,1)", 1.0), ("tiny 1e-3", 1e-3), ("large 3e4", 3e4), ("outlier", 1.0)):
             x = torch.randn(M, K, device=dev, generator=g) * scale
             if kind == "outlier":
                 x[:, 3] *= 500
@@ -28,6 +28,11 @@ for M, K, N in ((45, 96, 80), (128, 32, 256), (129, 64, 257), (1000, 512, 1536),
                 ref = 0.5 * ref * (1.0 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
             elif epi == "residual":
                 ref = ref + r.double()
+            pl2 = ops.split2_planes(w)                       # run to run: the same bits (a race would show here)
+            y0 = ops.conv1d_h2(x, pl2, b, epi, r)
+            if not all(torch.equal(y0, ops.conv1d_h2(x, pl2, b, epi, r)) for _ in range(3)):
+                bad += 1
+                print(f"   h2 NOT REPRODUCIBLE at {M}x{K}x{N} {epi} {kind}", flush=True)
             res = {}
             for name, fn in (("h2", lambda: ops.conv1d_h2(x, ops.split2_planes(w), b, epi, r)),
                              ("s3", lambda: ops.conv1d_s3(x, ops.split3_planes(w), b, epi, r)),
