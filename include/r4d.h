@@ -12,7 +12,14 @@
  *   - return value: 0 = R4D_OK, negative = error; the message is available from r4d_last_error()
  *     (thread-local).  No exceptions cross the ABI;
  *   - all floating-point data is fp32 (the reference computes in fp32), Jaccard ratios are f64
- *     (python floats), indices are int32 / int64 as stated.
+ *     (python floats), indices are int32 / int64 as stated;
+ *   - PROCESS MODEL: one process drives ONE device (one process per GPU, torch.distributed over RCCL between them).  A few
+ *     launch parameters are latched per process the first time a kernel family runs (occupancy of the scan kernels, the
+ *     > 64 KB dynamic-LDS attribute of the LDS-DMA scan forms, the persistent GEMM's ticket slots), i.e. for the device that was
+ *     current then; a process that switched devices afterwards would get R4D_ERR_HIP from the first such launch on the second
+ *     device (loud, never a wrong result).  The arithmetic switches (r4d_set_gemm_split3, r4d_set_attention_fused) are
+ *     process-wide too: the ranks of a sharded job must select the same Conv1D arithmetic, or the merged per-shard top-k differs
+ *     from the one-GPU result in the last bits of the scores.
  */
 #ifndef R4D_H
 #define R4D_H
@@ -34,7 +41,7 @@ extern "C" {
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
 /* 0 for a product build.  Non-zero when the library was compiled with one of the kernel-ablation macros of
- * tools/kc_ablate.sh (bit 0 KC_DBG, bit 1 ATT_DBG, bit 2 SK_DBG, bit 3 JAC_DBG, bit 4 SCAN_DBG, bit 5 S3_DBG): such a build
+ * tools/kc_ablate.sh (bit 0 KC_DBG, bit 1 ATT_DBG, bit 2 SK_DBG, bit 3 JAC_DBG, bit 4 SCAN_DBG, bit 5 S3_DBG, bit 6 H2_DBG): such a build
  * computes WRONG results by construction and the Python binding refuses to load it outside tools/. */
 int r4d_build_flags(void);
 /* Message of the last failing call on this thread ("" if none). */

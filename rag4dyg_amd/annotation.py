@@ -119,6 +119,34 @@ def iter_row_chunks(target_csr, source_csr, vocab, zero_diag=False, chunk=ROW_CH
         yield r0, m
 
 
+# ---- text: the reference's files are O(Q x N) decimal numbers.  ``str`` per number was 0.24 s of a 0.45 s hepth run; a Jaccard
+# matrix holds a few hundred DISTINCT values (quotients of small integers) and the indices are 0 .. N-1, so every number's text is
+# made once and the rows are assembled by table lookup (same bytes: the table entries ARE ``str(float)`` / ``str(int)``).
+_INT_STR = np.empty(0, dtype=object)
+
+
+def _int_strings(n):
+    """object array: _int_strings(n)[i] == str(i) for i < n (grown on demand, shared by every file of a run)."""
+    global _INT_STR
+    if _INT_STR.size < n:
+        _INT_STR = np.array([str(i) for i in range(max(n, 2 * _INT_STR.size))], dtype=object)
+    return _INT_STR
+
+
+def _float_lines(m):
+    """Rows of a device f64 matrix as text, ``' '.join(str(x) for x in row)`` per row: distinct values found on the device
+    (``torch.unique``), their shortest round-trip text made once, rows assembled by lookup."""
+    u, inv = torch.unique(m, return_inverse=True)
+    tab = np.array([str(x) for x in u.cpu().tolist()], dtype=object)
+    inv = inv.to(torch.int32 if u.numel() < 2 ** 31 else torch.int64).cpu().numpy()
+    return [' '.join(tab[r].tolist()) for r in inv]
+
+
+def _int_lines(idx_np):
+    tab = _int_strings(int(idx_np.max()) + 1 if idx_np.size else 1)
+    return [' '.join(tab[r].tolist()) for r in idx_np]
+
+
 def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_file, rows=None):
     """``retrieval_data_annotation.py:88-93``: full ranking (canonical stable order) + every score, as text."""
     with open(save_index_file, 'w') as f, open(save_score_file, 'w') as g:
@@ -127,12 +155,9 @@ def save_index_score(target_csr, source_csr, vocab, save_index_file, save_score_
                 perm = ops.argsort_desc(m)
             with phase("download"):
                 indices = perm.cpu().numpy()
-                mh = m.cpu().numpy()
             with phase("text: format + write"):
-                # python scalars format ~3x faster than numpy scalars and print the same shortest round-trip digits
-                for ind_row, sc_row in zip(indices.tolist(), mh.tolist()):
-                    f.write(' '.join(map(str, ind_row)) + '\n')
-                    g.write(' '.join(map(str, sc_row)) + '\n')
+                f.write('\n'.join(_int_lines(indices)) + '\n')
+                g.write('\n'.join(_float_lines(m)) + '\n')
 
 
 def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk=10, rows=None):
@@ -142,67 +167,88 @@ def save_score_file_train(out_csr, vocab, save_file_index, save_file_score, topk
             with phase("device: top-10"):
                 vals, idx = ops.topk_f64(m, min(topk, m.shape[1]))
             with phase("download"):
-                vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+                idx_h = idx.cpu().numpy()
             with phase("text: format + write"):
-                for ind_row, sc_row in zip(idx.tolist(), vals.tolist()):
-                    f_index.write(' '.join(map(str, ind_row)) + '\n')
-                    f_score.write(' '.join(map(str, sc_row)) + '\n')
+                f_index.write('\n'.join(_int_lines(idx_h)) + '\n')
+                f_score.write('\n'.join(_float_lines(vals)) + '\n')
 
 
-def train_annotation_rows(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False, rows=None):
-    """Per anchor row: (i, positives, negative candidates, out-score row) following
-    ``retrieval_data_annotation.py:52-74``; candidate order = canonical stable ranking of the input-set
-    similarities (the reference's order is tie-dependent)."""
+def _mix64(x):
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap-around is the arithmetic wanted): a counter-based hash, so the
+    pick of (anchor row i, its j-th positive) is a pure function of (seed, i, j) -- no generator state walks from row to row."""
+    x = (x ^ (x >> 30 & 0x3FFFFFFFF)) * -4658895280553007687          # 0xBF58476D1CE4E5B9
+    x = (x ^ (x >> 27 & 0x1FFFFFFFFF)) * -7723592293110705685         # 0x94D049BB133111EB
+    return x ^ (x >> 31 & 0x1FFFFFFFF)
+
+
+def train_annotation_chunks(out_csr, in_csr, vocab, threshold=0.8, neg_num=5, dialog=False, rows=None, choice_seed=0):
+    """Per chunk of anchor rows, everything ``save_train_annotation`` writes, found ON THE DEVICE and downloaded as five small
+    arrays: (anchor i, positive, picked negative, score of the positive, score of the negative) per (anchor, positive) pair in
+    the reference's order (``retrieval_data_annotation.py:52-85``: anchors ascending, positives ascending; dialog keeps the first
+    four positives, :73-74), plus -- for the tests -- the candidate lists.  Candidate order = canonical stable ranking of the
+    input-set similarities (the reference's order is tie-dependent): walk it, first the non-positive entries
+    with an output score > 0, then -- only if fewer than ``neg_num`` -- those with score 0.  The negative of a pair is a uniform
+    pick among the candidates, as upstream's unseeded ``np.random.choice`` (:79), drawn by ``_mix64(seed, i, j)``."""
     gen_in = iter_row_chunks(in_csr, in_csr, vocab, zero_diag=True, rows=rows)
     for (r0, m_out), (_r0b, m_in) in zip(iter_row_chunks(out_csr, out_csr, vocab, zero_diag=True, rows=rows), gen_in):
         with phase("device: positives + argsort of the input-set rows"):
-            has_pos = (m_out > threshold).any(dim=1)
-            rows = torch.nonzero(has_pos).flatten()
-            if rows.numel() == 0:
+            posmask = m_out > threshold
+            rows_d = torch.nonzero(posmask.any(dim=1)).flatten()
+            if rows_d.numel() == 0:
                 continue
-            order_d = ops.argsort_desc(m_in[rows].contiguous()).long()
-            # the five negative candidates of every anchor row at once (index glue on the device; was a python loop over the
-            # ranked pool per row: 0.8 s of a 1.2 s hepth run): walk the row's stable ranking of the input-set similarities,
-            # first the non-positive entries with an output score > 0, then -- only if fewer than neg_num -- those with score 0
-            ro = torch.gather(m_out[rows], 1, order_d)                       # output scores in ranking order
+            mo = m_out[rows_d]
+            order_d = ops.argsort_desc(m_in[rows_d].contiguous()).long()
+            ro = torch.gather(mo, 1, order_d)                                # output scores in ranking order
             notpos = ~(ro > threshold)
             cls = torch.where(notpos & (ro > 0), 0, torch.where(notpos & (ro == 0), 1, 2))
             npool = ro.shape[1]
             key = cls * npool + torch.arange(npool, device=ro.device)[None, :]
             kk = min(neg_num, npool)
             best = torch.topk(key, kk, dim=1, largest=False, sorted=True).values
-            neg_idx_d = torch.gather(order_d, 1, best % npool)
+            neg_idx_d = torch.gather(order_d, 1, best % npool)               # [rows, kk] candidates, in walk order
             neg_cnt_d = (best < 2 * npool).sum(dim=1)
-        with phase("download"):
-            mo = m_out[rows].cpu().numpy()
-            neg_idx, neg_cnt = neg_idx_d.cpu().numpy(), neg_cnt_d.cpu().numpy()
-        for r, i_local in enumerate(rows.tolist()):
-            row = mo[r]
-            pos = np.where(row > threshold)[0].tolist()
-            negs = [int(x) for x in neg_idx[r, :int(neg_cnt[r])]]
+            pr, pc = torch.nonzero(posmask[rows_d], as_tuple=True)           # (row, positive) pairs, row-major = the reference's order
+            first = torch.searchsorted(pr, torch.arange(rows_d.numel(), device=pr.device))
+            ordinal = torch.arange(pr.numel(), device=pr.device) - first[pr]  # j: which positive of its row
             if dialog:
-                pos = pos[:4]
-            yield r0 + i_local, pos, negs, row
+                keep = ordinal < 4
+                pr, pc, ordinal = pr[keep], pc[keep], ordinal[keep]
+            anchor = rows_d[pr] + r0
+            ncand = neg_cnt_d[pr]
+            if bool((ncand == 0).any()):
+                raise ValueError("'a' cannot be empty unless no samples are taken")     # np.random.choice([]) upstream
+            h = _mix64(_mix64(anchor + int(choice_seed)) + ordinal)
+            pick = torch.remainder(h & 0x7FFFFFFFFFFFFFFF, ncand)
+            neg = neg_idx_d[pr, pick]
+            s_pos, s_neg = mo[pr, pc], mo[pr, neg]
+        with phase("download"):
+            out = dict(anchor=anchor.cpu().numpy(), pos=pc.cpu().numpy(), neg=neg.cpu().numpy(), s_pos=s_pos, s_neg=s_neg,
+                       cand_rows=(rows_d + r0).cpu().numpy(), cand_idx=neg_idx_d.cpu().numpy(), cand_cnt=neg_cnt_d.cpu().numpy())
+        yield out
 
 
 def save_train_annotation(out_csr, in_csr, vocab, save_file, save_file_score, threshold=0.8, neg_num=5, dataset="",
                           rows=None, choice_seed=None):
     """``retrieval_data_annotation.py:43-85``: ``i pos neg`` triples; the negative is a uniform random pick among the
-    candidates as upstream (``np.random.choice``, :79 -- unseeded there, so column 3 is not reproducible by design).  The
-    picks of anchor row i come from a generator seeded with ``choice_seed + i`` (``choice_seed`` itself is drawn from
-    numpy's global state, so ``np.random.seed`` still governs a run): a row's picks do not depend on which rows were
-    processed before it, which is what lets the rows be dealt to several ranks and still give the one-rank file."""
+    candidates as upstream (``np.random.choice``, :79 -- unseeded there, so column 3 is not reproducible by design).  Here the
+    pick is a counter-based hash of (``choice_seed``, anchor row, which positive) -- ``choice_seed`` itself is drawn from numpy's
+    global state, so ``np.random.seed`` still governs a run: a row's picks do not depend on which rows were processed before it,
+    which is what lets the rows be dealt to several ranks and still give the one-rank file."""
     if choice_seed is None:
         choice_seed = int(np.random.randint(0, 2 ** 31 - 1))
     cnt, n = 0, out_csr[0].numel() - 1
     with open(save_file, 'w') as f, open(save_file_score, 'w') as g:
-        for i, pos, negs, row in train_annotation_rows(out_csr, in_csr, vocab, threshold, neg_num, 'dialog' in dataset, rows):
-            pick = np.random.RandomState((choice_seed + i) % (2 ** 32))
-            for pos_ind in pos:
-                neg_i = pick.choice(negs)
-                f.write(f"{i} {pos_ind} {neg_i}\n")
-                g.write(f"{i} {row[pos_ind]} {row[neg_i]}\n")
-                cnt += 1
+        for c in train_annotation_chunks(out_csr, in_csr, vocab, threshold, neg_num, 'dialog' in dataset, rows, choice_seed):
+            with phase("text: format + write"):
+                k = len(c["anchor"])
+                if k == 0:
+                    continue
+                tab = _int_strings(int(max(c["anchor"].max(), c["pos"].max(), c["neg"].max())) + 1)
+                a_s = tab[c["anchor"]].tolist()
+                sc = _float_lines(torch.stack([c["s_pos"], c["s_neg"]], dim=1))
+                f.write('\n'.join(map(' '.join, zip(a_s, tab[c["pos"]].tolist(), tab[c["neg"]].tolist()))) + '\n')
+                g.write('\n'.join(a + ' ' + s_ for a, s_ in zip(a_s, sc)) + '\n')
+                cnt += k
     return n, cnt
 
 

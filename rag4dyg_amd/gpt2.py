@@ -8,6 +8,7 @@ unchanged and the reference call sites (``train/train_retriever.py:419,430``,
 ``forward`` hands their device pointers to ``r4d_gpt2_encode_f32`` -- inference only (no autograd), GPU
 only (CPU tensors raise: there is no fallback).
 """
+import contextlib
 import ctypes
 import weakref
 import json
@@ -67,13 +68,32 @@ class GPT2Config:
         return cls(**d)
 
 
+_SKIP_INIT = [False]
+
+
+@contextlib.contextmanager
+def skip_random_init():
+    """Construct a model WITHOUT drawing its random initial weights -- for callers that overwrite every parameter right afterwards
+    (the evaluation-only command lines: strict ``load_state_dict`` of a checkpoint).  The draws were 0.46 s of a 0.56 s
+    ``main_retriever.py --do_eval`` run (each tensor initialised twice on the CPU, by its torch module and by ``_init_weights``,
+    then replaced by the checkpoint).  Parameters are left as allocated (arbitrary bytes): never use such a model unloaded."""
+    saved = (nn.init.normal_, nn.init.kaiming_uniform_, nn.init.uniform_)
+    nn.init.normal_ = nn.init.kaiming_uniform_ = nn.init.uniform_ = lambda t, *a, **k: t
+    _SKIP_INIT[0] = True
+    try:
+        yield
+    finally:
+        _SKIP_INIT[0] = False
+        nn.init.normal_, nn.init.kaiming_uniform_, nn.init.uniform_ = saved
+
+
 class Conv1D(nn.Module):
     """Parameter holder with the reference layout: weight [nx, nf] (``modeling_utils.py:1255-1265``)."""
 
     def __init__(self, nf, nx):
         super().__init__()
         self.nf = nf
-        self.weight = nn.Parameter(torch.empty(nx, nf).normal_(std=0.02))
+        self.weight = nn.Parameter(torch.empty(nx, nf) if _SKIP_INIT[0] else torch.empty(nx, nf).normal_(std=0.02))
         self.bias = nn.Parameter(torch.zeros(nf))
 
     def forward(self, x):
@@ -115,7 +135,8 @@ class _PreTrained(nn.Module):
     def _init_weights(self, module):
         """``modeling_gpt2.py:251-262``."""
         if isinstance(module, (nn.Linear, nn.Embedding, Conv1D)):
-            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+            if not _SKIP_INIT[0]:
+                module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
             if isinstance(module, (nn.Linear, Conv1D)) and module.bias is not None:
                 module.bias.data.zero_()
         elif isinstance(module, nn.LayerNorm):
@@ -202,7 +223,8 @@ class GPT2Model(_PreTrained):
         if new_num_tokens is None or new_num_tokens == old.num_embeddings:
             return old
         new = nn.Embedding(new_num_tokens, old.embedding_dim).to(old.weight.device)
-        new.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        if not _SKIP_INIT[0]:
+            new.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
         n = min(old.num_embeddings, new_num_tokens)
         new.weight.data[:n, :] = old.weight.data[:n, :]
         self.wte = new

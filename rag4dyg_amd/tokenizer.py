@@ -198,9 +198,14 @@ def get_model_tokenizer(args, MODEL_CLASSES):
     tok.save_pretrained(os.path.join('./tokenizers/', args.dataset, str(args.timestamp)))
     print('vocab size: ', tok.vocab_size)
     config.max_token_id = tok.vocab_size
-    model = model_class(config=config)
-    model.to(args.device)
-    model.resize_token_embeddings(len(tok))
+    # evaluation only: every parameter comes from a checkpoint (strict load_state_dict) -- no random draws (gpt2.skip_random_init)
+    import contextlib
+    from .gpt2 import skip_random_init
+    eval_only = bool(getattr(args, "do_eval", False)) and not bool(getattr(args, "do_train", False)) and args.dataset != 'hepth'
+    with (skip_random_init() if eval_only else contextlib.nullcontext()):
+        model = model_class(config=config)
+        model.to(args.device)
+        model.resize_token_embeddings(len(tok))
     if args.dataset == 'hepth':                          # node-feature injection, utils/tokenizer.py:56-66
         feats = np.load(args.node_feat_file)[:tok.vocab_size]
         if feats.shape[1] < args.n_embed:
