@@ -8,7 +8,8 @@ OUT=$R/gpurun_out/prof_$TAG
 export R4D_PROFILE_SHAPE=${R4D_PROFILE_SHAPE:-UCI_13}
 # --headline-only: warm-up + timed steps and NOTHING else (no roofline re-run, no exact-f32 second run, no length-bucketed
 # run), so that the per-kernel averages of this trace are the headline launches' (the r02 trace mixed them)
-GEMM=${R4D_PROFILE_GEMM:-split3}
+export R4D_PROFILE_GEMM=${R4D_PROFILE_GEMM:-f16x2}
+GEMM=$R4D_PROFILE_GEMM
 ARGS="--shape $R4D_PROFILE_SHAPE --gemm $GEMM --steps 32 --warmup 16 --random-pool --headline-only"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

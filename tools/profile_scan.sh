@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_scan_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export R4D_SCAN_CASES=${R4D_SCAN_CASES:-12500x512,100000x512,100000x768}
+export R4D_SCAN_CASES=${R4D_SCAN_CASES:-12512x512,100000x512,100000x768}
 # one pool size per process, so that the per-kernel averages and the per-launch counter means are not a mix of sizes
 for size in ${R4D_SCAN_CASES//,/ }; do
   echo "trace $size" >> $OUT/progress.log

@@ -22,7 +22,7 @@ stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --shape {os.environ.get('R4D_PROFILE_SHAPE', 'UCI_13')} "
-            f"--gemm {os.environ.get('R4D_PROFILE_GEMM', 'split3')} --steps 32 --warmup 16 --random-pool --headline-only\n")
+            f"--gemm {os.environ.get('R4D_PROFILE_GEMM', 'f16x2')} --steps 32 --warmup 16 --random-pool --headline-only\n")
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in rows:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
@@ -74,11 +74,14 @@ def bench_class(k):
         return f"gemm_s3_{m.group(1)}x{m.group(2)}x32"
     if k.startswith("gemm_s3p_kernel"):                      # persistent form of the same tile: same bench.py class
         return "gemm_s3_128x256x32"
+    m = re.match(r"gemm_h2_kernel<(\d+), (\d+), ", k)
+    if m:
+        return f"gemm_h2_{m.group(1)}x{m.group(2)}x32"
     if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
         return "layernorm"
-    if k.startswith("pool_scan_ks_kernel"):
+    if k.startswith(("pool_scan_ks_kernel", "pool_scan_dma_kernel", "pool_scan_ring_kernel")):
         return "pool_scan"
     return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
             "lnf_partial_kernel<8>": "lnf_partial", "lnf_partial_kernel<16>": "lnf_partial", "lnf_partial_kernel<32>": "lnf_partial", "meanpool_reduce_kernel": "meanpool_reduce", "gemm_skinny_kernel": "gemm_skinny",
@@ -128,7 +131,7 @@ except Exception as e:                                                        # 
 sys.path.insert(0, repo)
 from bench import source_sha                                                   # noqa: E402
 shape = os.environ.get("R4D_PROFILE_SHAPE", "UCI_13")
-gemm = os.environ.get("R4D_PROFILE_GEMM", "split3")
+gemm = os.environ.get("R4D_PROFILE_GEMM", "f16x2")
 traffic["_workload"] = {"shape": shape, "batches_per_step": 8, "n_gpus": 1, "pool_rows_per_gpu": 100000, "gemm": gemm,
                         "source_sha": source_sha(),
                         "command": f"bench.py --shape {shape} --gemm {gemm} --steps 32 --warmup 16 --random-pool --headline-only"}
