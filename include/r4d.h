@@ -92,7 +92,7 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * loading the gain / shift or forming c1 / c2 per launch; NULL = it forms them from ln_1 / ln_2 and *_wT as before. */
     const float* c_attn_wTg;    const float* c_attn_lnc;
     const float* c_fc_wTg;      const float* c_fc_lnc;
-    /* OPTIONAL f16x2 planes of the four weights (ABI v5; r4d_split2_planes_f16: uint16 [2][out][in], hi and 2^11-scaled lo
+    /* OPTIONAL f16x2 planes of the four weights (ABI v5; r4d_split2_planes_f16: uint16 [out][in/32][2][32], hi and 2^11-scaled lo
      * as fp16), made once per checkpoint; NULL = not provided.  With them and r4d_set_gemm_split3(2) the four Conv1D GEMMs of a
      * block run on the fp16 matrix cores with THREE products per fp32 product at fp32 accuracy (r4d_conv1d_h2_f32; csrc/gemm_h2.hip
      * for the error analysis and the operand range: |activation| < 2^18, |weight| < 6e4). */
@@ -235,6 +235,18 @@ int r4d_lm_logits_f32(const float* hidden_d, const float* wte_d, int32_t M, int3
  * 2 = fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning).  Same results to fp32 rounding. */
 int r4d_set_attention_fused(int32_t mode);
 
+/* f16x2 attention (ABI v5, additive): in gemm mode 2 (f16x2) r4d_gpt2_encode_* runs head_dim 128 / 256 attention on the fp16
+ * matrix cores (csrc/attention_h2.hip) -- the c_attn GEMM then writes its result as "h2 words" (uint32 per element:
+ * fp16 hi | fp16 lo' << 16 of value / 4, value = hi + 2^-11 lo' to 2^-22 relative; csrc/h2.h) instead of fp32, and the attention
+ * kernel consumes them without conversion.  Not used when the caller asks for the qkv tensor (out_qkv_d) and for other head
+ * dims; |q|, |k|, |v| < 2^18.  r4d_set_attention_h2(0) keeps the exact-f32 attention kernels in every mode (returns the previous
+ * setting; process-wide like r4d_set_gemm_split3: ranks must agree).
+ * r4d_pack_h2_words_f32: x_d fp32 [n] -> words_d uint32 [n] (what the GEMM epilogue writes; for tests and external producers).
+ * r4d_attention_h2_f32: r4d_attention_f32 on words: qkv_words_d [B*T, 3d] -> a_d fp32 [B*T, d]; head_dim 128 / 256 only. */
+int r4d_set_attention_h2(int32_t on);
+int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream);
+int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream);
+
 /* --- single ops, exported for per-op parity tests (same kernels the encoder launches) --- */
 /* y = LayerNorm(x) over the last dim.  nn.LayerNorm, modeling_gpt2.py:219,221,339. */
 int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int32_t rows, int32_t d,
@@ -265,7 +277,8 @@ int r4d_conv1d_s3_f32(const float* x_d, const uint16_t* planes_d, const float* b
  * in profiles/).  Operand range: |x| < 2^18 for the activation (pre-scaled by 2^-2 inside the kernel; full precision for elements >= 2.4e-4,
  * an absolute floor of 6e-11 below), |w| < 6e4 for the
  * weight; beyond it the result is inf / NaN, not a silently wrong number.
- * r4d_split2_planes_f16: w_d fp32 [K,N] (transposed != 0: [N,K]) -> planes_d fp16 [2][N][K] (4 * N * K bytes), once per checkpoint.
+ * r4d_split2_planes_f16: w_d fp32 [K,N] (transposed != 0: [N,K]) -> planes_d fp16 [N][K/32][2][32] (4 * N * K bytes: per row and 32 consecutive k one 128-byte line of 32 hi then 32 lo'
+ * values; K % 32 == 0), once per checkpoint.
  * r4d_conv1d_h2_f32: y = epilogue(x[M,K] @ W + bias), K % 32 == 0; epilogue as r4d_conv1d_f32.
  */
 int r4d_split2_planes_f16(const float* w_d, int32_t K, int32_t N, int32_t transposed, uint16_t* planes_d, void* stream);

@@ -70,6 +70,9 @@ PROTOTYPES = {
     "r4d_gpt2_encode_groups_ex_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), c_int32, POINTER(_P), POINTER(_P),
                                                 POINTER(c_int32), POINTER(c_int32), _P, _P, _P, _P, c_size_t, _P]),
     "r4d_set_attention_fused": (c_int32, [c_int32]),
+    "r4d_set_attention_h2": (c_int32, [c_int32]),
+    "r4d_pack_h2_words_f32": (c_int32, [_P, c_int64, _P, _P]),
+    "r4d_attention_h2_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_gpt2_decode_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32]),
     "r4d_gpt2_decode_step_f32": (c_int32, [POINTER(GPT2ConfigC), POINTER(GPT2WeightsC), _P, _P, _P, _P, c_int32, c_int32,
                                            _P, _P, c_size_t, _P]),

@@ -27,14 +27,6 @@ namespace r4d {
 
 typedef float f32x16a __attribute__((ext_vector_type(16)));
 
-// Up to ATT_MAXG right-padded batches (each with its own T) in ONE launch: blockIdx.z walks the sequences of all
-// batches; the batch of a sequence is found by a short scan of the prefix table (kernel argument, by value).
-struct AttnGroups {
-    int n;
-    int seq_prefix[ATT_MAXG + 1];     // first global sequence index of each batch
-    int T[ATT_MAXG];
-    long long row0[ATT_MAXG];         // first token row of each batch in qkv / out
-};
 constexpr int ATT_LDQ = 33;
 
 template <int VW>

@@ -1,0 +1,349 @@
+// Fused causal multi-head attention on the fp16 matrix cores at fp32 accuracy (the f16x2 form of gemm_h2.hip) for head_dim
+// 128 / 256: softmax(Q.K^T / sqrt(hd), causal) . V  (Attention._attn + split/merge_heads, models/modeling_gpt2.py:140-175).
+//
+// Operands arrive as "h2 words" (csrc/h2.h): qkv [rows, 3d] uint32, every element  hi | lo' << 16  of value / 4 -- written by
+// the c_attn GEMM's EPI_H2WORDS epilogue (gemm_h2.hip), so neither K nor V is converted here: a register of words IS an MFMA
+// operand holding two k-slots (hi, lo') per element, and against it the other operand takes the two forms
+//     F1 = (hi, 0)  -> sum hi.hi  (accumulator set 0)        F2 = (lo', hi)  -> sum hi.lo' + lo'.hi  (set 1, factor 2^11)
+// i.e. TWO v_mfma_f32_32x32x16_f16 per 8 elements (the plane form of gemm_h2.hip needs three per 16, but would need K and V
+// re-laid by whoever produces them) against sixteen v_mfma_f32_32x32x2_f32 in attention_fused.hip: the matrix work per
+// (query, key) pair drops 4 x for Q.K^T and 8 x for P.V.  The dropped term 2^-22 lo'.lo' and the roundings are gemm_h2.hip's.
+//
+// Structure = attention_fused.hip's column-split kernel: one workgroup = one (sequence, head, 32-query tile); its 4 wavefronts
+// walk 128-key super-tiles together -- wave w computes S^T = K.Q^T for its own 32 keys over the full head_dim (A = its K rows
+// straight from global memory, 16 bytes = 4 words per lane and step; B = the Q tile from LDS, its two forms derived in
+// registers: one AND and one rotate per word), the row max / row sum are combined across the waves through LDS, every wave
+// publishes its probabilities to LDS IN BOTH FORMS (split once by the producer: 12 VALU per two probabilities, against two
+// per word and reader), and wave w accumulates its quarter of the head columns of O^T over all 128 keys (A = V words, four
+// 4-byte loads per tile column group; B = the two P forms, one ds_read_b128 each per 8 keys).
+// Logits: S = (acc0 + 2^-11 acc1) * 16 log2(e) / sqrt(hd)  (the 16 undoes the two 2^-2 pre-scales), exp2 domain, fp32 online
+// softmax exactly as in attention_fused.hip; masked keys are skipped.
+// Range: |q|, |k|, |v| < 2^18 (beyond: inf -> NaN in the output, never a quiet wrong number).
+#include <math.h>
+#include "common.h"
+#include "h2.h"
+
+#ifndef ATH_DBG
+#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills
+#endif
+
+#ifndef ATH_KD
+#define ATH_KD 8    // K loads (16 bytes per lane) in flight per wave
+#endif
+#ifndef ATH_VD
+#define ATH_VD 3    // V key-groups (8 keys) in flight per wave
+#endif
+#ifndef ATH_QP
+#define ATH_QP 4    // Q fragments (one ds_read_b128 each) in flight per wave
+#endif
+#ifndef ATH_OCC128
+#define ATH_OCC128 3   // workgroups per CU the head_dim-128 instantiation is compiled for
+#endif
+
+namespace r4d {
+
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void pack_h2_words_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ w) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    unsigned w0, w1;
+    h2_words<true>(x[i], i + 1 < n ? x[i + 1] : 0.f, w0, w1);
+    w[i] = w0;
+    if (i + 1 < n) w[i + 1] = w1;
+}
+
+#define ATH_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, A_), __builtin_bit_cast(f16x8q, B_), C_, 0, 0, 0)
+
+template <int HD>
+__global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H,
+                                                                                  int ntq, float qscale, float* __restrict__ out) {
+    constexpr int CW = HD / 4;                         // head columns owned by one wave
+    constexpr int VW = CW / 32;                        // O^T tiles per wave (1 or 2): tile j = columns wid * CW + 32 j + lane
+    constexpr int NSTEP = HD / 8;                      // 16-byte K loads (and Q reads) per key row: 8 elements per MFMA pair
+    constexpr int LDQ = HD + 4, LDP = 132;             // row strides (words): 16-lane b128 groups hit 16 distinct slots
+    constexpr int KD = NSTEP < ATH_KD ? NSTEP : ATH_KD;   // K loads in flight per lane
+    constexpr int VD = ATH_VD;                         // V key-groups (8 keys) in flight
+    constexpr int QP = ATH_QP;                         // Q fragments (ds_read_b128) in flight: a fragment feeds TWO 32-cycle MFMAs
+    extern __shared__ unsigned ldsw[];                 //   (sixteen 64-cycle ones in attention_fused.hip), so the LDS latency shows unless the reads run ahead
+    unsigned* Qs = ldsw;                               // [32][LDQ]  the query tile's words
+    unsigned* P1 = ldsw + 32 * LDQ;                    // [32][LDP]  probabilities of the current super-tile, form (hi, 0), [query][key]
+    unsigned* P2 = P1 + 32 * LDP;                      // [32][LDP]  form (lo', hi)
+    float* red = reinterpret_cast<float*>(P2 + 32 * LDP);   // [2][4][32] per-wave row max / row sum
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // work mapping: attention_fused.hip's (all query tiles of one (sequence, head) on the same XCD, long tiles first)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / ntq) * 8 + xcd;           // (sequence, head) index
+    if (pair >= G.seq_prefix[G.n] * H) return;
+    const int qt = ntq - 1 - slot % ntq, h = pair % H, seq = pair / H;
+    int gi = 0;
+    while (gi + 1 < G.n && seq >= G.seq_prefix[gi + 1]) ++gi;
+    const int T = G.T[gi];
+    const int q0 = qt * 32;
+    if (q0 >= T) return;                               // ntq covers the longest batch
+    const long long rowb = G.row0[gi] + (long long)(seq - G.seq_prefix[gi]) * T;     // first row of the sequence
+    const int ld3 = 3 * d;
+    const unsigned* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
+    const int seq_bytes = ((T - 1) * ld3 + HD) * 4;    // one head's K (or V) rows of this sequence, as a byte range
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + d), 0, seq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + 2 * d), 0, seq_bytes, 0x00020000);
+    const int qidx = q0 + li;
+    const int key_limit = min(T, q0 + 32);             // keys >= key_limit are masked for every query of the tile
+    const int k_voff = ((32 * wid + li) * ld3 + 4 * lh) * 4;                 // bytes; + scalar (st0 * ld3 + 8u) * 4
+    const int v_voff = (4 * lh * ld3 + wid * CW + li) * 4;                   // bytes; + scalar ((st0 + 8s + c) * ld3 + 32 j) * 4
+    u32x4q kb[KD];
+    if (wid * 32 < key_limit) {
+#pragma unroll
+        for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, 32 * u, 0);
+    }
+    {   // Q tile: thread t stages row t/8, 16-byte pieces 4*(t%8) + 32j; rows past T repeat the last row (never stored)
+        const int row = tid >> 3, seg = 4 * (tid & 7);
+        const unsigned* src = base + (long long)min(q0 + row, T - 1) * ld3 + seg;
+        u32x4q qv[HD / 32];
+#pragma unroll
+        for (int j = 0; j < HD / 32; ++j) qv[j] = *reinterpret_cast<const u32x4q*>(src + 32 * j);
+#pragma unroll
+        for (int j = 0; j < HD / 32; ++j) *reinterpret_cast<u32x4q*>(Qs + row * LDQ + seg + 32 * j) = qv[j];
+    }
+    __syncthreads();
+
+    f32x16q O0[VW], O1[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { O0[c][r] = 0.f; O1[c][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const unsigned* q_frag = Qs + li * LDQ + 4 * lh;
+    const unsigned* p1_frag = P1 + li * LDP + 4 * lh;
+    const unsigned* p2_frag = P2 + li * LDP + 4 * lh;
+
+    for (int st0 = 0; st0 < key_limit; st0 += 128) {
+        const int key0 = st0 + wid * 32;
+        const bool active = key0 < key_limit;           // wave-uniform
+        f32x16q S;
+        float mt = -INFINITY;
+        if (active) {
+            f32x16q S0, S1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S0[r] = 0.f; S1[r] = 0.f; }
+            const int k_soff = st0 * ld3 * 4;
+            u32x4q qb[QP];
+#pragma unroll
+            for (int u = 0; u < QP; ++u) qb[u] = *reinterpret_cast<const u32x4q*>(q_frag + 8 * u);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < ((ATH_DBG & 1) ? 1 : NSTEP); ++u) {
+                const u32x4q kw = kb[u % KD];
+                const u32x4q qw = qb[u % QP];
+                u32x4q f1, f2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f1[e] = qw[e] & 0xffffu; f2[e] = __builtin_amdgcn_alignbit(qw[e], qw[e], 16); }
+                S0 = ATH_MFMA(kw, f1, S0);
+                S1 = ATH_MFMA(kw, f2, S1);
+                if (u + QP < NSTEP) qb[u % QP] = *reinterpret_cast<const u32x4q*>(q_frag + 8 * (u + QP));
+                if (!(ATH_DBG & 8) && u + KD < NSTEP)  // refill AFTER the slot's MFMAs in program order: no register copies
+                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
+                // pinned: the step's eight VALU, its two MFMAs, then the Q read of step u + QP and the K load of step u + KD
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (u + QP < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (!(ATH_DBG & 8) && u + KD < NSTEP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = __builtin_fmaf(S1[r], H2_LO_UNSCALE, S0[r]) * qscale;
+            if (key0 + 31 > q0) {                      // the sub-tile touches the diagonal (or runs past T): mask
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    S[r] = (key <= qidx) ? S[r] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, S[r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        }
+        const int ngroups = (min(128, key_limit - st0) + 7) >> 3;      // 8-key groups of the P.V phase, wave-uniform
+        const int v_soff = st0 * ld3 * 4;
+        u32x4q vb[VD][VW];                              // vb[u][j][c] = V word of key 8 (s0 + u) + 4 lh + c, column tile j
+#define ATH_VLOAD(U, SG)                                                                            \
+    {                                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                               \
+            _Pragma("unroll") for (int j = 0; j < VW; ++j)                                          \
+                vb[U][j][c] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_voff, v_soff + ((8 * (SG) + c) * ld3 + 32 * j) * 4, 0); \
+    }
+#pragma unroll
+        for (int u = 0; u < VD; ++u) ATH_VLOAD(u, u)
+        if (lh == 0) red[wid * 32 + li] = mt;
+        if (!(ATH_DBG & 4)) __syncthreads();
+        const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
+        const float m_new = fmaxf(m_run, m_tile);      // finite from the first super-tile on (key 0 is never masked)
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        float ps = 0.f;
+        if (active) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(S[4 * g + e] - m_new);
+                ps += (p[0] + p[1]) + (p[2] + p[3]);
+                unsigned a[4], b[4];
+                h2_forms(p[0], p[1], a[0], a[1], b[0], b[1]);
+                h2_forms(p[2], p[3], a[2], a[3], b[2], b[3]);
+                const u32x4q f1 = {a[0], a[1], a[2], a[3]}, f2 = {b[0], b[1], b[2], b[3]};
+                const int po = li * LDP + wid * 32 + 8 * g + 4 * lh;                      // keys 8g + 4lh + 0..3
+                *reinterpret_cast<u32x4q*>(P1 + po) = f1;
+                *reinterpret_cast<u32x4q*>(P2 + po) = f2;
+            }
+            ps += __shfl_xor(ps, 32, 64);
+        }
+        if (lh == 0) red[128 + wid * 32 + li] = ps;
+        if (!(ATH_DBG & 4)) __syncthreads();
+        l_run = l_run * alpha + ((red[128 + li] + red[160 + li]) + (red[192 + li] + red[224 + li]));
+        if (__any(alpha != 1.0f && m_run != -INFINITY)) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { O0[c][r] *= alpha; O1[c][r] *= alpha; }
+        }
+        m_run = m_new;
+        // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P[q][key], 8 keys per group:
+        // lane half lh handles keys 8s + 4lh + c (c = 0..3) -- the four words of its ds_read_b128 of each P form
+        if (!(ATH_DBG & 8) && st0 + 128 + wid * 32 < key_limit) {         // this wave's K rows of the next super-tile
+            const int kn_soff = (st0 + 128) * ld3 * 4;
+#pragma unroll
+            for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
+        }
+        // the P forms of group s + 1 are read before the MFMAs of group s (a group is 2 VW MFMAs: 64-128 cycles, the LDS latency);
+        // group 16 does not exist: its read stays inside the row (LDP = 132) and is never used
+        u32x4q pn1 = *reinterpret_cast<const u32x4q*>(p1_frag), pn2 = *reinterpret_cast<const u32x4q*>(p2_frag);
+        for (int s0 = 0; s0 < ((ATH_DBG & 2) ? min(ngroups, 1) : ngroups); s0 += VD) {
+#pragma unroll
+            for (int u = 0; u < VD; ++u) {
+                const int sg = s0 + u;
+                if (sg < ngroups) {
+                    const u32x4q pf1 = pn1, pf2 = pn2;
+                    pn1 = *reinterpret_cast<const u32x4q*>(p1_frag + 8 * (sg + 1));
+                    pn2 = *reinterpret_cast<const u32x4q*>(p2_frag + 8 * (sg + 1));
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        O0[j] = ATH_MFMA(vb[u][j], pf1, O0[j]);
+                        O1[j] = ATH_MFMA(vb[u][j], pf2, O1[j]);
+                    }
+                    if (!(ATH_DBG & 16)) ATH_VLOAD(u, sg + VD)             // refill behind the slot's MFMAs; past the range: zeros
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * VW, 0);
+                    if (!(ATH_DBG & 16)) __builtin_amdgcn_sched_group_barrier(0x020, 4 * VW, 0);
+                }
+            }
+        }
+#undef ATH_VLOAD
+    }
+    // ---- join the two sets, normalise, transpose through LDS (re-using the Q / P buffers), coalesced row stores
+    __syncthreads();
+    constexpr int LDO = HD + 4;                         // (16-byte rows: one ds_read_b128 per lane and output piece)
+    float* Os = reinterpret_cast<float*>(ldsw);
+    {
+        const float inv = H2_A_UNSCALE / l_run;
+#pragma unroll
+        for (int j = 0; j < VW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = wid * CW + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Os[li * LDO + c] = __builtin_fmaf(O1[j][r], H2_LO_UNSCALE, O0[j][r]) * inv;
+            }
+    }
+    __syncthreads();
+    for (int q = wid; q < 32; q += 4) {
+        if (q0 + q >= T) break;
+        float* dst = out + (rowb + q0 + q) * d + (long long)h * HD;
+        for (int c = lane * 4; c < HD; c += 256)
+            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(&Os[q * LDO + c]);
+    }
+}
+
+template <int HD>
+static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, hipStream_t s) {
+    const size_t lds = ((size_t)32 * (HD + 4) + 2 * 32 * 132 + 256) * 4;   // >= the [32][HD+4] output tile
+    if (lds > 64 * 1024) {
+        static bool raised = false;                     // (one process drives one device: include/r4d.h, PROCESS MODEL)
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)attn_h2_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("attention_h2: cannot raise the dynamic LDS limit");
+                return R4D_ERR_HIP;
+            }
+            raised = true;
+        }
+    }
+    ProfScope prof(PK_ATTN_FUSED, flop, s);
+    const int ntq = cdiv(Tmax, 32);
+    const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
+    R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
+    hipLaunchKernelGGL((attn_h2_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
+                       (float)(16.0 * 1.4426950408889634 / sqrt((double)HD)), out);
+    R4D_CHECK_LAUNCH("attn_h2");
+    return R4D_OK;
+}
+
+bool attention_h2_supported(int H, int d) {
+    if (H < 1 || d % H) return false;
+    const int hd = d / H;
+    return hd == 128 || hd == 256;
+}
+
+// Attention of n <= ATT_MAXG batches in one launch (launch_attention_fused_groups's contract) on h2 words
+int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
+                               float* out, hipStream_t s) {
+    R4D_REQUIRE(qkv && out, "attention_h2: null pointer");
+    R4D_REQUIRE(attention_h2_supported(H, d), "attention_h2: head_dim %d has no instantiation (128 / 256)", H > 0 ? d / H : 0);
+    R4D_REQUIRE(n >= 1 && n <= ATT_MAXG, "attention_h2: %d batches per launch (max %d)", n, ATT_MAXG);
+    const int hd = d / H;
+    AttnGroups G;
+    G.n = n;
+    G.seq_prefix[0] = 0;
+    int Tmax = 0;
+    double flop = 0.0;                                  // causal half of Q.K^T and P.V: 2 * T^2 * hd per head
+    for (int g = 0; g < n; ++g) {
+        R4D_REQUIRE(Bs[g] >= 1 && Ts[g] >= 1 && (long long)Ts[g] * 3 * d < (1ll << 29), "attention_h2: batch %d: B=%d T=%d", g, Bs[g], Ts[g]);
+        G.seq_prefix[g + 1] = G.seq_prefix[g] + Bs[g];
+        G.T[g] = Ts[g];
+        G.row0[g] = row0s[g];
+        if (Ts[g] > Tmax) Tmax = Ts[g];
+        flop += 2.0 * Bs[g] * H * (double)Ts[g] * Ts[g] * hd;
+    }
+    for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
+    R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention_h2: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
+    if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128>(qkv, G, Tmax, flop, H, d, out, s); }
+    R4D_BRANCH(ATT_H2_256);
+    return launch_ah2<256>(qkv, G, Tmax, flop, H, d, out, s);
+}
+
+int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s) {
+    R4D_REQUIRE(x && words && n >= 1 && n < (1ll << 39), "pack_h2_words: bad arguments");
+    hipLaunchKernelGGL(pack_h2_words_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, s, x, n, words);
+    R4D_CHECK_LAUNCH("pack_h2_words");
+    return R4D_OK;
+}
+
+int dbgflag_att_h2() { return ATH_DBG != 0; }
+
+}  // namespace r4d
+
+using namespace r4d;
+
+extern "C" {
+
+int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream) {
+    return launch_pack_h2_words(x_d, n, words_d, (hipStream_t)stream);
+}
+
+int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream) {
+    R4D_REQUIRE(B >= 1 && T >= 1, "attention_h2: B=%d T=%d", B, T);
+    const long long row0 = 0;
+    return launch_attention_h2_groups(qkv_words_d, 1, &B, &T, &row0, n_head, d, a_d, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -70,7 +70,7 @@ struct ProfScope {
     X(SK16_SPLITK, "skinny16:split-K last-arriver") X(SK8_NG2, "skinny8:ng2") X(SK8_NG3, "skinny8:ng3")                    \
     X(SK8_LN, "tuning:skinny8:+layernorm") X(SK8_SPLITK, "skinny8:split-K + epilogue launch") X(SK_PLAIN, "skinny:plain + epilogue launch") \
     X(ATT_KS32, "attention:key-split hd32") X(ATT_KS64, "attention:key-split hd64") X(ATT_CS96, "attention:column-split hd96") \
-    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256")                              \
+    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256") X(ATT_H2_128, "attention:f16x2 hd128") X(ATT_H2_256, "attention:f16x2 hd256")                              \
     X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
     X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
     X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \
@@ -98,7 +98,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 enum GemmEpilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_SCALE_DIV = 3, EPI_HALF_PLUS = 4,
                     // gemm_s3 only (training): GELU_KEEP writes gelu(v) to C and the pre-activation v to the `resid` buffer;
                     // GELU_GRAD writes v * gelu'(u) with u read from the `resid` buffer
-                    EPI_GELU_KEEP = 5, EPI_GELU_GRAD = 6 };
+                    EPI_GELU_KEEP = 5, EPI_GELU_GRAD = 6,
+                    // gemm_h2 only: C receives the result as uint32 "h2 words" (fp16 hi | fp16 lo' << 16 of value / 4: csrc/h2.h), the
+                    // operand format of attention_h2.hip
+                    EPI_H2WORDS = 7 };
 enum GemmCausal { CAUSAL_NONE = 0, CAUSAL_QK = 1, CAUSAL_PV = 2 };
 
 struct GemmArgs {
@@ -212,6 +215,21 @@ struct GreedyState {
 // clearing of `n_zero` 32-bit words (the step's split-K ticket counters)
 struct GreedyEmbed { const float* wte; const float* wpe; float* x_out; unsigned* zero_words; int vocab, n_positions, d, n_zero; };
 int launch_greedy_advance(const float* logits, int B, int V, const GreedyState& st, hipStream_t s, const GreedyEmbed* embed = nullptr);
+// Up to ATT_MAXG right-padded batches (each with its own T) in ONE attention launch: the workgroup index walks the sequences
+// of all batches; the batch of a sequence is found by a short scan of the prefix table (kernel argument, by value).
+struct AttnGroups {
+    int n;
+    int seq_prefix[ATT_MAXG + 1];     // first global sequence index of each batch
+    int T[ATT_MAXG];
+    long long row0[ATT_MAXG];         // first token row of each batch in qkv / out
+};
+// attention_h2.hip: the same attention on the fp16 matrix cores (f16x2 form), qkv as uint32 "h2 words" (csrc/h2.h; written by
+// gemm_h2's EPI_H2WORDS epilogue or launch_pack_h2_words); head_dim 128 / 256 (attention_h2_supported)
+bool attention_h2_supported(int H, int d);
+int launch_attention_h2_groups(const unsigned* qkv_words, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
+                               float* out, hipStream_t s);
+int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s);
+int dbgflag_att_h2();
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation
 int launch_attention_fused(const float* qkv, int B, int T, int H, int d, float* out, hipStream_t s);
 int launch_attention_fused_groups(const float* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H,

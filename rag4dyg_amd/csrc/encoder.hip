@@ -25,7 +25,7 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
                                   sk_counters_zeroed);
     // f16x2 planes present and selected: fp16 matrix cores, three products per fp32 product, fp32 accuracy (gemm_h2.hip).
     // NOT gated on M, like the bf16x3 branch below
-    if (w2h && g_gemm_split3 == 2 && epilogue <= EPI_RESIDUAL && gemm_h2_supported(M, K, N)) {
+    if (w2h && g_gemm_split3 == 2 && (epilogue <= EPI_RESIDUAL || epilogue == EPI_H2WORDS) && gemm_h2_supported(M, K, N)) {
         S3Args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.planes = w2h; a.C = y; a.bias = bias; a.resid = resid;
@@ -41,6 +41,7 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
         a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
         return launch_gemm_s3(a, s);
     }
+    R4D_REQUIRE(epilogue != EPI_H2WORDS, "conv1d: the h2-word epilogue exists in the f16x2 GEMM only");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = x; g.C = y; g.bias = bias; g.resid = resid;
@@ -60,6 +61,7 @@ static inline int tpad(int T) { return (T + 127) / 128 * 128; }
 // into the merged-head layout.  The B*H*T*T score block (29 MB at the worst UCI_13 batch) stays in
 // the 256 MB Infinity Cache between the launches.
 int g_attention_fused = -1;           // -1 auto (by head_dim), 0 three launches, 1 fused wherever instantiated
+int g_attention_h2 = 1;               // r4d_set_attention_h2: in f16x2 mode, head_dim 128 / 256 on the fp16 matrix cores (attention_h2.hip)
 
 static int attention(const float* qkv, int B, int T, int H, int d, float* a_out, float* scores, hipStream_t s) {
     // Measured on MI355X (tools/attn_bench.py, B=128, T=128..300): the fused kernels are 1.15-2.7x faster than the
@@ -148,7 +150,7 @@ extern "C" {
 
 int r4d_abi_version(void) { return R4D_ABI_VERSION; }
 int r4d_build_flags(void) {
-    return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4) | (dbgflag_s3() << 5) | (dbgflag_h2() << 6);
+    return dbgflag_kc() | (dbgflag_att() << 1) | (dbgflag_sk() << 2) | (dbgflag_jac() << 3) | (dbgflag_scan() << 4) | (dbgflag_s3() << 5) | (dbgflag_h2() << 6) | (dbgflag_att_h2() << 7);
 }
 int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* ln_b_d, int32_t N, int32_t K, float* wTg_d,
                            float* lnc_d, void* stream) {
@@ -157,6 +159,12 @@ int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* 
 
 int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode == 2 ? 2 : (mode != 0); return R4D_OK; }
 int r4d_get_gemm_split3(void) { return g_gemm_split3; }
+int r4d_set_attention_h2(int32_t on) {
+    const int prev = g_attention_h2;
+    g_attention_h2 = on != 0;
+    return prev;
+}
+
 int r4d_set_attention_fused(int32_t mode) {
     // mode 2: fused with the key-split kernel forced at head_dim 96/128/256 (A/B tuning); 1: fused (column-split there)
     g_attention_variant = (mode == 2) ? 1 : 0;
@@ -242,9 +250,27 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             return R4D_ERR_HIP;
         }
         float* qkv = out_qkv_d ? out_qkv_d + (size_t)l * M * 3 * d : ws.qkv;
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2))) return rc;
+        // f16x2 mode, head_dim 128 / 256, qkv not handed out: c_attn writes h2 words (csrc/h2.h) and the attention runs on
+        // the fp16 matrix cores (attention_h2.hip); every other case: fp32 qkv and the exact-f32 kernels below
+        bool words = !out_qkv_d && g_attention_h2 && g_attention_fused != 0 && g_gemm_split3 == 2 && L.c_attn_h2 &&
+                     attention_h2_supported(H, d) && gemm_h2_supported(M, d, 3 * d);
+        for (int g0 = 0; g0 < n_groups && words; g0 += ATT_MAXG) {
+            int nseq = 0;
+            for (int j = g0; j < n_groups && j < g0 + ATT_MAXG; ++j) nseq += groups[j].B;
+            if (nseq > 65535) words = false;
+        }
+        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2))) return rc;
         bool fused_done = false;
-        if (g_attention_fused != 0) {                    // all batches of the call in ceil(n/16) fused launches
+        if (words) {
+            fused_done = true;
+            for (int g0 = 0; g0 < n_groups; g0 += ATT_MAXG) {
+                int Bs[ATT_MAXG], Ts[ATT_MAXG];
+                long long r0[ATT_MAXG];
+                const int n = n_groups - g0 < ATT_MAXG ? n_groups - g0 : ATT_MAXG;
+                for (int j = 0; j < n; ++j) { Bs[j] = groups[g0 + j].B; Ts[j] = groups[g0 + j].T; r0[j] = (long long)groups[g0 + j].row0; }
+                if ((rc = launch_attention_h2_groups(reinterpret_cast<const unsigned*>(qkv), n, Bs, Ts, r0, H, d, ws.att, s))) return rc;
+            }
+        } else if (g_attention_fused != 0) {             // all batches of the call in ceil(n/16) fused launches
             fused_done = true;
             for (int g0 = 0; g0 < n_groups && fused_done; g0 += ATT_MAXG) {
                 int Bs[ATT_MAXG], Ts[ATT_MAXG];

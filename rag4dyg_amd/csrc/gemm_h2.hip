@@ -20,13 +20,14 @@
 // are checked when their planes are made (|w| < 6e4, ops.split2_planes) and keep the bf16x3 planes otherwise.
 //
 // Operands: A is the fp32 activation [M,K], split on the fly while its tile is staged; W is a STATIC weight, split once per
-// checkpoint into two k-contiguous fp16 planes [2][N][K] (r4d_split2_planes_f16).  Tile structure, LDS image (64-byte rows,
+// checkpoint into fp16 lines [N][K/32][2][32] -- 32 hi and 32 lo' values per 128 bytes -- (r4d_split2_planes_f16).  Tile structure, LDS image (64-byte rows,
 // 16-byte chunk index XOR (row >> 2) & 3), buffer loads, register-staged pipeline and the pinned MFMA / DS / VMEM interleaving
 // are those of gemm_s3.hip with two planes per operand instead of three: a stage of the 128 x 256 tile is 48 KB, so THREE
 // stages fit (144 KB) where bf16x3 had room for two.
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#include "h2.h"
 
 #ifndef H2_DBG
 #define H2_DBG 0   // tuning aid (tools/kc_ablate.sh gemm_h2.hip H2_DBG n): bit 0 drops the fragment reads, bit 1 the LDS staging stores (and the split), bit 2 the barrier, bit 3 the global loads, bit 5 the epilogue, bit 6 the MFMAs
@@ -38,26 +39,9 @@ typedef float f32x16h __attribute__((ext_vector_type(16)));
 typedef float f32x2h __attribute__((ext_vector_type(2)));
 typedef float f32x4h __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2h __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
-
-constexpr float H2_A_PRESCALE = 0.25f;        // 2^-2 on the activation operand (exact), undone in the epilogue
-constexpr float H2_A_UNSCALE = 4.0f;
-constexpr float H2_LO_SCALE = 2048.0f;        // 2^11 on the second term of BOTH operands
-constexpr float H2_LO_UNSCALE = 1.0f / 2048.0f;
-
-// two fp32 -> packed (hi, hi), (lo', lo') of x * PRE
-template <bool PRESCALE>
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
-    f32x2h v = {x0, x1};
-    if (PRESCALE) v = v * H2_A_PRESCALE;
-    const f16x2h hh = __builtin_convertvector(v, f16x2h);            // v_cvt_pk_f16_f32: RNE
-    const f32x2h hf = __builtin_convertvector(hh, f32x2h);
-    const f32x2h r = (v - hf) * H2_LO_SCALE;                          // exact
-    const f16x2h ll = __builtin_convertvector(r, f16x2h);
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, ll);
-}
 
 __device__ __forceinline__ f32x2h gelu_new_h2(f32x2h x) {            // the epilogue of gemm_s3.hip / gemm_f32_kc.hip, same instructions
     const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f * k0;
@@ -77,11 +61,14 @@ __device__ __forceinline__ float gelu_new_h2_1(float x) {
 
 struct H2Shape {
     int M, N, K, lda, ldc, ldr;
-    int plane_bytes;          // N * K * 2: distance between the two fp16 planes of W
+    int plane_bytes;          // N * K * 2: half the size of W's fp16 lines
 };
 
 // ---------------------------------------------------------------------------------------------- weight planes
 // w element (n, k) at w[k * ld_k + n * ld_n]  (reference Conv1D layout [K,N]: ld_k = N, ld_n = 1; a [N,K] copy: 1, K)
+// Plane layout [N][K/32][2][32] fp16: the 32 hi values of row n, k-tile kt and its 32 lo' values are ONE 128-byte line -- the
+// unit the vector L1 fetches from L2 -- so a k-tile of the GEMM reads whole lines (two planes [2][N][K], the round-4 first
+// form, made every k-tile fetch the 64-byte halves of twice as many lines, the other halves evicted before the next k-tile).
 __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restrict__ w, int N, int K, long long ld_k,
                                                             long long ld_n, unsigned short* __restrict__ planes) {
     __shared__ float tile[32][33];
@@ -95,31 +82,33 @@ __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restr
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {                                // write along k
-        const int n = n0 + r, k = k0 + tx;
-        if (n >= N || k >= K) continue;
+        const int n = n0 + r;
+        if (n >= N) continue;
         unsigned h, l;
         split2_pair<false>(tile[r][tx], 0.f, h, l);
-        const size_t o = (size_t)n * K + k, P = (size_t)N * K;
+        const size_t o = ((size_t)n * (K >> 5) + blockIdx.y) * 64 + tx;
         planes[o] = (unsigned short)(h & 0xffffu);
-        planes[P + o] = (unsigned short)(l & 0xffffu);
+        planes[o + 32] = (unsigned short)(l & 0xffffu);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- the GEMM
-// BF32: the second operand is NOT pre-split -- Bp points at fp32 rows [N][K] that are split on the fly like A, without the
-// activation pre-scale (the normalised pool of the retrieval scoring GEMM: |x| <= 1)
-template <int BM, int BN, int WGM, int WGN, int EPI, bool BF32 = false>
+template <int BM, int BN, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kernel(
     const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
     const float* __restrict__ biasg, const float* __restrict__ residg, const H2Shape g) {
     constexpr int BK = 32;
     constexpr int NTHREADS = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    constexpr int NIA = BM * 4 / NTHREADS, NIB = BN * 4 / NTHREADS;   // (row, 8-k chunk) items per thread
-    constexpr int A_PLANE = BM * 4, B_PLANE = BN * 4;                 // uint4 units (a row = 4 chunks of 16 bytes)
-    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    // Staging moves WHOLE 128-byte lines per wave-instruction: a k-tile of an A row is one line of fp32 (32 k), a k-tile of a W
+    // row one line of fp16 (32 hi + 32 lo'); eight consecutive lanes take the eight 16-byte pieces of one line, a wave eight lines.
+    constexpr int NLA = BM * 8 / NTHREADS, NLB = BN * 8 / NTHREADS;   // (row, 16-byte piece) items per thread
+    constexpr int A_PLANE = BM * 4, B_PLANE = BN * 4;                 // uint4 units (an image row = 32 k of one plane = 4 chunks of 16 bytes)
+    constexpr int B_SKEW = 4;                                         // W's lo' plane starts 64 bytes past a multiple of 128: the eight lanes of a line store its hi and lo' halves in one ds_write_b128 group, and those must not share banks
+    constexpr int B_PLANE1 = B_PLANE + B_SKEW;
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE) + B_SKEW;
     constexpr int NBUF = 3;                                           // LDS stages (48 KB each at 128 x 256)
-    static_assert(NIA >= 1 && NIB >= 1 && NIA <= 2 && NIB <= 2 && TM >= 1 && TN >= 1, "tile");
+    static_assert(NLA >= 1 && NLB >= 1 && NLA <= 4 && NLB <= 8 && TM >= 1 && TN >= 1, "tile");
     __shared__ u32x4h lds[NBUF * STAGE];
 
     // XCD-aware grouped tile order (gemm_f32_kc.hip)
@@ -138,70 +127,49 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
     const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 31, lh = lane >> 5;
 
-    int a_off[NIA], b_off[NIB], a_dst[NIA], b_dst[NIB];
+    int a_off[NLA], b_off[NLB], a_dst[NLA], b_dst[NLB];
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) {
-        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
-        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + c * 8) * 4;
-        a_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    for (int i = 0; i < NLA; ++i) {                                  // piece c of the line = k 4c .. 4c+3 -> half (c & 1) of image chunk c >> 1
+        const int idx = tid + i * NTHREADS, row = idx >> 3, c = idx & 7;
+        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + c * 4) * 4;
+        a_dst[i] = (row * 4 + ((c >> 1) ^ ((row >> 2) & 3))) * 2 + (c & 1);      // 8-byte units
     }
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) {
-        const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
-        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * (BF32 ? 4 : 2);
-        b_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
+    for (int i = 0; i < NLB; ++i) {                                  // piece c of the line = chunk c & 3 of plane c >> 2
+        const int idx = tid + i * NTHREADS, row = idx >> 3, c = idx & 7;
+        b_off[i] = (min(n0 + row, g.N - 1) * g.K * 2 + c * 8) * 2;
+        b_dst[i] = (c >> 2) * B_PLANE1 + row * 4 + ((c & 3) ^ ((row >> 2) & 3));
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Ag), 0, (int)(((long long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(Bp), 0, BF32 ? (int)((long long)g.N * g.K * 4) : 2 * g.plane_bytes, 0x00020000);
+        const_cast<unsigned short*>(Bp), 0, 2 * g.plane_bytes, 0x00020000);
 
-    u32x4h ra[NIA][2], rb[NIB][2];                       // BF32: rb[..][0..1] = the 8 fp32 of the item; else the two planes' chunks
+    u32x4h ra[NLA], rb[NLB];
 #define H2_LOAD(KT)                                                                                \
     {                                                                                              \
         const int kt_ = min((KT), nkt - 1);                                                        \
-        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
-            ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
-            ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
-        }                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
-            if (BF32) {                                                                            \
-                rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 4), 0); \
-                rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i] + 16, kt_ * (BK * 4), 0); \
-            } else {                                                                               \
-                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                      \
-                    rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
-            }                                                                                      \
-        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NLB; ++i)                                            \
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * 128, 0);         \
+        _Pragma("unroll") for (int i = 0; i < NLA; ++i)                                            \
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * 128, 0);         \
     }
 #define H2_STORE(STG)                                                                              \
     {                                                                                              \
         u32x4h* sa_ = lds + (STG) * STAGE;                                                         \
+        u32x2h* sa2_ = reinterpret_cast<u32x2h*>(sa_);                                             \
         u32x4h* sb_ = sa_ + 2 * A_PLANE;                                                           \
-        _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
-            u32x4h h_, l_;                                                                         \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
-                /* (cast the WHOLE vector: __builtin_bit_cast on an ext-vector element reads element 0) */ \
-                const f32x4h src_ = __builtin_bit_cast(f32x4h, ra[i][q >> 1]);                     \
-                unsigned hh_, ll_;                                                                 \
-                split2_pair<true>(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, ll_);             \
-                h_[q] = hh_; l_[q] = ll_;                                                          \
-            }                                                                                      \
-            sa_[a_dst[i]] = h_; sa_[A_PLANE + a_dst[i]] = l_;                                      \
-        }                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
-            if (BF32) {                                                                            \
-                u32x4h h_, l_;                                                                     \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
-                    const f32x4h src_ = __builtin_bit_cast(f32x4h, rb[i][q >> 1]);                 \
-                    unsigned hh_, ll_;                                                             \
-                    split2_pair<false>(src_[(q & 1) * 2], src_[(q & 1) * 2 + 1], hh_, ll_);        \
-                    h_[q] = hh_; l_[q] = ll_;                                                      \
-                }                                                                                  \
-                sb_[b_dst[i]] = h_; sb_[B_PLANE + b_dst[i]] = l_;                                  \
-            } else {                                                                               \
-                _Pragma("unroll") for (int p = 0; p < 2; ++p) sb_[p * B_PLANE + b_dst[i]] = rb[i][p]; \
-            }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NLB; ++i) sb_[b_dst[i]] = rb[i];                     \
+        _Pragma("unroll") for (int i = 0; i < NLA; ++i) {                                          \
+            /* (cast the WHOLE vector: __builtin_bit_cast on an ext-vector element reads element 0) */ \
+            const f32x4h src_ = __builtin_bit_cast(f32x4h, ra[i]);                                 \
+            u32x2h h_, l_;                                                                         \
+            unsigned hh_, ll_;                                                                     \
+            split2_pair<true>(src_[0], src_[1], hh_, ll_);                                         \
+            h_[0] = hh_; l_[0] = ll_;                                                              \
+            split2_pair<true>(src_[2], src_[3], hh_, ll_);                                         \
+            h_[1] = hh_; l_[1] = ll_;                                                              \
+            sa2_[a_dst[i]] = h_; sa2_[2 * A_PLANE + a_dst[i]] = l_;                                \
         }                                                                                          \
     }
 
@@ -230,7 +198,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
         _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][1] = (H2_DBG & 1) ? dbg_frag : st_[fa_base + 1 * A_PLANE + i * 128 + fo_]; \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][0] = (H2_DBG & 1) ? dbg_frag : st_[fb_base + 0 * B_PLANE + j * 128 + fo_]; \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[SET][i][0] = (H2_DBG & 1) ? dbg_frag : st_[fa_base + 0 * A_PLANE + i * 128 + fo_]; \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = (H2_DBG & 1) ? dbg_frag : st_[fb_base + 1 * B_PLANE + j * 128 + fo_]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = (H2_DBG & 1) ? dbg_frag : st_[fb_base + B_PLANE1 + j * 128 + fo_]; \
     }
     /* consecutive MFMAs go to different accumulators; the two writes of one acc1 tile are TM TN instructions apart */
 #define H2_MFMAS(SET)                                                                              \
@@ -253,32 +221,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
 
     // Three LDS stages, ONE barrier per k-tile, every fragment read under MFMAs.  Iteration kt enters with fragment set 0 = k-step 0
     // of stage CUR = kt % 3 and the staging registers = k-tile kt + 2 (requested during iteration kt - 1):
-    //   k-step 0's MFMAs with, between them, the reads of k-step 1 (set 1), the split of the staged A elements and the LDS stores
-    //   of k-tile kt + 2 into stage WR = (kt + 2) % 3 -- read last in iteration kt - 1, every wave is past that barrier;
-    //   k-step 1's MFMAs with the global loads of k-tile kt + 3 and the reads of k-step 0 of stage NXT = (kt + 1) % 3 (set 0
-    //   again) -- stored during iteration kt - 1, i.e. in front of the same barrier;
+    //   k-step 0's MFMAs with, between them, the reads of k-step 1 (set 1) and, item by item, the LDS store of a staged piece of
+    //   k-tile kt + 2 into stage WR = (kt + 2) % 3 (read last in iteration kt - 1, every wave is past that barrier; the A pieces
+    //   are split on the way) FOLLOWED AT ONCE BY THE GLOBAL LOAD of the same piece of k-tile kt + 3 into the registers it just
+    //   left: a load is consumed a whole iteration (~ 22 MFMAs, 700 cycles) after its issue.  (First form of round 4: the loads
+    //   in the second half, consumed 7 MFMAs later -- every k-tile began with a few hundred cycles of s_waitcnt vmcnt; MFMA
+    //   pipe 45-52 % busy);
+    //   k-step 1's MFMAs with the reads of k-step 0 of stage NXT = (kt + 1) % 3 (set 0 again) -- stored during iteration
+    //   kt - 1, i.e. in front of the same barrier;
     //   barrier.
-    constexpr int NMF = 3 * TM * TN, NFR = 2 * (TM + TN), NDW = 2 * (NIA + NIB), NVM = 2 * NIA + 2 * NIB;
-    static_assert(NMF >= NFR && NMF >= NVM && NMF >= NDW, "interleave");
+    constexpr int NMF = 3 * TM * TN, NFR = 2 * (TM + TN);
+    static_assert(NMF >= NFR && NMF >= NLA + NLB, "interleave");
 #define H2_ITER(CUR, NXT, WR)                                                                      \
     {                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (!(H2_DBG & 2)) H2_STORE(WR)                                                            \
+        if (!(H2_DBG & 8)) H2_LOAD(kt + 3)                                                         \
         H2_FRAGS(1, CUR, 1)                                                                        \
         H2_MFMAS(0)                                                                                \
         _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
             if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                     \
-            if (m_ >= NMF - NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            if (m_ < NLB) {                                  /* a W piece: store, reload */        \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+            } else if (m_ < NLB + NLA) {                     /* an A piece: split, store, reload */ \
+                __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);                                \
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+            }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (!(H2_DBG & 8)) H2_LOAD(kt + 3)                                                         \
         H2_FRAGS(0, NXT, 0)                                                                        \
         H2_MFMAS(1)                                                                                \
         _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-            if (m_ < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
             if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -322,7 +299,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
     // lane stores 16 bytes per instruction, a quarter of the store instructions -- was built in round 4 and REMOVED: no faster
     // (c_attn 442 vs 430 us) and its GELU variant gave run-to-run different values in lanes 12-15 / 28-31 of each half-wave at some
     // shapes (scalar or packed arithmetic, with or without wait states; tools/h2_check.py now repeats every launch three times).
-    constexpr float UNS = BF32 ? 1.0f : H2_A_UNSCALE;
+    constexpr float UNS = H2_A_UNSCALE;
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
     if (interior) {
@@ -352,11 +329,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
                     if (EPI == EPI_GELU) v2 = gelu_new_h2(v2);
                     else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
                     else if (EPI == EPI_HALF_PLUS) { v2.x = (v2.x + 1.0f) / 2.0f; v2.y = (v2.y + 1.0f) / 2.0f; }     // train_retriever.py:438
+                    const float vx = v2.x, vy = v2.y;     // (copies first: __builtin_bit_cast on an ext-vector ELEMENT reads element 0)
+                    unsigned o2[2] = {__builtin_bit_cast(unsigned int, vx), __builtin_bit_cast(unsigned int, vy)};
+                    if (EPI == EPI_H2WORDS) h2_words<true>(v2.x, v2.y, o2[0], o2[1]);     // C is the uint32 word image of the result (attention_h2.hip)
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = r2 + h2;
-                        const float v = h2 ? v2.y : v2.x;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), c_rsrc, lane_c,
+                        __builtin_amdgcn_raw_buffer_store_b32(o2[h2], c_rsrc, lane_c,
                                                               ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
                     }
                 }
@@ -379,6 +358,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
                 if (EPI == EPI_GELU) v = gelu_new_h2_1(v);
                 else if (EPI == EPI_RESIDUAL) v += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
                 else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
+                else if (EPI == EPI_H2WORDS) { unsigned w0, w1; h2_words<true>(v, 0.f, w0, w1); v = __builtin_bit_cast(float, w0); }
                 if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
             }
         }
@@ -399,6 +379,7 @@ static int launch_h2(const S3Args& a, int cls, hipStream_t stream) {
         case EPI_NONE: H2_LAUNCH_(EPI_NONE); break;
         case EPI_GELU: H2_LAUNCH_(EPI_GELU); break;
         case EPI_RESIDUAL: H2_LAUNCH_(EPI_RESIDUAL); break;
+        case EPI_H2WORDS: H2_LAUNCH_(EPI_H2WORDS); break;
         default: set_error("gemm_h2: epilogue %d has no instantiation", a.epilogue); return R4D_ERR_INVALID;
     }
 #undef H2_LAUNCH_
@@ -432,6 +413,7 @@ int launch_gemm_h2(const S3Args& a, hipStream_t stream) {
 int launch_split2_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s) {
     R4D_REQUIRE(w && planes && N >= 1 && K >= 1, "split2_planes: bad arguments");
     R4D_REQUIRE(ld_n == 1 || ld_k == 1, "split2_planes: one of the two strides must be 1");
+    R4D_REQUIRE(K % 32 == 0, "split2_planes: K = %d is not a multiple of 32 (the plane layout is per 32-k line)", K);
     hipLaunchKernelGGL(split2_planes_kernel, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(256), 0, s, w, N, K, ld_k, ld_n, planes);
     R4D_CHECK_LAUNCH("split2_planes");
     return R4D_OK;

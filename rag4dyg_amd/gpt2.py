@@ -267,7 +267,7 @@ class GPT2Model(_PreTrained):
         return ent[1].data_ptr()
 
     def _h2(self, w):
-        """f16x2 planes [2,out,in] of a static Conv1D weight (``ops.split2_planes``), cached like ``_wt``; None unless
+        """f16x2 lines [out, in/32, 2, 32] of a static Conv1D weight (``ops.split2_planes``), cached like ``_wt``; None unless
         ``ops.gemm_mode() == "f16x2"``, and for a weight outside the fp16 range or a shape without a kernel."""
         if ops.gemm_mode() != "f16x2" or w.shape[0] % 32 != 0:
             return None

@@ -108,9 +108,10 @@ H2_MAX_WEIGHT = 6.0e4          # fp16 tops out at 65504: a weight beyond this ke
 
 
 def split2_planes(w, transposed=False):
-    """Static Conv1D weight [K,N] (``transposed``: an [N,K] copy) -> its two k-contiguous fp16 planes (hi, 2^11-scaled lo), a
-    uint16 tensor [2,N,K] (fp16 bit patterns): the operand format of :func:`conv1d_h2`.  None when the weight exceeds the fp16
-    range (one host read of the tensor's maximum, once per checkpoint)."""
+    """Static Conv1D weight [K,N] (``transposed``: an [N,K] copy) -> its two fp16 terms (hi, 2^11-scaled lo) as 128-byte lines,
+    a uint16 tensor [N, K/32, 2, 32] (fp16 bit patterns; ``[:, :, 0]`` = hi, ``[:, :, 1]`` = lo of 32 consecutive k): the operand
+    format of :func:`conv1d_h2`.  K must be a multiple of 32.  None when the weight exceeds the fp16 range (one host read of the
+    tensor's maximum, once per checkpoint)."""
     if transposed:
         N, K = w.shape
     else:
@@ -118,7 +119,9 @@ def split2_planes(w, transposed=False):
     amax = float(w.detach().abs().max())
     if not (amax < H2_MAX_WEIGHT):
         return None
-    planes = torch.empty(2, N, K, dtype=torch.int16, device=w.device)
+    if K % 32:
+        raise ValueError(f"split2_planes: K = {K} is not a multiple of 32")
+    planes = torch.empty(N, K // 32, 2, 32, dtype=torch.int16, device=w.device)
     check(_lib.load().r4d_split2_planes_f16(_dev(w, torch.float32, "w"), K, N, int(bool(transposed)), planes.data_ptr(),
                                             _stream()), "split2_planes")
     return planes
@@ -127,7 +130,7 @@ def split2_planes(w, transposed=False):
 def conv1d_h2(x, planes, bias, epilogue="none", residual=None):
     """:func:`conv1d` on the fp16 matrix cores at fp32 accuracy (two fp16 terms per operand, three partial products, two fp32
     accumulator sets); ``planes`` from :func:`split2_planes`.  |x| < 2^18."""
-    _, N, K = planes.shape
+    N, K = planes.shape[0], planes.shape[1] * 32
     M = x.numel() // K
     y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
     epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
@@ -180,6 +183,32 @@ def conv1d_s3(x, planes, bias, epilogue="none", residual=None):
 def set_attention_fused(mode):
     """-1 / None: auto by head_dim (default); True: fused flash-style kernel; False: three-launch GEMM form."""
     _lib.load().r4d_set_attention_fused(-1 if mode is None or mode == -1 else (2 if mode == 2 else int(bool(mode))))
+
+
+def set_attention_h2(on):
+    """In gemm mode "f16x2": head_dim 128 / 256 attention of the encoder on the fp16 matrix cores (csrc/attention_h2.hip; default
+    on).  Off: the exact-f32 attention kernels in every mode.  Returns the previous setting.  Process-wide: ranks must agree."""
+    return bool(_lib.load().r4d_set_attention_h2(int(bool(on))))
+
+
+def pack_h2_words(x):
+    """fp32 tensor -> its "h2 words" (int32 tensor of the same shape: fp16 hi | fp16 lo' << 16 of value / 4), the operand format of
+    :func:`attention_h2` -- what the f16x2 c_attn GEMM writes inside the encoder."""
+    x = x.contiguous()
+    w = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    check(_lib.load().r4d_pack_h2_words_f32(_dev(x, torch.float32, "x"), x.numel(), w.data_ptr(), _stream()), "pack_h2_words")
+    return w
+
+
+def attention_h2(qkv_words, n_head):
+    """:func:`attention` on the fp16 matrix cores at fp32 accuracy: ``qkv_words`` = :func:`pack_h2_words` of the packed c_attn
+    output [B,T,3d]; head_dim 128 / 256."""
+    B, T, d3 = qkv_words.shape
+    d = d3 // 3
+    a = torch.empty(B, T, d, dtype=torch.float32, device=qkv_words.device)
+    check(_lib.load().r4d_attention_h2_f32(_dev(qkv_words, torch.int32, "qkv_words"), B, T, n_head, d, a.data_ptr(), _stream()),
+          "attention_h2")
+    return a
 
 
 def attention(qkv, n_head):

@@ -118,6 +118,17 @@ def test_every_dispatcher_branch_is_exercised(dev):
                 gpt2_mod.FOLD_DECODE_LAYERNORM = fold_before
             assert rel_err(h2.cpu().numpy(), ref[:, 20].numpy()) < 1e-4, ("decode, unfolded LayerNorm", H, d)
 
+    # ---- f16x2 mode: head_dim 128 / 256 attention on the fp16 matrix cores, fed with h2 words by the c_attn GEMM (attention_h2.hip)
+    ops.set_gemm_mode("f16x2")
+    try:
+        for H, d in ((2, 256), (2, 512)):
+            sd, m = model(1, H, d)
+            out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
+            ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]
+            assert rel_err(out["hidden"].cpu().numpy(), ref.numpy()) < 1e-4, ("f16x2 attention", H, d)
+    finally:
+        ops.set_gemm_mode("bf16x3")
+
     # ---- pool scan variants (d), the short-shard form, the tiled-GEMM path (Q > 64), top-k forms, argsort forms
     def scan(Q, N, d, k=5):
         q, p = ops.normalize_rows(rnd(Q, d).to(dev)), ops.normalize_rows(rnd(N, d).to(dev))

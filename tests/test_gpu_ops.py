@@ -78,7 +78,7 @@ def test_conv1d_f16x2_all_epilogues_tiles_and_range(dev, M, K, N):
     ref = gpt2_ref.conv1d(x, w, b)
     xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
     p2, p3 = ops.split2_planes(wd), ops.split3_planes(wd)
-    hi, lo = p2.view(torch.float16)[0].double(), p2.view(torch.float16)[1].double()
+    hi, lo = (p2.view(torch.float16)[:, :, t].reshape(N, K).double() for t in (0, 1))      # lines [N, K/32, 2, 32]
     # the planes ARE the split: |w - (hi + 2^-11 lo')| <= 2^-22 |w|, with the absolute floor 2^-36 where hi is an fp16 subnormal (|w| < 6.1e-5)
     assert ((hi + lo / 2048.0 - wd.t().double()).abs() <= 2.0 ** -22 * wd.t().double().abs() + 2.0 ** -36).all()
     assert rel_err(ops.conv1d_h2(xd, p2, bd).cpu().numpy(), ref.numpy()) < 1e-5
@@ -171,6 +171,67 @@ def test_attention_oracle_shapes(dev, B, T, H, hd, attn_mode):
                              v.view(B, T, H, hd).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, T, d)
     out = ops.attention(qkv.to(dev), H).cpu()
     assert rel_err(out.numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["attn_hd128_T24_s1", "attn_hd256_T20_s1"])
+def test_attention_f16x2_golden(dev, tag):
+    """csrc/attention_h2.hip (fp16 matrix cores, q / k / v as "h2 words") on the reference's Attention._attn vectors."""
+    from rag4dyg_amd import ops
+    g = load_golden("g2_ops")
+    q, k, v, a = (torch.from_numpy(g[tag + s]) for s in ("_q", "_k", "_v", "_a"))
+    B, H, T, hd = q.shape
+    qkv = torch.cat([q.permute(0, 2, 1, 3).reshape(B, T, H * hd), k.permute(0, 3, 1, 2).reshape(B, T, H * hd),
+                     v.permute(0, 2, 1, 3).reshape(B, T, H * hd)], dim=2).contiguous()
+    out = ops.attention_h2(ops.pack_h2_words(qkv.to(dev)), H).cpu()
+    assert rel_err(out.numpy(), a.permute(0, 2, 1, 3).reshape(B, T, H * hd).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 128), (2, 129, 2, 256), (2, 339, 2, 256), (1, 1024, 2, 128), (2, 257, 6, 128),
+                                      (33, 31, 2, 256), (1, 512, 1, 256), (5, 160, 3, 128)])
+def test_attention_f16x2_words_against_float64(dev, B, T, H, hd):
+    """The h2 words ARE the split (value / 4 = hi + 2^-11 lo' to 2^-22); ``r4d_attention_h2_f32`` against the oracle at the
+    exact-f32 kernels' bound, and against a float64 attention beside the exact-f32 fused kernel on the same inputs: not a larger
+    error (x 1.25 + 2^-22, the words' own resolution) -- N(0,1), logits x 30 and an outlier head column x 100 (peaked softmaxes, logits of several hundred: the fp32 logits' own error
+    dominates and the 22 bits a word keeps of q and k count: x 2, comparison only), v of 3e3; three launches
+    give the same bits; beyond the fp16 range the output is NaN, never a quiet wrong number."""
+    from rag4dyg_amd import ops
+    from oracle import gpt2_ref
+    g = torch.Generator().manual_seed(T * 7 + hd)
+    d = H * hd
+    base = torch.randn(B, T, 3 * d, generator=g)
+    w = ops.pack_h2_words(base.to(dev))
+    hi = (w & 0xffff).to(torch.int16).view(torch.float16).double()
+    lo = ((w >> 16) & 0xffff).to(torch.int16).view(torch.float16).double()
+    x4 = base.to(dev).double() / 4
+    assert ((hi + lo / 2048.0 - x4).abs() <= 2.0 ** -22 * x4.abs() + 2.0 ** -36).all()
+
+    def ref64(qkv):
+        q, k, v = qkv.double().split(d, dim=2)
+        return gpt2_ref.attn_core(q.view(B, T, H, hd).permute(0, 2, 1, 3), k.view(B, T, H, hd).permute(0, 2, 3, 1),
+                                  v.view(B, T, H, hd).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, T, d)
+    for kind in ("N(0,1)", "logits x 30", "3e3", "outlier"):
+        qkv = base.clone()
+        if kind == "logits x 30":
+            qkv[:, :, :d] *= 30.0
+        elif kind == "3e3":
+            qkv[:, :, 2 * d:] *= 3e3
+        elif kind == "outlier":
+            qkv[:, :, 5::hd] *= 100.0
+        ref = ref64(qkv)
+        qd = qkv.to(dev)
+        words = ops.pack_h2_words(qd)
+        out = ops.attention_h2(words, H)
+        assert all(torch.equal(out, ops.attention_h2(words, H)) for _ in range(2)), kind
+        ops.set_attention_fused(True)
+        try:
+            f32 = ops.attention(qd, H)
+        finally:
+            ops.set_attention_fused(None)
+        e_h2 = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        e_f32 = float((f32.cpu().double() - ref).abs().max() / ref.abs().max())
+        peaked = kind in ("logits x 30", "outlier")     # logits of several hundred: the 22 bits a word keeps of q and k count
+        assert (e_h2 < 2e-5 or peaked) and e_h2 <= (2.0 if peaked else 1.25) * e_f32 + 2.5e-7, (kind, e_h2, e_f32)    # 2^-22: what a word keeps of v (T = 1: out = v)
+    assert not torch.isfinite(ops.attention_h2(ops.pack_h2_words(base.to(dev) * 1e6), H)).all()
 
 
 @pytest.mark.parametrize("L,H,d", [(2, 2, 64), (2, 8, 768), (1, 2, 512), (1, 8, 1024), (2, 2, 256)])

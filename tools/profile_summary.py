@@ -77,7 +77,7 @@ def bench_class(k):
     m = re.match(r"gemm_h2_kernel<(\d+), (\d+), ", k)
     if m:
         return f"gemm_h2_{m.group(1)}x{m.group(2)}x32"
-    if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel")):
+    if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel", "attn_h2_kernel")):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
         return "layernorm"
