@@ -634,7 +634,10 @@ def main():
                                        "async, consumed one step later (3-stage pipeline)" if pipe is not None else "synchronous")},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "extras": {"source_sha": source_sha(), "gemm": args.gemm, "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "verify": verify,
+            "extras": {"source_sha": source_sha(), "gemm": args.gemm,
+                       "attention": ("f16x2 (q, k, v as h2 words, two v_mfma_f32_32x32x16_f16 per 8 elements; csrc/attention_h2.hip)"
+                                     if args.gemm == "f16x2" and (shape.n_embd // shape.n_head) in (128, 256) else "exact f32 (v_mfma_f32_32x32x2_f32)"),
+                       "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "verify": verify,
                        "length_bucketed": bucketed,
                        "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),

@@ -24,7 +24,7 @@
 #include "h2.h"
 
 #ifndef ATH_DBG
-#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills
+#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills, bit 5 every second K / V refill only (half the traffic)
 #endif
 
 #ifndef ATH_KD
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
                 S0 = ATH_MFMA(kw, f1, S0);
                 S1 = ATH_MFMA(kw, f2, S1);
                 if (u + QP < NSTEP) qb[u % QP] = *reinterpret_cast<const u32x4q*>(q_frag + 8 * (u + QP));
-                if (!(ATH_DBG & 8) && u + KD < NSTEP)  // refill AFTER the slot's MFMAs in program order: no register copies
+                if (!(ATH_DBG & 8) && !((ATH_DBG & 32) && (u & 1)) && u + KD < NSTEP)  // refill AFTER the slot's MFMAs in program order: no register copies
                     kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
                 // pinned: the step's eight VALU, its two MFMAs, then the Q read of step u + QP and the K load of step u + KD
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 if (u + QP < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (!(ATH_DBG & 8) && u + KD < NSTEP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (!(ATH_DBG & 8) && !((ATH_DBG & 32) && (u & 1)) && u + KD < NSTEP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
                         O0[j] = ATH_MFMA(vb[u][j], pf1, O0[j]);
                         O1[j] = ATH_MFMA(vb[u][j], pf2, O1[j]);
                     }
-                    if (!(ATH_DBG & 16)) ATH_VLOAD(u, sg + VD)             // refill behind the slot's MFMAs; past the range: zeros
+                    if (!(ATH_DBG & 16) && !((ATH_DBG & 32) && (u & 1))) ATH_VLOAD(u, sg + VD)             // refill behind the slot's MFMAs; past the range: zeros
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * VW, 0);
-                    if (!(ATH_DBG & 16)) __builtin_amdgcn_sched_group_barrier(0x020, 4 * VW, 0);
+                    if (!(ATH_DBG & 16) && !((ATH_DBG & 32) && (u & 1))) __builtin_amdgcn_sched_group_barrier(0x020, 4 * VW, 0);
                 }
             }
         }
