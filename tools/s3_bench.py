@@ -81,8 +81,9 @@ def child():
         if K <= 4096:                                          # the planes are an exact split: hi + mid + lo == w
             p = planes.view(torch.bfloat16).float()
             out["planes_exact"] = bool(torch.equal(p[0].double() + p[1].double() + p[2].double(), wt.double()))
-            p2 = planes2.view(torch.float16).double()
-            out["h2_planes_relerr"] = float(((p2[0] + p2[1] / 2048.0 - wt.double()).abs() / wt.double().abs().clamp_min(1e-30)).max())
+            p2 = planes2.view(torch.float16).double()                  # lines [N, K/32, 2, 32]: hi, lo' of 32 consecutive k
+            hi2, lo2 = p2[:, :, 0].reshape(N, K), p2[:, :, 1].reshape(N, K)
+            out["h2_planes_relerr"] = float(((hi2 + lo2 / 2048.0 - wt.double()).abs() / wt.double().abs().clamp_min(1e-30)).max())
         print(json.dumps({"tile": tile, "M": M, "K": K, "N": N, "epi": epi, **out}), flush=True)
 
 
