@@ -49,6 +49,7 @@ elif [ "$PART" = lines ]; then
   python tools/s3_acceptance.py > $EV/${TAG}_h2_acceptance.md 2>> $LOG
   python tools/s3_bench.py auto 2>> $LOG | grep "^{" > $EV/${TAG}_gemm_shapes.jsonl
   python tools/attn_acceptance.py > $EV/${TAG}_attention_h2_acceptance.md 2>> $LOG
+  python tools/h2_power_probe.py 2>> $LOG | grep "^{" > $EV/${TAG}_h2_power_probe.jsonl
   python tools/annotation_e2e.py annotation retriever 2>> $LOG | grep "^{" > $EV/${TAG}_cli_end_to_end.jsonl
   cp profiles/pmc_traffic_f16x2.json profiles/pmc_traffic.json profiles/pmc_traffic_f32.json profiles/pmc_traffic_wikiv2_f16x2.json profiles/pmc_scan.json $EV/ 2>/dev/null
   echo "== lines part done" >> $LOG
