@@ -295,6 +295,33 @@ def scan_q32_shard8(index, shape, k, device):
     return out
 
 
+def gemm_zero_operand_probe(shape, rows, device, reps=20):
+    """Outside the timed region, f16x2 only: the step's c_attn GEMM (rows x d x 3d) on N(0,1) operands and the SAME launch on all-zero
+    operands -- identical instructions, addresses and bytes, no switching activity in the multipliers.  The ratio is what the clock
+    the chip sustains under fp16 MFMA load on real data costs this kernel."""
+    d = shape.n_embd
+    out = {"M": rows, "K": d, "N": 3 * d}
+    b = torch.zeros(3 * d, device=device)
+    for kind in ("normal", "zeros"):
+        x = torch.randn(rows, d, device=device) if kind == "normal" else torch.zeros(rows, d, device=device)
+        w = torch.randn(d, 3 * d, device=device) * 0.02 if kind == "normal" else torch.zeros(d, 3 * d, device=device)
+        planes = ops.split2_planes(w)
+        for _ in range(4):
+            ops.conv1d_h2(x, planes, b)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv1d_h2(x, planes, b)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        out[kind + "_us"] = round(us, 1)
+        out[kind + "_TFLOPs"] = round(2.0 * rows * d * 3 * d / us / 1e6, 1)
+    out["zeros_over_normal_speed"] = round(out["normal_us"] / out["zeros_us"], 3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -570,6 +597,12 @@ def main():
         scan = scan_q32(index, shape, k, device)
         if world == 1 and int(index.pool_hat.shape[0]) >= 8 * 64:
             scan8 = scan_q32_shard8(index, shape, k, device)
+    power_probe = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.gemm == "f16x2":
+        try:
+            power_probe = gemm_zero_operand_probe(shape, int(sum(int(b.numel()) for b in q_batches[:G])), device)
+        except Exception as e:                                       # noqa: BLE001
+            power_probe = {"error": f"{type(e).__name__}: {e}"}
     # --- SURVEY 8d's second, "length-bucketed" run (N = 1): the SAME queries sorted by length before they are cut into
     # batches of 32, so a batch pads to similar lengths.  NOT parity-comparable with the reference (an embedding is a mean
     # over its batch's padded positions) and never the headline value: it shows what the reference's file-order batching costs.
@@ -637,7 +670,7 @@ def main():
             "extras": {"source_sha": source_sha(), "gemm": args.gemm,
                        "attention": ("f16x2 (q, k, v as h2 words, two v_mfma_f32_32x32x16_f16 per 8 elements; csrc/attention_h2.hip)"
                                      if args.gemm == "f16x2" and (shape.n_embd // shape.n_head) in (128, 256) else "exact f32 (v_mfma_f32_32x32x2_f32)"),
-                       "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "verify": verify,
+                       "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "gemm_zero_operand_probe": power_probe, "verify": verify,
                        "length_bucketed": bucketed,
                        "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),
