@@ -81,6 +81,9 @@ def test_conv1d_f16x2_all_epilogues_tiles_and_range(dev, M, K, N):
     hi, lo = (p2.view(torch.float16)[:, :, t].reshape(N, K).double() for t in (0, 1))      # lines [N, K/32, 2, 32]
     # the planes ARE the split: |w - (hi + 2^-11 lo')| <= 2^-22 |w|, with the absolute floor 2^-36 where hi is an fp16 subnormal (|w| < 6.1e-5)
     assert ((hi + lo / 2048.0 - wd.t().double()).abs() <= 2.0 ** -22 * wd.t().double().abs() + 2.0 ** -36).all()
+    h_ref = w.t().contiguous().half()                                   # ... and bit for bit RN16(w), RN16((w - hi) 2^11)
+    l_ref = ((w.t().contiguous() - h_ref.float()) * 2048.0).half()
+    assert torch.equal(p2.view(torch.float16)[:, :, 0].reshape(N, K).cpu(), h_ref) and torch.equal(p2.view(torch.float16)[:, :, 1].reshape(N, K).cpu(), l_ref)
     assert rel_err(ops.conv1d_h2(xd, p2, bd).cpu().numpy(), ref.numpy()) < 1e-5
     yg = ops.conv1d_h2(xd, p2, bd, "gelu")
     assert rel_err(yg.cpu().numpy(), gpt2_ref.gelu_new(ref).numpy()) < 1e-5
@@ -204,6 +207,11 @@ def test_attention_f16x2_words_against_float64(dev, B, T, H, hd):
     lo = ((w >> 16) & 0xffff).to(torch.int16).view(torch.float16).double()
     x4 = base.to(dev).double() / 4
     assert ((hi + lo / 2048.0 - x4).abs() <= 2.0 ** -22 * x4.abs() + 2.0 ** -36).all()
+    # ... bit for bit the format csrc/h2.h states: hi = RN16(x / 4), lo' = RN16((x / 4 - hi) 2^11), round to nearest even
+    h_ref = (base / 4).half()
+    l_ref = ((base / 4 - h_ref.float()) * 2048.0).half()
+    w_ref = (h_ref.view(torch.int16).int() & 0xffff) | (l_ref.view(torch.int16).int() << 16)
+    assert torch.equal(w.cpu(), w_ref)
 
     def ref64(qkv):
         q, k, v = qkv.double().split(d, dim=2)
