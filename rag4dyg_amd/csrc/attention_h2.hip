@@ -283,7 +283,7 @@ static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double
     const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
     R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
     hipLaunchKernelGGL((attn_h2_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
-                       (float)(16.0 * 1.4426950408889634 / sqrt((double)HD)), out);
+                       (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out);      // both pre-scales undone in the logits
     R4D_CHECK_LAUNCH("attn_h2");
     return R4D_OK;
 }

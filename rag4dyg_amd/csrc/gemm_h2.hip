@@ -225,8 +225,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
     //   k-tile kt + 2 into stage WR = (kt + 2) % 3 (read last in iteration kt - 1, every wave is past that barrier; the A pieces
     //   are split on the way) FOLLOWED AT ONCE BY THE GLOBAL LOAD of the same piece of k-tile kt + 3 into the registers it just
     //   left: a load is consumed a whole iteration (~ 22 MFMAs, 700 cycles) after its issue.  (First form of round 4: the loads
-    //   in the second half, consumed 7 MFMAs later -- every k-tile began with a few hundred cycles of s_waitcnt vmcnt; MFMA
-    //   pipe 45-52 % busy);
+    //   in the second half, consumed 7 MFMAs later, an s_waitcnt vmcnt at the head of every k-tile.  Measured: the same time --
+    //   the launch is held by the clock under fp16 MFMA load, tools/h2_power_probe.py -- but this is the schedule that does
+    //   not depend on the L2 being fast);
     //   k-step 1's MFMAs with the reads of k-step 0 of stage NXT = (kt + 1) % 3 (set 0 again) -- stored during iteration
     //   kt - 1, i.e. in front of the same barrier;
     //   barrier.
