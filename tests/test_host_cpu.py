@@ -520,6 +520,40 @@ def test_small_integer_division_scheme_is_correctly_rounded():
             assert q1 == a / b, (a, b)
 
 
+def test_two_term_fp16_form_reaches_fp32_accuracy():
+    """The arithmetic of the f16x2 kernels restated in numpy (oracle/h2_ref.py; rag4dyg_amd/csrc/h2.h, gemm_h2.hip,
+    attention_h2.hip): the two fp16 terms reproduce an fp32 number to 2^-22 (with the second term a NORMAL fp16 number thanks to
+    its 2^11 scale), the word forms (hi,0) / (lo',hi) evaluate hi.hi + 2^-11 (hi.lo' + lo'.hi) exactly, and a K = 512 dot product
+    computed that way is no further from float64 than the fp32 chain the reference runs -- for N(0,1) x N(0,0.02) operands (the
+    Conv1D case), for activations of 1e-3 and of 3e4."""
+    from oracle import h2_ref
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(4096) * np.array([1.0, 1e-3, 3e4, 0.02])[rng.integers(0, 4, 4096)]).astype(np.float32)
+    hi, lo = h2_ref.split(x, 0.25)                                   # activations enter pre-scaled by 2^-2 (range 2^18)
+    x4 = x.astype(np.float64) / 4
+    err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) / 2048.0 - x4)
+    assert (err <= 2.0 ** -22 * np.abs(x4) + 2.0 ** -36).all()
+    assert (np.abs(lo[np.abs(x4) > 1e-3].astype(np.float64)) >= 6.1e-5).mean() > 0.99     # the second term is not a subnormal
+    w = h2_ref.words(x)
+    h2, l2 = h2_ref.unpack(w)
+    hq, lq = h2_ref.split(x, 0.25)
+    assert np.array_equal(h2, hq.astype(np.float64)) and np.array_equal(l2, lq.astype(np.float64))
+    e_h2, e_wf, e_f32 = [], [], []
+    for scale in (1.0, 1e-3, 3e4):
+        for _ in range(40):
+            a = (rng.standard_normal(512) * scale).astype(np.float32)
+            b = (rng.standard_normal(512) * 0.02).astype(np.float32)
+            ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+            norm = float(np.sqrt(np.sum((a.astype(np.float64) * b.astype(np.float64)) ** 2)))      # the size of a typical sum
+            chain = np.float32(0.0)
+            for k in range(512):
+                chain = np.float32(chain + a[k] * b[k])                                      # one fp32 FMA chain (rounded products)
+            e_f32.append(abs(float(chain) - ref) / norm)
+            e_h2.append(abs(float(h2_ref.dot_planes(a, b)) - ref) / norm)
+            e_wf.append(abs(float(h2_ref.dot_word_forms(h2_ref.words(a), h2_ref.words(b, 1.0))) * 4.0 - ref) / norm)
+    assert np.mean(e_h2) <= np.mean(e_f32) and np.mean(e_wf) <= 1.5 * np.mean(e_f32), (np.mean(e_h2), np.mean(e_wf), np.mean(e_f32))
+
+
 def test_generator_fused_graph_matches_networkx_and_gcn_norm():
     """the union-of-stars graph of ``fusion_graphpooling`` (``utils/model.py:181-189``) -- node order and
     edges of the oracle's and the product's construction equal networkx's own; the dense GCN normalisation equals
