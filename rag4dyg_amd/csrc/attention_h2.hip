@@ -13,9 +13,10 @@
 // walk 128-key super-tiles together -- wave w computes S^T = K.Q^T for its own 32 keys over the full head_dim (A = its K rows
 // straight from global memory, 16 bytes = 4 words per lane and step; B = the Q tile from LDS, its two forms derived in
 // registers: one AND and one rotate per word), the row max / row sum are combined across the waves through LDS, every wave
-// publishes its probabilities to LDS IN BOTH FORMS (split once by the producer: 12 VALU per two probabilities, against two
-// per word and reader), and wave w accumulates its quarter of the head columns of O^T over all 128 keys (A = V words, four
-// 4-byte loads per tile column group; B = the two P forms, one ds_read_b128 each per 8 keys).
+// publishes its probabilities to LDS as h2 words too (one image: with both forms stored the head_dim-256 workgroup needs 68 KB
+// and only two fit a CU; 51 KB and 168 VGPRs give three, head_dim 128 four -- worth 5 % / 12 %), and wave w accumulates its
+// quarter of the head columns of O^T over all 128 keys (A = V words, four 4-byte loads per tile column group; B = the two
+// forms of the P words, derived like Q's, one ds_read_b128 per 8 keys).
 // Logits: S = (acc0 + 2^-11 acc1) * 16 log2(e) / sqrt(hd)  (the 16 undoes the two 2^-2 pre-scales), exp2 domain, fp32 online
 // softmax exactly as in attention_fused.hip; masked keys are skipped.
 // Range: |q|, |k|, |v| < 2^18 (beyond: inf -> NaN in the output, never a quiet wrong number).
@@ -28,16 +29,19 @@
 #endif
 
 #ifndef ATH_KD
-#define ATH_KD 8    // K loads (16 bytes per lane) in flight per wave
+#define ATH_KD 4    // K loads (16 bytes per lane) in flight per wave (8 / 16: no faster, and the registers cost a workgroup per CU)
 #endif
 #ifndef ATH_VD
 #define ATH_VD 3    // V key-groups (8 keys) in flight per wave
 #endif
 #ifndef ATH_QP
-#define ATH_QP 4    // Q fragments (one ds_read_b128 each) in flight per wave
+#define ATH_QP 2    // Q fragments (one ds_read_b128 each) in flight per wave
+#endif
+#ifndef ATH_OCC256
+#define ATH_OCC256 3   // workgroups per CU the head_dim-256 instantiation is compiled for (168 VGPRs, 51 KB of LDS)
 #endif
 #ifndef ATH_OCC128
-#define ATH_OCC128 3   // workgroups per CU the head_dim-128 instantiation is compiled for
+#define ATH_OCC128 4   // workgroups per CU the head_dim-128 instantiation is compiled for (128 VGPRs, 35 KB of LDS)
 #endif
 
 namespace r4d {
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_h2_words_kernel(const float* __restr
 #define ATH_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, A_), __builtin_bit_cast(f16x8q, B_), C_, 0, 0, 0)
 
 template <int HD>
-__global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H,
+__global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H,
                                                                                   int ntq, float qscale, float* __restrict__ out) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // O^T tiles per wave (1 or 2): tile j = columns wid * CW + 32 j + lane
@@ -69,9 +73,8 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
     constexpr int QP = ATH_QP;                         // Q fragments (ds_read_b128) in flight: a fragment feeds TWO 32-cycle MFMAs
     extern __shared__ unsigned ldsw[];                 //   (sixteen 64-cycle ones in attention_fused.hip), so the LDS latency shows unless the reads run ahead
     unsigned* Qs = ldsw;                               // [32][LDQ]  the query tile's words
-    unsigned* P1 = ldsw + 32 * LDQ;                    // [32][LDP]  probabilities of the current super-tile, form (hi, 0), [query][key]
-    unsigned* P2 = P1 + 32 * LDP;                      // [32][LDP]  form (lo', hi)
-    float* red = reinterpret_cast<float*>(P2 + 32 * LDP);   // [2][4][32] per-wave row max / row sum
+    unsigned* Ps = ldsw + 32 * LDQ;                    // [32][LDP]  probabilities of the current super-tile as h2 words, [query][key]
+    float* red = reinterpret_cast<float*>(Ps + 32 * LDP);   // [2][4][32] per-wave row max / row sum
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // work mapping: attention_fused.hip's (all query tiles of one (sequence, head) on the same XCD, long tiles first)
@@ -117,8 +120,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
         for (int r = 0; r < 16; ++r) { O0[c][r] = 0.f; O1[c][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
     const unsigned* q_frag = Qs + li * LDQ + 4 * lh;
-    const unsigned* p1_frag = P1 + li * LDP + 4 * lh;
-    const unsigned* p2_frag = P2 + li * LDP + 4 * lh;
+    const unsigned* p_frag = Ps + li * LDP + 4 * lh;
 
     for (int st0 = 0; st0 < key_limit; st0 += 128) {
         const int key0 = st0 + wid * 32;
@@ -190,13 +192,11 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(S[4 * g + e] - m_new);
                 ps += (p[0] + p[1]) + (p[2] + p[3]);
-                unsigned a[4], b[4];
-                h2_forms(p[0], p[1], a[0], a[1], b[0], b[1]);
-                h2_forms(p[2], p[3], a[2], a[3], b[2], b[3]);
-                const u32x4q f1 = {a[0], a[1], a[2], a[3]}, f2 = {b[0], b[1], b[2], b[3]};
-                const int po = li * LDP + wid * 32 + 8 * g + 4 * lh;                      // keys 8g + 4lh + 0..3
-                *reinterpret_cast<u32x4q*>(P1 + po) = f1;
-                *reinterpret_cast<u32x4q*>(P2 + po) = f2;
+                unsigned a[4];
+                h2_words<false>(p[0], p[1], a[0], a[1]);
+                h2_words<false>(p[2], p[3], a[2], a[3]);
+                const u32x4q w4 = {a[0], a[1], a[2], a[3]};
+                *reinterpret_cast<u32x4q*>(Ps + li * LDP + wid * 32 + 8 * g + 4 * lh) = w4;            // keys 8g + 4lh + 0..3
             }
             ps += __shfl_xor(ps, 32, 64);
         }
@@ -217,24 +217,26 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
 #pragma unroll
             for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
         }
-        // the P forms of group s + 1 are read before the MFMAs of group s (a group is 2 VW MFMAs: 64-128 cycles, the LDS latency);
-        // group 16 does not exist: its read stays inside the row (LDP = 132) and is never used
-        u32x4q pn1 = *reinterpret_cast<const u32x4q*>(p1_frag), pn2 = *reinterpret_cast<const u32x4q*>(p2_frag);
+        // the P words of group s + 1 are read before the MFMAs of group s (a group is 2 VW MFMAs: 64-128 cycles, the LDS latency);
+        // group 16 does not exist: its read stays inside the allocation (LDP = 132, then `red`) and is never used
+        u32x4q pn = *reinterpret_cast<const u32x4q*>(p_frag);
         for (int s0 = 0; s0 < ((ATH_DBG & 2) ? min(ngroups, 1) : ngroups); s0 += VD) {
 #pragma unroll
             for (int u = 0; u < VD; ++u) {
                 const int sg = s0 + u;
                 if (sg < ngroups) {
-                    const u32x4q pf1 = pn1, pf2 = pn2;
-                    pn1 = *reinterpret_cast<const u32x4q*>(p1_frag + 8 * (sg + 1));
-                    pn2 = *reinterpret_cast<const u32x4q*>(p2_frag + 8 * (sg + 1));
+                    u32x4q pf1, pf2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pf1[e] = pn[e] & 0xffffu; pf2[e] = __builtin_amdgcn_alignbit(pn[e], pn[e], 16); }
+                    pn = *reinterpret_cast<const u32x4q*>(p_frag + 8 * (sg + 1));
 #pragma unroll
                     for (int j = 0; j < VW; ++j) {
                         O0[j] = ATH_MFMA(vb[u][j], pf1, O0[j]);
                         O1[j] = ATH_MFMA(vb[u][j], pf2, O1[j]);
                     }
                     if (!(ATH_DBG & 16) && !((ATH_DBG & 32) && (u & 1))) ATH_VLOAD(u, sg + VD)             // refill behind the slot's MFMAs; past the range: zeros
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * VW, 0);
                     if (!(ATH_DBG & 16) && !((ATH_DBG & 32) && (u & 1))) __builtin_amdgcn_sched_group_barrier(0x020, 4 * VW, 0);
                 }
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? 2 : ATH_OCC128) void attn_h2_kerne
 
 template <int HD>
 static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, hipStream_t s) {
-    const size_t lds = ((size_t)32 * (HD + 4) + 2 * 32 * 132 + 256) * 4;   // >= the [32][HD+4] output tile
+    const size_t lds = ((size_t)32 * (HD + 4) + 32 * 132 + 256) * 4;       // >= the [32][HD+4] output tile
     if (lds > 64 * 1024) {
         static bool raised = false;                     // (one process drives one device: include/r4d.h, PROCESS MODEL)
         if (!raised) {
