@@ -77,7 +77,7 @@ struct ProfScope {
     X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_DMA, "scan:short shard, LDS-DMA staged") X(SCAN_RING, "scan:long shard, LDS-DMA ring") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)") X(SCAN_BF16X3, "scan:bf16x3 operands") X(SCAN_F32, "scan:exact-f32 operands")  \
     X(TOPK_ONE_WG, "topk:one workgroup per row") X(TOPK_TICKET, "topk:cross-workgroup ticket merge")                      \
     X(TOPK_MULTI, "topk:second launch over candidates") X(TOPK_F64, "topk:f64 rows")                                      \
-    X(LN4_2, "layernorm:ln4<2>") X(LN4_4, "layernorm:ln4<4>") X(LN4_8, "layernorm:ln4<8>") X(LN_GENERIC, "layernorm:generic") \
+    X(EMBED_LN4, "embed+layernorm:16-byte lanes") X(EMBED_GENERIC, "embed+layernorm:generic") X(LN4_2, "layernorm:ln4<2>") X(LN4_4, "layernorm:ln4<4>") X(LN4_8, "layernorm:ln4<8>") X(LN_GENERIC, "layernorm:generic") \
     X(LNF_8, "lnf_meanpool:<8>") X(LNF_16, "lnf_meanpool:<16>") X(LNF_32, "lnf_meanpool:<32>")                             \
     X(DEC_ATT_32, "decode_attention:<32>") X(DEC_ATT_64, "decode_attention:<64>")                                         \
     X(JAC_LDS, "jaccard:LDS table") X(JAC_MERGE, "jaccard:merge walk (vocab too large for LDS)")                          \

@@ -163,6 +163,66 @@ __global__ __launch_bounds__(256) void embed_ln_groups_kernel(const RowTable G, 
         if (i < nv) y_out[row * d + lane + 64 * i] = v[i] * w[lane + 64 * i] + b[lane + 64 * i];
 }
 
+// the same with 16-byte lanes (d % 256 == 0, every pointer 16-byte aligned): a quarter of the memory instructions of the 4-byte form,
+// which held this write-bound kernel at 2.5 TB/s (ln4_kernel's layout and reduction order)
+template <int NQ>
+__global__ __launch_bounds__(256) void embed_ln4_groups_kernel(const RowTable G, const RowInputs in,
+                                                               const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                               int vocab, int d, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float eps,
+                                                               float* __restrict__ x_out, float* __restrict__ y_out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= G.row_prefix[G.n]) return;
+    int g = 0;
+    while (g + 1 < G.n && row >= G.row_prefix[g + 1]) ++g;
+    const long long local = row - G.row_prefix[g];
+    const int nq = d >> 8;
+    const float* src;
+    bool bad = false;
+    if (in.ids[g]) {
+        const long long id = in.ids[g][local];
+        bad = id < 0 || id >= vocab;                     // out-of-vocabulary id: poison the row, never fault
+        src = wte + (bad ? 0 : id) * (long long)d;
+    } else {
+        src = in.emb[g] + local * d;
+    }
+    const float4* s4 = reinterpret_cast<const float4*>(src) + lane;
+    const float4* p4 = reinterpret_cast<const float4*>(wpe + (local % G.T[g]) * d) + lane;
+    float4* xr = reinterpret_cast<float4*>(x_out + row * d) + lane;
+    float4 v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nq) {
+            const float4 e = s4[64 * i], q = p4[64 * i];
+            const float nan = __builtin_nanf("");
+            v[i] = bad ? make_float4(nan, nan, nan, nan) : make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
+            xr[64 * i] = v[i];
+        }
+    }
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) s_ += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s_) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (i < nq) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    float4* yr = reinterpret_cast<float4*>(y_out + row * d) + lane;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (i < nq) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[lane + 64 * i], bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+            yr[64 * i] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                     (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+        }
+}
+
 int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
                                   const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
@@ -173,8 +233,17 @@ int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const fl
     RowInputs in;
     for (int g = 0; g < ATT_MAXG; ++g) { in.ids[g] = g < G.n ? G.ids[g] : nullptr; in.emb[g] = g < G.n ? G.emb[g] : nullptr; }
     ProfScope prof(PK_EMBED_LN, 12.0 * rows * d + 8.0 * rows, s);   // bytes: gather row + write x, y (+ ids)
-    hipLaunchKernelGGL(embed_ln_groups_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, t, in, wte, wpe, vocab, d,
-                       w, b, eps, x_out, y_out);
+    uintptr_t align = (uintptr_t)wte | (uintptr_t)wpe | (uintptr_t)w | (uintptr_t)b | (uintptr_t)x_out | (uintptr_t)y_out;
+    for (int g = 0; g < G.n; ++g) align |= (uintptr_t)in.emb[g];
+    const bool vec = d % 256 == 0 && (align & 15) == 0;
+    const dim3 grid((unsigned)cdiv(rows, 4));
+    if (vec && d <= 512) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<2>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }
+    else if (vec && d <= 1024) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<4>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }
+    else if (vec) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<8>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }
+    else {
+        R4D_BRANCH(EMBED_GENERIC);
+        hipLaunchKernelGGL(embed_ln_groups_kernel, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out);
+    }
     R4D_CHECK_LAUNCH("embed_layernorm");
     return R4D_OK;
 }

@@ -81,6 +81,8 @@ def bench_class(k):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
         return "layernorm"
+    if k.startswith("embed_ln4_groups_kernel"):
+        return "embed_layernorm"
     if k.startswith(("pool_scan_ks_kernel", "pool_scan_dma_kernel", "pool_scan_ring_kernel")):
         return "pool_scan"
     return {"ln_kernel": "layernorm", "embed_ln_groups_kernel": "embed_layernorm", "causal_softmax_kernel": "causal_softmax",
