@@ -333,6 +333,19 @@ class AdamW:
     def grad_norm(self):
         return float(self.sumsq[0].sqrt().item())
 
+    def load_state(self, state):
+        """Moments, step count and learning rate written by :func:`save_checkpoint` (``r4d_optimizer.pt``): what
+        ``get_optimizer_scheduler`` does with ``optimizer.pt`` / ``scheduler.pt`` when training continues from a checkpoint
+        directory (``utils/model.py:96-102``)."""
+        if state.get("format") != "rag4dyg_amd.AdamW" or set(state["m"]) != set(self.m):
+            raise _lib.R4DError("AdamW.load_state: not an r4d_optimizer.pt of this model")
+        for n in self.m:
+            if state["m"][n].shape != self.m[n].shape:
+                raise _lib.R4DError(f"AdamW.load_state: {n}: shape {tuple(state['m'][n].shape)} != {tuple(self.m[n].shape)}")
+            self.m[n].copy_(state["m"][n])
+            self.v[n].copy_(state["v"][n])
+        self.t, self.lr = int(state["t"]), float(state["lr"])
+
 
 def _to_device(x, dev):
     """Host tensor -> device through pinned memory, asynchronously: a pageable ``.to(device)`` is a blocking copy that first
@@ -423,14 +436,42 @@ def save_checkpoint(model, optimizer, tokenizer, args, global_step):
     torch.save({"last_epoch": optimizer.t}, os.path.join(out, "r4d_scheduler.pt"))
 
 
-def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args):
+def get_training_info(n_batches, args):
+    """``train/train_retriever.py:100-118``: training continues from ``--model_name_or_path`` when that is an existing directory
+    whose name ends in ``-<global_step>`` (``.../checkpoint-<n>``): (global_step, epochs already trained, optimizer steps to skip
+    at the head of an epoch).  Anything else starts at zero."""
+    global_step = epochs_trained = steps_trained_in_current_epoch = 0
+    path = getattr(args, "model_name_or_path", None)
+    if path and os.path.exists(path):
+        per_epoch = n_batches // max(1, int(getattr(args, "gradient_accumulation_steps", 1)))
+        try:
+            global_step = int(path.split("-")[-1].split("/")[0])
+            epochs_trained = global_step // per_epoch
+            steps_trained_in_current_epoch = global_step % per_epoch
+            print("  Continuing training from checkpoint, will skip to saved global_step")
+            print("  Continuing training from epoch %d" % epochs_trained)
+            print("  Continuing training from global step %d" % global_step)
+            print("  Will skip the first %d steps in the first epoch" % steps_trained_in_current_epoch)
+        except (ValueError, ZeroDivisionError):
+            global_step = epochs_trained = steps_trained_in_current_epoch = 0
+            print("  Starting fine-tuning.")
+    return global_step, epochs_trained, steps_trained_in_current_epoch
+
+
+def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args,
+                steps_trained_in_current_epoch=0):
     """``train/train_retriever.py:132-227``: one pass over the shuffled triples.  Returns (global_step, summed loss,
-    summed contrastive loss, summed augmentation loss)."""
+    summed contrastive loss, summed augmentation loss).  ``steps_trained_in_current_epoch`` batches at the head of the pass are
+    skipped (:165-167; upstream hands the same count to EVERY epoch of a continued run -- it is passed by value -- and so does
+    this)."""
     tr_loss = tr_cl = tr_aug = 0.0
     model.train()                                              # :161 -- dropout on (EncoderTrainer reads model.training)
     for i, batch in enumerate(train_dataloader):
         if args.lrdecay == 1:
             adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
+        if steps_trained_in_current_epoch > 0:
+            steps_trained_in_current_epoch -= 1
+            continue
         r = training_step(args, model, trainer, optimizer, batch, all_query_time, micro_step=i, sync=False)
         tr_loss = tr_loss + r["loss"]; tr_cl = tr_cl + r["cl_loss"]; tr_aug = tr_aug + r["aug_loss"]   # device sums: no wait per step
         if r["stepped"]:                                       # an optimizer update (train_retriever.py:212-221)
@@ -464,8 +505,9 @@ def train(args, train_dataset, model, tokenizer):
     takes its ``DistributedSampler`` share of the triples and the gradients are averaged with one all-reduce per update (RCCL;
     ``R4D_DIST_BACKEND=gloo`` for ranks that share a card); every rank validates (identical numbers, so the early-stopping
     decision needs no broadcast), rank 0 writes the checkpoints.  Dropout (``model.train()``) draws its masks from the
-    library's counter-based generator keyed by ``--seed`` instead of torch's RNG stream.  Differences: ``--fp16`` (apex) is
-    not built (raises)."""
+    library's counter-based generator keyed by ``--seed`` instead of torch's RNG stream.  Continuing from a ``checkpoint-<n>``
+    directory given as ``--model_name_or_path`` follows ``get_training_info`` (:100-118) and restores the optimizer state this build
+    saved there.  Differences: ``--fp16`` (apex) is not built (raises)."""
     from .dataloader import get_dataloader
     from .retriever import test
     if getattr(args, "fp16", False):
@@ -488,13 +530,19 @@ def train(args, train_dataset, model, tokenizer):
     print("  Instantaneous batch size per GPU = {}".format(args.per_gpu_train_batch_size))
     all_query_time = torch.load(os.path.join("resources/", args.dataset + '_train_query_time.pt'))     # get_train_query_time.py
     all_query_time = torch.as_tensor(all_query_time).to(args.device)
-    global_step, tr_loss = 0, 0.0
+    # continuing from a checkpoint directory (train_retriever.py:276; optimizer / schedule state: utils/model.py:96-102)
+    global_step, epochs_trained, steps_to_skip = get_training_info(len(train_dataloader), args)
+    opt_state = os.path.join(args.model_name_or_path, "r4d_optimizer.pt") if getattr(args, "model_name_or_path", None) else None
+    if opt_state and os.path.isfile(opt_state):
+        optimizer.load_state(torch.load(opt_state, map_location="cpu", weights_only=True))
+    tr_loss = 0.0
     best_score, best_epoch, best_state, counter = None, 0, None, 0
     snapshot = lambda: {k: v.detach().clone() for k, v in model.state_dict().items()}
-    last_state, epoch = None, 0
-    for epoch in range(int(args.num_train_epochs)):
+    last_state, epoch = None, epochs_trained
+    for epoch in range(epochs_trained, int(args.num_train_epochs)):
         print('==> Training Epoch: ', epoch)
-        global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args)
+        global_step, ep_loss, cl, au = train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataloader, global_step, args,
+                                                   steps_to_skip)
         tr_loss = ep_loss            # the reference resets tr_loss every epoch (train_retriever.py:158): its logged / returned
                                      # "train_loss" is the LAST epoch's summed loss over the cumulative step count (:303, :354)
         val_metrics, val_loss = test(epoch, args, model, tokenizer, evaluate=True)

@@ -203,6 +203,36 @@ def test_training_step_parameter_update_equals_oracle_adamw(dev):
     assert "_wt_cache" not in m.transformer.__dict__                         # stale transposed copies dropped
 
 
+def test_optimizer_state_survives_a_checkpoint_round_trip(dev, tmp_path):
+    """``save_checkpoint`` writes the AdamW moments / step / learning rate (``r4d_optimizer.pt``); ``AdamW.load_state`` -- what a
+    continued run does with them (utils/model.py:96-102) -- restores them exactly, and refuses another model's file."""
+    import types
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    from rag4dyg_amd.training import AdamW, EncoderTrainer, save_checkpoint
+    torch.manual_seed(3)
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=50, n_positions=32, n_ctx=32, n_embd=64, n_layer=1, n_head=2)).to(dev)
+    tr = EncoderTrainer(m, seed=1)
+    opt = AdamW(tr.params, tr.grads, lr=1e-3, weight_decay=0.01, flat_grads=tr.flat_grads)
+    for g in tr.grads.values():
+        g.copy_(torch.randn_like(g) * 0.01)
+    opt.step(max_grad_norm=1.0); opt.step(max_grad_norm=1.0)
+    opt.lr = 7e-4
+
+    class Tok:
+        def save_pretrained(self, d):
+            pass
+    args = types.SimpleNamespace(output_dir=str(tmp_path), save_total_limit=None)
+    save_checkpoint(m, opt, Tok(), args, 5)
+    state = torch.load(os.path.join(str(tmp_path), "checkpoint-5", "r4d_optimizer.pt"), map_location="cpu", weights_only=True)
+    opt2 = AdamW(tr.params, tr.grads, lr=1e-3, weight_decay=0.01, flat_grads=tr.flat_grads)
+    opt2.load_state(state)
+    assert opt2.t == 2 and opt2.lr == 7e-4
+    assert all(torch.equal(opt2.m[n], opt.m[n]) and torch.equal(opt2.v[n], opt.v[n]) for n in opt.m)
+    bad = dict(state, m={k + "_x": v for k, v in state["m"].items()})
+    with pytest.raises(Exception):
+        opt2.load_state(bad)
+
+
 def test_non_finite_gradient_stays_loud_in_the_deterministic_embedding_sum(dev):
     """the token-embedding gradient is a 64-bit fixed-point sum (bit-reproducible); a NaN / Inf contribution has no
     fixed-point image and used to become 0 or a saturated integer -- a finite, WRONG gradient.  Now it poisons the table: the whole

@@ -749,6 +749,27 @@ def test_train_query_times_match_reference_on_all_shipped_datasets(tmp_path, mon
         query_time.query_times([0], [1], [1.0], [9], [0], 5, 1)           # no event early enough
 
 
+def test_training_continues_from_a_checkpoint_directory_like_the_reference(tmp_path, monkeypatch):
+    """``get_training_info`` (train/train_retriever.py:100-118): the step count comes from the directory NAME of an existing
+    ``--model_name_or_path`` (the text after its last ``-``, up to the next ``/``: relative paths here, as the scripts use them);
+    epochs done and steps to skip from the batches per epoch and the accumulation steps."""
+    import types
+    from rag4dyg_amd.training import get_training_info
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("run/checkpoint-37")
+    args = types.SimpleNamespace(model_name_or_path="run/checkpoint-37", gradient_accumulation_steps=2)
+    assert get_training_info(10, args) == (37, 7, 2)                   # 5 optimizer steps per epoch
+    args.gradient_accumulation_steps = 1
+    assert get_training_info(10, args) == (37, 3, 7)
+    args.model_name_or_path = "run/checkpoint-38"                      # does not exist: a fresh run
+    assert get_training_info(10, args) == (0, 0, 0)
+    os.makedirs("run/best")
+    args.model_name_or_path = "run/best"                               # exists, no step in its name: "Starting fine-tuning."
+    assert get_training_info(10, args) == (0, 0, 0)
+    args.model_name_or_path = None
+    assert get_training_info(10, args) == (0, 0, 0)
+
+
 def test_learning_rate_schedule_matches_reference():
     """adjust_learning_rate (linear warm-up over --warmup_steps EPOCHS, then half a cosine) against the reference function's own
     values (G8b): three (warm-up, epochs, iterations per epoch, base lr) settings, every epoch, four iterations each."""
