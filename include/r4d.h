@@ -36,7 +36,7 @@ extern "C" {
 #define R4D_ERR_HIP (-2)          /* a HIP runtime call or kernel launch failed */
 #define R4D_ERR_WORKSPACE (-3)    /* workspace too small */
 
-#define R4D_ABI_VERSION 5
+#define R4D_ABI_VERSION 6
 
 /* ABI version of the loaded library. */
 int r4d_abi_version(void);
@@ -246,6 +246,23 @@ int r4d_set_attention_fused(int32_t mode);
 int r4d_set_attention_h2(int32_t on);
 int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream);
 int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream);
+
+/* Range guard (ABI v6, additive).  The f16x2 arithmetic has fp16's exponent range: an activation, q, k or v of magnitude >= 2^18
+ * becomes inf in its first fp16 term and every hidden state downstream of it NaN -- and NaN scores are ordered below everything by
+ * the selection, i.e. an ordinary-looking top-k of garbage.  r4d_set_range_flag registers ONE caller-owned
+ * device word for the process (one process per device; NULL unregisters; the library never clears it).  While registered:
+ *   bit 0 (R4D_RANGE_NONFINITE_HIDDEN) is OR-ed in by the ln_f / mean-pool kernel of r4d_gpt2_encode_* for every row of the
+ *         final residual stream that is non-finite or whose variance overflowed (any arithmetic; in f16x2 mode this is how an
+ *         out-of-range activation surfaces);
+ *   bit 1 (R4D_RANGE_BAD_NORM) by r4d_normalize_rows_f32 for every row whose norm is NaN, inf or zero.
+ * The calls stay asynchronous: the caller reads the word at its own synchronisation points.  What the Python host mirror does
+ * with it (rag4dyg_amd/ops.py, retrieval.py, gpt2.py): retrieval.encode_batches and GPT2Model.forward re-run an f16x2 call whose
+ * bit 0 came up ONCE under bf16x3 (fp32's exponent range) with a warning and raise R4DError if the bit comes up again;
+ * PoolIndex and search raise R4DError on either bit before any top-k result is handed out; bench.py reports the word of the
+ * whole timed region.  encode_* called directly leave the check to the caller (ops.take_range_flag). */
+#define R4D_RANGE_NONFINITE_HIDDEN 1u
+#define R4D_RANGE_BAD_NORM 2u
+int r4d_set_range_flag(uint32_t* flag_d);
 
 /* --- single ops, exported for per-op parity tests (same kernels the encoder launches) --- */
 /* y = LayerNorm(x) over the last dim.  nn.LayerNorm, modeling_gpt2.py:219,221,339. */

@@ -70,13 +70,14 @@ def _scratch_cwd():
     return d
 
 
-def _ref_model(flavour, n_layer, n_head, n_embd, vocab, n_positions, sd, output_hidden_states=False):
+def _ref_model(flavour, n_layer, n_head, n_embd, vocab, n_positions, sd, output_hidden_states=False, output_attentions=False):
     from models import GPT2Config
     import models.modeling_gpt2 as mg
     import models.modeling_rag as mr
     cfg = GPT2Config(vocab_size=vocab, n_positions=n_positions, n_ctx=n_positions, n_embd=n_embd,
                      n_layer=n_layer, n_head=n_head)
     cfg.output_hidden_states = output_hidden_states
+    cfg.output_attentions = output_attentions
     cls = {"gpt2": mg.GPT2LMHeadModel, "rag": mr.GPT2LMHeadModel}[flavour]
     m = cls(cfg).eval()
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -146,7 +147,9 @@ def g2_ops():
         out.update(conv_w=c.weight.numpy(), conv_b=c.bias.numpy(), conv_y=c(x).numpy())
         gx = torch.linspace(-6, 6, 257)
         out.update(gelu_x=gx.numpy(), gelu_y=mg.gelu_new(gx).numpy())
-        for hd, T, scale in ((32, 40, 1.0), (64, 33, 1.0), (96, 24, 1.0), (128, 24, 1.0), (256, 20, 1.0), (64, 48, 30.0)):
+        for hd, T, scale in ((32, 40, 1.0), (64, 33, 1.0), (96, 24, 1.0), (128, 24, 1.0), (256, 20, 1.0), (64, 48, 30.0),
+                              # (round 5: the head dims attention_h2.hip serves, logits x 900 -- appended, so every earlier vector keeps its draws)
+                              (128, 48, 30.0), (256, 40, 30.0), (128, 61, 6.0), (256, 64, 6.0)):
             cfg = GPT2Config(vocab_size=8, n_positions=64, n_ctx=64, n_embd=2 * hd, n_layer=1, n_head=2)
             att = mg.Attention(2 * hd, 64, cfg, scale=True).eval()
             q = torch.randn(2, 2, T, hd, generator=g) * scale
@@ -900,6 +903,73 @@ def g12_real_wikiv2_reddit():
     _save("g12_reddit_generator", **out)
 
 
+# --------------------------------------------------------------------------- G13
+def g13_h2_attention_stress():
+    """Reference-held vectors with HARD statistics at the head dims ``csrc/attention_h2.hip`` serves (G11 is
+    head_dim 64 and routes to the exact-f32 kernel).  Four cases, each the reference model on the real UCI_13/12 ids (first 256
+    pool histories = 8 reference batches, all 110 test queries), as g10 does:
+      hd128_plain    the TRAINED G10 tensors loaded with n_head = 1 (one head of 128);
+      hd128_stress   the same after ``gpt2_ref.stress_transform`` (G11's transform);
+      hd128_peaked   the same after ``stress_transform`` and ``sharpen_attention(4)`` (every logit x 16);
+      hd256_peaked   a seeded L2 H2 d512 model (-> head_dim 256; weights by ``make_state_dict``, not committed) after
+                     ``stress_transform`` and ``sharpen_attention(6)`` (every logit x 36).
+    Stored per case: embeddings, scores, stable top-10, three token rows of the ln_f hidden states of the first query batch (the
+    mean-pool hides per-token error), the per-tensor weight checksum (sum of the fp32 BIT PATTERNS: exact, independent of
+    summation order and thread count), and HOW peaked the reference's own softmax was (median /
+    90th percentile of the row maximum of its attention probabilities per layer, from ``config.output_attentions``)."""
+    print("G13 attention_h2 head dims under stress")
+    gw = np.load(os.path.join(GOLD, "g10_trained_small.npz"))
+    trained = {k[2:]: torch.from_numpy(gw[k]) for k in gw.files if k.startswith("w:")}
+    trained["lm_head.weight"] = trained["transformer.wte.weight"]
+    g6 = np.load(os.path.join(GOLD, "g6_uci_tokens.npz"))
+    pad = int(g6["pad_id"])
+
+    def seqs(flat, off):
+        return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    pool, test = seqs(g6["pool_flat"], g6["pool_off"])[:256], seqs(g6["test_flat"], g6["test_off"])
+
+    def batches(examples):          # dataloader/retriever.py:153-166 around the reference model (as g4)
+        for s in range(0, len(examples), 32):
+            ch = [torch.tensor(e, dtype=torch.long) for e in examples[s:s + 32]]
+            yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=pad)
+    seeded = gpt2_ref.make_state_dict(2, 512, 1801, seed=2031, random_affine=True)
+    cases = {"hd128_plain": (trained, 1), "hd128_stress": (gpt2_ref.stress_transform(trained), 1),
+             "hd128_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(trained), 4.0), 1),
+             "hd256_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(seeded), 6.0), 2)}
+    out = {}
+    for tag, (sd, H) in cases.items():
+        V, d = sd["transformer.wte.weight"].shape
+        n_pos = sd["transformer.wpe.weight"].shape[0]
+        L = gpt2_ref.n_layers_of(sd)
+        m = _ref_model("rag", L, H, d, V, n_pos, sd)
+        with torch.no_grad():
+            pe = torch.cat([torch.mean(m(input_ids=b)[1], dim=1) for b in batches(pool)], dim=0)
+            hid0 = None
+            qs = []
+            for b in batches(test):
+                h = m(input_ids=b)[1]
+                if hid0 is None:
+                    T0 = h.shape[1]
+                    rows = [0, T0 // 2, T0 - 1]
+                    hid0 = h[:, rows, :].numpy().copy()
+                qs.append(torch.mean(h, dim=1))
+            qe = torch.cat(qs, dim=0)
+            qn = qe / qe.norm(dim=1, keepdim=True)                      # train_retriever.py:433-438
+            pn = pe / pe.norm(dim=1, keepdim=True)
+            S = ((torch.matmul(qn, pn.t()) + 1) / 2).numpy()
+            ma = _ref_model("gpt2", L, H, d, V, n_pos, sd, output_attentions=True)
+            att = ma(next(batches(test)))[-1]                             # tuple over layers of [B,H,T,T] probabilities
+            peak = np.array([[float(a.max(-1).values.median()), float(a.max(-1).values.quantile(0.9))] for a in att])
+        top10 = np.argsort(-S, axis=1, kind="stable")[:, :10].astype(np.int32)
+        sig = gpt2_ref.weight_bit_checksums(sd)
+        out.update({f"{tag}:cfg": np.array([L, H, d, V, n_pos]), f"{tag}:pool_emb": pe.numpy(), f"{tag}:query_emb": qe.numpy(),
+                    f"{tag}:scores": S, f"{tag}:top10_stable": top10, f"{tag}:hidden_rows": hid0, f"{tag}:rows": np.array(rows),
+                    f"{tag}:weight_checksums": sig, f"{tag}:attn_rowmax_median_p90": peak})
+        print(f"    {tag}: L{L} H{H} d{d} -> head_dim {d // H}; attention row-max median / p90 per layer {peak.round(3).tolist()}; "
+              f"query emb absmax {float(qe.abs().max()):.3f}; score range {float(S.min()):.4f} .. {float(S.max()):.4f}")
+    _save("g13_h2_attention_stress", seed_hd256=np.array(2031), pool_rows=np.array(256), **out)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "g10":                   # g10 <tag> [weights.npz] [device.npz]
         torch.set_num_threads(os.cpu_count() or 1)
@@ -909,7 +979,7 @@ def main():
         return
     groups = {"g1": g1_tiny_forward, "g2": g2_ops, "g3": g3_config_shapes, "g4": g4_g6_uci_retrieval, "g5": g5_jaccard,
               "g6b": g6_more_tokenizers, "g7": g7_generator, "g8": g8_training_step, "g8b": g8b_lr_schedule, "g9": g9_query_times,
-              "g10": g10_trained, "g12": g12_real_wikiv2_reddit}
+              "g10": g10_trained, "g12": g12_real_wikiv2_reddit, "g13": g13_h2_attention_stress}
     want = [a for a in sys.argv[1:] if a in groups] or list(groups)
     torch.set_num_threads(os.cpu_count() or 1)
     _install_stubs()

@@ -227,3 +227,30 @@ def stress_transform(sd):
     else:
         out["lm_head.weight"] = out["transformer.wte.weight"]
     return out
+
+
+def sharpen_attention(sd, factor):
+    """PEAKED-SOFTMAX input generator (fixture G13): every block's `c_attn` query and key columns (weight
+    and bias) x ``factor``, i.e. every attention logit x ``factor``^2 -- an N(0, 0.02) initialisation has logits of a few tenths
+    at head_dim 128 / 256, a trained model several tens to hundreds.  Values are untouched.  Like ``stress_transform`` nothing
+    here comes from the reference: it is applied identically before the reference model (oracle/gen_golden.py g13) and the HIP
+    path (tests) load the weights.  Returns a new dict; a tied `lm_head.weight` stays the `wte` alias."""
+    out = {k: v.clone() for k, v in sd.items() if k != "lm_head.weight"}
+    d = out["transformer.wte.weight"].shape[1]
+    for i in range(n_layers_of(out)):
+        p = f"transformer.h.{i}.attn.c_attn."
+        out[p + "weight"][:, :2 * d] *= float(factor)
+        out[p + "bias"][:2 * d] *= float(factor)
+    if "lm_head.weight" in sd and not torch.equal(sd["lm_head.weight"], sd["transformer.wte.weight"]):
+        out["lm_head.weight"] = sd["lm_head.weight"].clone()
+    else:
+        out["lm_head.weight"] = out["transformer.wte.weight"]
+    return out
+
+
+def weight_bit_checksums(sd):
+    """uint64 per tensor (sorted by name, the tied ``lm_head.weight`` left out): the sum of its fp32 BIT PATTERNS mod 2^64 -- an
+    exact signature, the same on every machine (a floating-point sum of 10^6 elements depends on the thread count)."""
+    import numpy as np
+    return np.array([int(sd[k].detach().contiguous().numpy().view(np.uint32).astype(np.uint64).sum(dtype=np.uint64))
+                     for k in sorted(sd) if k != "lm_head.weight"], dtype=np.uint64)

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("R4D_LIB_PATH") or os.path.join(PKG, "librag4dyg_hip.so")   # override: tools/ A/B tuning only
 
-R4D_ABI_VERSION = 5
+R4D_ABI_VERSION = 6
 
 
 class R4DError(RuntimeError):
@@ -71,6 +71,7 @@ PROTOTYPES = {
                                                 POINTER(c_int32), POINTER(c_int32), _P, _P, _P, _P, c_size_t, _P]),
     "r4d_set_attention_fused": (c_int32, [c_int32]),
     "r4d_set_attention_h2": (c_int32, [c_int32]),
+    "r4d_set_range_flag": (c_int32, [_P]),
     "r4d_pack_h2_words_f32": (c_int32, [_P, c_int64, _P, _P]),
     "r4d_attention_h2_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_gpt2_decode_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32]),

@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, HD >= 256 ? 1 : 2) void attn_fused_kernel(cons
 // there is no merge phase.
 //
 // Instruction diet (plain VALU / LDS / VMEM instructions do not hide under v_mfma on gfx950, tools/mfma_peak.hip):
-//   * Q is staged ROW-major [query][HD+4] and pre-multiplied by log2(e)/sqrt(hd): the logits come out of the MFMA in
-//     the exp2 domain (softmax = exp2(s - max), no per-element scale), and a lane's Q operand for FOUR MFMAs is one
+//   * Q is staged ROW-major [query][HD+4], unscaled: the logits come out of the MFMA as raw dot products and the softmax is
+//     exp2((s - max) * log2(e)/sqrt(hd)) (subtract first: exact for nearby logits), and a lane's Q operand for FOUR MFMAs is one
 //     conflict-free ds_read_b128 -- matching the four k of the lane's 16-byte K load;
 //   * K and V rows come in through buffer loads: lane offset loop-invariant, the key row in the SCALAR offset, rows
 //     past the sequence answered with zeros by the range check -- no clamps, no 64-bit address arithmetic;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < HD / 32; ++j)
             *reinterpret_cast<float4*>(Qs + row * LDQ + seg + 32 * j) =
-                make_float4(qv[j].x * qscale, qv[j].y * qscale, qv[j].z * qscale, qv[j].w * qscale);
+                qv[j];        // UNSCALED (round 5): the logits leave the MFMA as raw dot products, see the softmax below
     }
     __syncthreads();
 
@@ -418,16 +418,20 @@ __global__ __launch_bounds__(256, 3) void attn_colsplit_kernel(const float* __re
         if (!(ATT_DBG & 4)) __syncthreads();
         const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
         const float m_new = fmaxf(m_run, m_tile);      // finite from the first super-tile on (key 0 is never masked)
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        // softmax on the RAW dot products: p = exp2((s - max) * log2(e)/sqrt(hd)).  The difference of two nearby logits is exact
+        // (Sterbenz) and the scale then rounds a SMALL number; scaling first (q pre-multiplied, rounds 1-4) rounded every logit
+        // at its own magnitude -- 2^-24 x 3,900 = 2e-4 in the exponent at logits of several hundred (G2 attn_hd256_T40_s30:
+        // 2.8e-4 from the reference against 5.5e-5 of the reference from float64).  Same instruction count per score.
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * qscale);
         float ps = 0.f;
         if (active) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 p;
-                p.x = __builtin_amdgcn_exp2f(S[4 * g + 0] - m_new);
-                p.y = __builtin_amdgcn_exp2f(S[4 * g + 1] - m_new);
-                p.z = __builtin_amdgcn_exp2f(S[4 * g + 2] - m_new);
-                p.w = __builtin_amdgcn_exp2f(S[4 * g + 3] - m_new);
+                p.x = __builtin_amdgcn_exp2f((S[4 * g + 0] - m_new) * qscale);
+                p.y = __builtin_amdgcn_exp2f((S[4 * g + 1] - m_new) * qscale);
+                p.z = __builtin_amdgcn_exp2f((S[4 * g + 2] - m_new) * qscale);
+                p.w = __builtin_amdgcn_exp2f((S[4 * g + 3] - m_new) * qscale);
                 ps += (p.x + p.y) + (p.z + p.w);
                 *reinterpret_cast<float4*>(Ps + li * LDP + wid * 32 + 8 * g + 4 * lh) = p;   // keys 8g + 4lh + 0..3
             }

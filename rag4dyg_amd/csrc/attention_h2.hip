@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[r] = __builtin_fmaf(S1[r], H2_LO_UNSCALE, S0[r]) * qscale;
+            for (int r = 0; r < 16; ++r) S[r] = __builtin_fmaf(S1[r], H2_LO_UNSCALE, S0[r]);      // RAW (q/4).(k/4): scaled AFTER the max is subtracted
             if (key0 + 31 > q0) {                      // the sub-tile touches the diagonal (or runs past T): mask
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -183,14 +183,16 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
         if (!(ATH_DBG & 4)) __syncthreads();
         const float m_tile = fmaxf(fmaxf(red[li], red[32 + li]), fmaxf(red[64 + li], red[96 + li]));
         const float m_new = fmaxf(m_run, m_tile);      // finite from the first super-tile on (key 0 is never masked)
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        // p = exp2((s - max) * qscale) on the raw dot products (round 5; attention_fused.hip has the reasoning): the difference of
+        // nearby logits is exact, only a small number is rounded by the scale.  Same instruction count as scale-then-subtract.
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * qscale);
         float ps = 0.f;
         if (active) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float p[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(S[4 * g + e] - m_new);
+                for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f((S[4 * g + e] - m_new) * qscale);
                 ps += (p[0] + p[1]) + (p[2] + p[3]);
                 unsigned a[4];
                 h2_words<false>(p[0], p[1], a[0], a[1]);

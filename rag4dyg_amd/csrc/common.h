@@ -91,6 +91,9 @@ enum DispatchBranch {
 extern unsigned long long g_branch_hits[BR_COUNT];
 #define R4D_BRANCH(id) (++r4d::g_branch_hits[r4d::BR_##id])
 
+// range guard (include/r4d.h: r4d_set_range_flag)
+extern unsigned* g_range_flag;         // bits: R4D_RANGE_NONFINITE_HIDDEN, R4D_RANGE_BAD_NORM
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -159,6 +159,7 @@ int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* 
 
 int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode == 2 ? 2 : (mode != 0); return R4D_OK; }
 int r4d_get_gemm_split3(void) { return g_gemm_split3; }
+int r4d_set_range_flag(uint32_t* flag_d) { g_range_flag = flag_d; return R4D_OK; }
 int r4d_set_attention_h2(int32_t on) {
     const int prev = g_attention_h2;
     g_attention_h2 = on != 0;

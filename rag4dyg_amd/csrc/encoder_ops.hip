@@ -563,7 +563,7 @@ template <int NV>                                   // NV = ceil over the instan
 __global__ __launch_bounds__(256) void lnf_partial_kernel(const RowTable G, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ b, int d,
                                                           float eps, float* __restrict__ hidden_out,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, unsigned* __restrict__ range_flag) {
     extern __shared__ float red[];                     // [4][d]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int chunk = blockIdx.x, seq = blockIdx.y;
@@ -597,6 +597,9 @@ __global__ __launch_bounds__(256) void lnf_partial_kernel(const RowTable G, cons
 #pragma unroll
         for (int i = 0; i < NV; ++i) if (i < nv) { const float c = v[r][i] - mean; q += c * c; }
         const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+        // range guard (r4d_set_range_flag): a non-finite residual row -- what an activation beyond the fp16 range of the f16x2
+        // GEMMs / h2 words turns into -- or a variance that overflowed leaves rstd NaN or 0 (wave-uniform)
+        if (range_flag && t < t1 && !(rstd > 0.f) && lane == 0) atomicOr(range_flag, R4D_RANGE_NONFINITE_HIDDEN);
         if (t < t1) {
             const long long base = (row0 + t) * d;
 #pragma unroll
@@ -633,6 +636,8 @@ __global__ __launch_bounds__(256) void meanpool_reduce_kernel(const RowTable G, 
 
 size_t lnf_meanpool_scratch_floats(int B, int T, int d) { return (size_t)B * cdiv(T, LNF_ROWS_PER_CHUNK) * d; }
 
+unsigned* g_range_flag = nullptr;       // r4d_set_range_flag: caller-owned device word, OR-ed by lnf_partial_kernel / normalize_rows_kernel
+
 int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* w, const float* b, int d, float eps,
                                float* hidden_out, float* pool_out, float* scratch, hipStream_t s) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "ln_f: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
@@ -650,9 +655,9 @@ int launch_lnf_meanpool_groups(const RowGroups& G, const float* x, const float* 
         const dim3 grid(cdiv(Tmax, LNF_ROWS_PER_CHUNK), nseq);
         float* part = pool_out ? scratch : nullptr;
         if (d <= 512) R4D_BRANCH(LNF_8); else if (d <= 1024) R4D_BRANCH(LNF_16); else R4D_BRANCH(LNF_32);
-        if (d <= 512) hipLaunchKernelGGL(lnf_partial_kernel<8>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
-        else if (d <= 1024) hipLaunchKernelGGL(lnf_partial_kernel<16>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
-        else hipLaunchKernelGGL(lnf_partial_kernel<32>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part);
+        if (d <= 512) hipLaunchKernelGGL(lnf_partial_kernel<8>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part, g_range_flag);
+        else if (d <= 1024) hipLaunchKernelGGL(lnf_partial_kernel<16>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part, g_range_flag);
+        else hipLaunchKernelGGL(lnf_partial_kernel<32>, grid, dim3(256), 4 * d * sizeof(float), s, t, x, w, b, d, eps, hidden_out, part, g_range_flag);
         R4D_CHECK_LAUNCH("lnf_partial");
     }
     if (pool_out) {

@@ -21,7 +21,7 @@ int dbgflag_scan() { return SCAN_DBG != 0; }
 
 // ------------------------------------------------------------------------------------ normalise rows
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int n, int d,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, unsigned* __restrict__ range_flag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float nrm = sqrtf(s);                       // x / x.norm(dim=1, keepdim=True): no eps
+    // range guard (r4d_set_range_flag): a row that cannot be normalised (NaN / inf element, overflowed or zero norm) would reach
+    // the scan as NaN scores, which the selection orders below everything -- an ordinary-looking top-k of garbage
+    if (range_flag && !(nrm > 0.f && nrm < __builtin_inff()) && lane == 0) atomicOr(range_flag, R4D_RANGE_BAD_NORM);
     for (int c = lane; c < d; c += 64) out[(long long)row * d + c] = p[c] / nrm;
 }
 
@@ -876,7 +879,7 @@ int r4d_normalize_rows_f32(const float* x_d, int32_t n, int32_t d, float* out_d,
     R4D_REQUIRE(x_d && out_d && n >= 0 && d >= 1, "normalize_rows: bad arguments");
     if (n == 0) return R4D_OK;
     ProfScope prof(PK_NORMALIZE, 8.0 * n * d, (hipStream_t)stream);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x_d, n, d, out_d);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x_d, n, d, out_d, g_range_flag);
     R4D_CHECK_LAUNCH("normalize_rows");
     return R4D_OK;
 }

@@ -347,6 +347,7 @@ class GPT2Model(_PreTrained):
             B, T = inputs_embeds.shape[:2]
         L = self.config.n_layer
         lib = _lib.load()
+        ops.range_flag(dev)                                           # range guard registered (include/r4d.h, ABI v6)
         c, w, _keep = self._c_structs()
         ws = ops.workspace(lib.r4d_gpt2_workspace_bytes(ctypes.byref(c), B, T), dev, "gpt2")
         out = {}
@@ -427,6 +428,7 @@ class GPT2Model(_PreTrained):
             ts.append(b.to(torch.float32).contiguous() if embeds else b.view(-1, b.shape[-1]).to(torch.int64).contiguous())
         n, dev = len(ts), ts[0].device
         lib = _lib.load()
+        ops.range_flag(dev)
         c, w, _keep = self._c_structs()
         Bs = (ctypes.c_int32 * n)(*[int(t.shape[0]) for t in ts])
         Ts = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in ts])
@@ -529,6 +531,7 @@ class GPT2Model(_PreTrained):
         n = len(ids)
         dev = ids[0].device
         lib = _lib.load()
+        ops.range_flag(dev)
         c, w, _keep = self._c_structs()
         Bs = (ctypes.c_int32 * n)(*[int(t.shape[0]) for t in ids])
         Ts = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in ids])
@@ -556,8 +559,27 @@ class GPT2Model(_PreTrained):
             if val is not None:
                 raise NotImplementedError(f"{name} is never passed on the encode-and-retrieve path "
                                           "(train_retriever.py:419,430; utils/model.py:222) and is not built")
+        src = input_ids if input_ids is not None else inputs_embeds
+        if src is not None and src.is_cuda:
+            ops.range_flag(src.device).zero_()
         r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states,
                         want_qkv=self.output_past)
+        # range guard (include/r4d.h, ABI v6): the reference-shaped call hands tensors to arbitrary code, so it reads the word
+        # itself -- one f16x2 -> bf16x3 re-run with a warning, then R4DError; NaN hidden states are never returned
+        flag = ops.take_range_flag()
+        if flag & ops.RANGE_NONFINITE_HIDDEN and ops.gemm_mode() == "f16x2":
+            import warnings
+            warnings.warn("rag4dyg_amd: an activation left the fp16 range of the f16x2 arithmetic (non-finite hidden state); "
+                          "re-running this forward with the bf16x3 GEMMs", RuntimeWarning, stacklevel=2)
+            ops.set_gemm_mode("bf16x3")
+            try:
+                r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states,
+                                want_qkv=self.output_past)
+                flag = ops.take_range_flag()
+            finally:
+                ops.set_gemm_mode("f16x2")
+        if flag & ops.RANGE_NONFINITE_HIDDEN:
+            raise _lib.R4DError("forward: a non-finite hidden state reached ln_f (weights or inputs overflow fp32 itself, or hold NaN)")
         outputs = (r["hidden"],)
         if self.output_past:
             outputs = outputs + (self._presents(r["qkv"]),)

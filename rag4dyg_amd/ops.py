@@ -233,8 +233,49 @@ def lm_logits(hidden, wte):
     return out
 
 
+# ------------------------------------------------------------------------------------------- range guard (include/r4d.h, ABI v6)
+RANGE_NONFINITE_HIDDEN, RANGE_BAD_NORM = 1, 2
+_RANGE_FLAG = None
+
+
+def range_flag(device=None):
+    """The process's range-guard word (int32 [1] on the GPU), registered with the library on first use (``r4d_set_range_flag``):
+    bit 0 = a non-finite row reached ln_f in an ``encode_*`` call (in f16x2 mode: an activation beyond the fp16 range), bit 1 = a
+    row that could not be normalised (NaN / inf / zero norm).  Sticky: the library only ORs bits in."""
+    global _RANGE_FLAG
+    if _RANGE_FLAG is None:
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        _RANGE_FLAG = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(_lib.load().r4d_set_range_flag(_RANGE_FLAG.data_ptr()), "set_range_flag")
+    return _RANGE_FLAG
+
+
+def take_range_flag():
+    """Read AND clear the range-guard word (one device synchronisation).  0 = every encode / normalise since the last call stayed
+    in range."""
+    f = range_flag()
+    v = int(f.item())
+    if v:
+        f.zero_()
+    return v
+
+
+def check_range(what):
+    """Raise ``R4DError`` if the range-guard word is set (and clear it): the point where results are about to leave the device."""
+    v = take_range_flag()
+    if v:
+        why = []
+        if v & RANGE_NONFINITE_HIDDEN:
+            why.append("a non-finite hidden state reached ln_f (an activation, q, k or v beyond the arithmetic's range: "
+                       "|x| >= 2^18 in gemm mode 'f16x2'; 'bf16x3' and 'f32' have fp32's exponent range)")
+        if v & RANGE_BAD_NORM:
+            why.append("an embedding row could not be normalised (NaN, inf or zero norm)")
+        raise _lib.R4DError(f"{what}: " + "; ".join(why) + " -- no ranking was produced from it")
+
+
 def normalize_rows(x):
     n, d = x.shape
+    range_flag(x.device)
     out = torch.empty_like(x)
     check(_lib.load().r4d_normalize_rows_f32(_dev(x, torch.float32, "x"), n, d, out.data_ptr(), _stream()),
           "normalize_rows")

@@ -96,3 +96,29 @@ def gemm_mode(request):
     ops.set_gemm_mode(request.param)
     yield request.param
     ops.set_gemm_mode(was)
+
+
+def g13_state_dict(case, g=None):
+    """Weights of one G13 case rebuilt exactly as ``oracle/gen_golden.py g13`` built them for the reference model -- the trained
+    G10 tensors (head_dim 128 cases, n_head = 1) or the seeded L2 H2 d512 model (head_dim 256), then the committed
+    ``stress_transform`` / ``sharpen_attention`` -- and checked against the fixture's per-tensor bit checksums.
+    Returns (state dict without the tied ``lm_head.weight``, n_head)."""
+    import torch
+    from oracle import gpt2_ref
+    g = g if g is not None else load_golden("g13_h2_attention_stress")
+    if case.startswith("hd128"):
+        gw = load_golden("g10_trained_small")
+        sd = {n[2:]: torch.from_numpy(gw[n]) for n in gw.files if n.startswith("w:")}
+        sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    else:
+        sd = gpt2_ref.make_state_dict(2, 512, 1801, seed=int(g["seed_hd256"]), random_affine=True)
+    if case != "hd128_plain":
+        sd = gpt2_ref.stress_transform(sd)
+    if case.endswith("peaked"):
+        sd = gpt2_ref.sharpen_attention(sd, 4.0 if case.startswith("hd128") else 6.0)
+    assert np.array_equal(gpt2_ref.weight_bit_checksums(sd), g[case + ":weight_checksums"]), \
+        f"G13 {case}: the transforms no longer produce the fixture's weights"
+    L, H, d, V, n_pos = (int(x) for x in g[case + ":cfg"])
+    assert sd["transformer.wte.weight"].shape == (V, d) and gpt2_ref.n_layers_of(sd) == L
+    sd = {n: v for n, v in sd.items() if n != "lm_head.weight"}
+    return sd, H

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.r4d_abi_version() == _lib.R4D_ABI_VERSION == 5
+    assert lib.r4d_abi_version() == _lib.R4D_ABI_VERSION == 6
     assert lib.r4d_build_flags() == 0                      # the in-tree library is a product build, not an ablation
     assert lib.r4d_last_error() == b""
     assert lib.r4d_profile_num_classes() > 0 and lib.r4d_profile_class_name(0).startswith(b"gemm")
