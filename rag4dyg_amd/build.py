@@ -78,6 +78,49 @@ def check_handoff_lowering(src):
                                "is no longer lowered to write-through / L1-bypassing instructions; use release / acquire there")
 
 
+# Packed-fp32 instructions with an SGPR operand in the f16x2 kernels (ADVICE r4 medium / VERDICT r4 item 8a).  Round 4 saw a
+# compiler-formed v_pk_fma_f32 with an SGPR-pair multiplier give a wrong high half in the lanes (lane & 12) == 12 of an epilogue
+# variant that was then removed.  tools/pk_fma_probe.hip (run by tests/test_gpu_dispatch.py on the GPU) checks every operand
+# FORM below against scalar arithmetic straight behind MFMAs on gfx950: all agree, bit-reproducibly -- the instruction forms are
+# exonerated (the lanes that were wrong are exactly the lanes whose LDS-image swizzle class (li >> 2) & 3 is 3: that variant's own
+# fragment addressing, gone with it).  What stays is a census: a shipped kernel may contain only forms the probe has covered
+# (register numbers normalised; SGPR operand broadcast from its low word, or a genuine pair).  A new form fails the build until
+# the probe covers it.
+PACKED_F32_FILES = ("gemm_h2.hip", "attention_h2.hip")
+PACKED_F32_FORMS = {
+    "v_pk_mul_f32 V, V, S op_sel_hi:[1,0]", "v_pk_mul_f32 V, S, V op_sel_hi:[0,1]", "v_pk_mul_f32 V, V, S", "v_pk_mul_f32 V, S, V",
+    "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,1]", "v_pk_fma_f32 V, S, V, V op_sel_hi:[0,1,1]",
+    "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]",
+    "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]",
+    "v_pk_fma_f32 V, S, V, V op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]",
+    "v_pk_add_f32 V, V, S op_sel_hi:[1,0]", "v_pk_add_f32 V, S, V op_sel_hi:[0,1]",
+}
+
+
+def check_packed_f32_forms(src):
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "--offload-device-only", "-S", src, "-o", asm],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+        text = open(asm).read()
+    seen = {}
+    for ln in re.findall(r"^\s*(v_pk_(?:fma|mul|add)_f32 [^\n;]*)", text, re.M):
+        if not re.search(r"\bs\[?\d", ln):
+            continue
+        form = re.sub(r"a\[[0-9:]+\]", "V", re.sub(r"v\[[0-9:]+\]", "V", re.sub(r"\bs\[[0-9:]+\]|\bs\d+\b", "S", ln))).strip()
+        seen[form] = seen.get(form, 0) + 1
+    new = {f: n for f, n in seen.items() if f not in PACKED_F32_FORMS}
+    if new:
+        raise RuntimeError(f"packed-fp32 census FAILED for {os.path.basename(src)}: operand forms with an SGPR source that "
+                           f"tools/pk_fma_probe.hip has not verified on gfx950: {new} -- add the form to the probe, run it on the GPU, "
+                           "then list it in rag4dyg_amd/build.py:PACKED_F32_FORMS (or pin that arithmetic scalar)")
+    return seen
+
+
 def build_library(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = _deps_mtime()
@@ -87,6 +130,8 @@ def build_library(force=False, verbose=True):
     for src, (_o, compiled) in zip(sources(), res):
         if compiled and os.path.basename(src) in HANDOFF_KERNELS:
             check_handoff_lowering(src)
+        if compiled and os.path.basename(src) in PACKED_F32_FILES:
+            check_packed_f32_forms(src)
     # (also when an earlier run compiled objects but stopped before the link, e.g. on a failed hand-off check)
     stale = os.path.exists(LIB) and any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
     if force or stale or any(c for _, c in res) or not os.path.exists(LIB):
