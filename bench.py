@@ -191,14 +191,15 @@ def verify_sharded(world, rank, device, index, last_out, model, q_batches, args,
         print(f"[bench] VERIFY FAILED: sharded top-k differs from the one-GPU recomputation on ranks {[r for r, o in enumerate(oks) if not o]}",
               file=sys.stderr)
     ms = [1e3 * t_ / args.steps for t_ in times]
-    # the step's two collectives on their own, HIP-event timed on this rank (embeddings: Q*d*4 B per rank; candidates: Q*k*12 B)
+    # the step's two collectives on their own, HIP-event timed on this rank (embeddings: Q*d*4 B per rank; candidates: Q*k*12 B, values and indices in ONE tensor)
     coll = {}
     try:
         cand_v = torch.zeros(q_all.shape[0], k, dtype=torch.float32, device=device)
         cand_i = torch.zeros(q_all.shape[0], k, dtype=torch.int64, device=device)
         q_loc = q_all[:q_all.shape[0] // world].contiguous()
+        from rag4dyg_amd.dist import pack_candidates, unpack_candidates
         for name, fn in (("all_gather_embeddings_us", lambda: gather(q_loc)),
-                         ("all_gather_candidates_us", lambda: (gather(cand_v), gather(cand_i)))):
+                         ("all_gather_candidates_us", lambda: unpack_candidates(gather(pack_candidates(cand_v, cand_i)), k))):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()

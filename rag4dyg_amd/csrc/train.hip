@@ -35,7 +35,7 @@ int launch_softmax_bwd(const float* P, float* dP, int nbh, int T, int ld, float 
 int launch_transpose(const float* in, int rows, int cols, long long ld_in, long long stride_in, float* out, long long ld_out,
                      long long stride_out, int nbatch, hipStream_t s);
 int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int d, int vocab, unsigned long long* acc_wte, float* dwpe,
-                         int first_group, hipStream_t s);
+                         int first_group, long long table_rows, hipStream_t s);
 int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, float* out, hipStream_t s);
 int launch_meanpool_bwd(const float* d_pool, long long rows, int T, int d, float* dh, hipStream_t s);
 
@@ -427,7 +427,7 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
     R4D_HIP(hipMemsetAsync(acc, 0, ((size_t)cfg->vocab * d + 1) * sizeof(unsigned long long), s));       // table + poison word
     R4D_HIP(hipMemsetAsync(gr->wpe, 0, (size_t)cfg->n_positions * d * sizeof(float), s));
     for (const TrainGroup& G : gs)
-        if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, G.B, G.T, d, cfg->vocab, acc, gr->wpe, 0, s))) return rc;
+        if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, G.B, G.T, d, cfg->vocab, acc, gr->wpe, 0, (long long)M, s))) return rc;
     return launch_embedding_fix_to_f32(acc, (long long)cfg->vocab * d, gr->wte, s);
 }
 

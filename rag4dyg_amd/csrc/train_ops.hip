@@ -218,15 +218,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 //   * dwte: which rows share a token is data dependent, so the contributions are added as 64-bit FIXED-POINT integers
 //     (value * 2^44, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
 //     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 5.7e-14, range +-5.2e5.
-//     A NON-FINITE contribution, or one beyond +-2^17 (no sum of 2^3 .. 2^5 such terms can wrap the 64 bits unnoticed), has
-//     no fixed-point image: it sets the POISON word behind the table and the conversion then writes NaN into the whole
+//     A NON-FINITE contribution, or one beyond +-`max_abs`, has no fixed-point image.  `max_abs` = min(2^17, 2^18 / M) for the
+//     M token rows that add into one table (launch_embedding_bwd): at most M contributions can meet in one element, each below
+//     max_abs 2^44, so their sum stays below 2^62 and CANNOT wrap the 64 bits (round 4 bounded the term at 2^17 alone: four
+//     same-sign terms at the limit wrapped unnoticed -- ADVICE r4).  At the 80k rows of a retriever step the bound is 3.3 per
+//     element, three orders above any gradient a clipped run produces.  Such a contribution
+//     sets the POISON word behind the table and the conversion then writes NaN into the whole
 //     gradient -- a diverged step stays as loud as with float atomics (NaN gradient norm, NaN parameters after the clip)
 //     instead of turning into a finite, wrong update.  Contributions below 1e-10 lose relative precision (the
 //     resolution is absolute); the training configurations of the reference's scripts sit eight orders above that.
 constexpr double EMB_FIX = 17592186044416.0;            // 2^44
 constexpr float EMB_MAX_ABS = 131072.0f;                // 2^17
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
-                                                            long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte) {
+                                                            long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte,
+                                                            float max_abs) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     bool poison = false;
     for (int c = lane; c < d; c += 64) {
         const float g = dx[row * d + c];
-        if (!(fabsf(g) <= EMB_MAX_ABS)) { poison = true; continue; }              // NaN, Inf or out of range
+        if (!(fabsf(g) <= max_abs)) { poison = true; continue; }                  // NaN, Inf or out of range
         const long long q = __double2ll_rn((double)g * EMB_FIX);
         atomicAdd(acc_wte + id * d + c, (unsigned long long)q);
     }
@@ -457,11 +462,14 @@ int launch_transpose(const float* in, int rows, int cols, long long ld_in, long 
 }
 // one batch [B, T] of a step: token part into the fixed-point table `acc_wte` [vocab, d] (zeroed by the caller once per step),
 // position part into dwpe rows [0, T) (`first_group`: the step's first batch overwrites, later ones add -- in call order)
+// `table_rows`: ALL token rows that add into this table before it is converted (every batch of the backward call)
 int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int d, int vocab, unsigned long long* acc_wte, float* dwpe,
-                         int first_group, hipStream_t s) {
+                         int first_group, long long table_rows, hipStream_t s) {
     const long long rows = (long long)B * T;
     if (rows <= 0) return R4D_OK;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte);
+    R4D_REQUIRE(table_rows >= rows, "embedding_bwd: table_rows %lld < rows %lld", table_rows, rows);
+    const float max_abs = fminf(EMB_MAX_ABS, 262144.0f / (float)table_rows);       // 2^62 / 2^44 / rows: the sum cannot wrap
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte, max_abs);
     R4D_CHECK_LAUNCH("embedding_bwd");
     hipLaunchKernelGGL(wpe_bwd_kernel, dim3((unsigned)(((long long)T * d + 255) / 256)), dim3(256), 0, s, dx, B, T, d, first_group, dwpe);
     R4D_CHECK_LAUNCH("wpe_bwd");

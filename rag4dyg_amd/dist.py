@@ -82,6 +82,23 @@ def encode_pool_sharded(encode, batches, group=None):
     return all_gather_rows(mine, counts, group)
 
 
+def pack_candidates(vals, idx):
+    """(vals [Q,k] f32, idx [Q,k] i64) -> ONE uint8 tensor [1, Q, 12k] (the value bytes, then the index bytes, per query): the
+    per-shard candidates travel in one all-gather instead of two (the collectives of a step are
+    latency-bound, far from the per-link bandwidth).  Lossless: ``unpack_candidates`` returns the same bits."""
+    Q = vals.shape[0]
+    return torch.cat([vals.contiguous().view(torch.uint8).reshape(Q, -1), idx.contiguous().view(torch.uint8).reshape(Q, -1)],
+                     dim=1).unsqueeze(0)
+
+
+def unpack_candidates(packed, k):
+    """[G, Q, 12k] uint8 (``pack_candidates`` of G ranks) -> (vals [G,Q,k] f32, idx [G,Q,k] i64)."""
+    G, Q = packed.shape[0], packed.shape[1]
+    vals = packed[..., :4 * k].contiguous().view(torch.float32).reshape(G, Q, k)
+    idx = packed[..., 4 * k:].contiguous().view(torch.int64).reshape(G, Q, k)
+    return vals, idx
+
+
 def sharded_topk(q_hat_all, pool_hat_shard, shard_offset, k, local_topk, merge, group=None):
     """Global top-k of every query against the sharded pool.
 
@@ -101,15 +118,14 @@ def sharded_topk(q_hat_all, pool_hat_shard, shard_offset, k, local_topk, merge, 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return vals, idx
-    gv = all_gather_cat(vals.unsqueeze(0), group)          # [G,Q,k]
-    gi = all_gather_cat(idx.unsqueeze(0), group)
+    gv, gi = unpack_candidates(all_gather_cat(pack_candidates(vals, idx), group), k)     # ONE collective: [G,Q,12k] bytes
     return merge(gv, gi)
 
 
 class PipelinedShardedTopK:
     """``sharded_topk`` as a three-stage software pipeline over query batches (one batch per ``submit``).
 
-    A batch needs two collectives (query embeddings, then per-shard candidates).  Run synchronously, every rank waits for
+    A batch needs two collectives (query embeddings, then the per-shard candidates: values and indices packed into one tensor).  Run synchronously, every rank waits for
     the slowest rank TWICE per batch -- and ranks are unequal from batch to batch, because each pads its own query batches
     to their own lengths.  Here both collectives are started asynchronously and consumed one ``submit`` later each:
 
@@ -127,7 +143,7 @@ class PipelinedShardedTopK:
         self.local_topk, self.merge, self.group = local_topk, merge, group
         self.world = dist.get_world_size(group)
         self._q = None          # (work, gathered queries, keep-alive)
-        self._cand = None       # ((work, gathered vals, keep), (work, gathered idx, keep))
+        self._cand = None       # (work, gathered packed candidates [G,Q,12k], keep)
 
     def _start_gather(self, t):
         t = t.contiguous()
@@ -149,9 +165,9 @@ class PipelinedShardedTopK:
     def _step(self, q_hat):
         done = None
         if self._cand is not None:
-            (wv, gv, _), (wi, gi, _) = self._cand
-            wv.wait(); wi.wait()
-            done = self.merge(gv, gi)                                   # [G,Q,k] each
+            wc, gc, _ = self._cand
+            wc.wait()
+            done = self.merge(*unpack_candidates(gc, self.k))           # [G,Q,k] each
             self._cand = None
         if self._q is not None:
             w, q_all, _ = self._q
@@ -164,7 +180,7 @@ class PipelinedShardedTopK:
                 v, i = self.local_topk(q_all, self.pool, kk, self.offset)
                 vals[:, :kk] = v
                 idx[:, :kk] = i
-            self._cand = (self._start_gather(vals.unsqueeze(0)), self._start_gather(idx.unsqueeze(0)))
+            self._cand = self._start_gather(pack_candidates(vals, idx))
             self._q = None
         if q_hat is not None:
             self._q = self._start_gather(q_hat)

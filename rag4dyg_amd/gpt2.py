@@ -76,9 +76,16 @@ def skip_random_init():
     """Construct a model WITHOUT drawing its random initial weights -- for callers that overwrite every parameter right afterwards
     (the evaluation-only command lines: strict ``load_state_dict`` of a checkpoint).  The draws were 0.46 s of a 0.56 s
     ``main_retriever.py --do_eval`` run (each tensor initialised twice on the CPU, by its torch module and by ``_init_weights``,
-    then replaced by the checkpoint).  Parameters are left as allocated (arbitrary bytes): never use such a model unloaded."""
+    then replaced by the checkpoint).  Every weight that WOULD have been drawn is filled with NaN instead (a memset, not a
+    draw): a tensor a later non-strict or partial load leaves out turns every output NaN, which the range guard reports
+    (``ops.check_range``) -- it cannot evaluate quietly on arbitrary bytes.  Not thread-safe: ``torch.nn.init`` is
+    patched process-wide for the duration of the ``with`` block; construct models on one thread."""
     saved = (nn.init.normal_, nn.init.kaiming_uniform_, nn.init.uniform_)
-    nn.init.normal_ = nn.init.kaiming_uniform_ = nn.init.uniform_ = lambda t, *a, **k: t
+
+    def _nan_fill(t, *a, **k):
+        with torch.no_grad():
+            return t.fill_(float("nan"))
+    nn.init.normal_ = nn.init.kaiming_uniform_ = nn.init.uniform_ = _nan_fill
     _SKIP_INIT[0] = True
     try:
         yield
@@ -93,7 +100,7 @@ class Conv1D(nn.Module):
     def __init__(self, nf, nx):
         super().__init__()
         self.nf = nf
-        self.weight = nn.Parameter(torch.empty(nx, nf) if _SKIP_INIT[0] else torch.empty(nx, nf).normal_(std=0.02))
+        self.weight = nn.Parameter(torch.full((nx, nf), float("nan")) if _SKIP_INIT[0] else torch.empty(nx, nf).normal_(std=0.02))
         self.bias = nn.Parameter(torch.zeros(nf))
 
     def forward(self, x):
@@ -137,6 +144,8 @@ class _PreTrained(nn.Module):
         if isinstance(module, (nn.Linear, nn.Embedding, Conv1D)):
             if not _SKIP_INIT[0]:
                 module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+            else:
+                module.weight.data.fill_(float("nan"))                 # loud if no checkpoint tensor replaces it
             if isinstance(module, (nn.Linear, Conv1D)) and module.bias is not None:
                 module.bias.data.zero_()
         elif isinstance(module, nn.LayerNorm):
@@ -225,6 +234,8 @@ class GPT2Model(_PreTrained):
         new = nn.Embedding(new_num_tokens, old.embedding_dim).to(old.weight.device)
         if not _SKIP_INIT[0]:
             new.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        else:
+            new.weight.data.fill_(float("nan"))
         n = min(old.num_embeddings, new_num_tokens)
         new.weight.data[:n, :] = old.weight.data[:n, :]
         self.wte = new

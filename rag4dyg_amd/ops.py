@@ -80,11 +80,16 @@ def gemm_mode():
     return _GEMM_MODE
 
 
+_LAST_SPLIT_MODE = None
+
+
 def set_gemm_mode(mode):
-    global _GEMM_MODE
+    global _GEMM_MODE, _LAST_SPLIT_MODE
     if mode not in _GEMM_MODES:
         raise ValueError(f"gemm mode {mode!r}: one of {sorted(_GEMM_MODES)}")
     _GEMM_MODE = mode
+    if mode != "f32":
+        _LAST_SPLIT_MODE = mode
     check(_lib.load().r4d_set_gemm_split3(_GEMM_MODES[mode]), "set_gemm_split3")
 
 
@@ -95,12 +100,14 @@ def gemm_split3_enabled():
 
 
 def set_gemm_split3(on):
-    """Older switch: True -> the default split mode ("bf16x3" unless the process selected "f16x2"), False -> "f32"."""
+    """Older on / off switch.  False -> "f32".  True -> the split mode that was selected LAST in this process ("f16x2" or
+    "bf16x3": off-then-on returns to where it was), else ``R4D_GEMM_MODE`` if that names a split mode, else
+    ``DEFAULT_GEMM_MODE``; a no-op while a split mode is already selected."""
     if not on:
         set_gemm_mode("f32")
     elif gemm_mode() == "f32":
         import os
-        m = os.environ.get("R4D_GEMM_MODE", DEFAULT_GEMM_MODE)
+        m = _LAST_SPLIT_MODE or os.environ.get("R4D_GEMM_MODE", DEFAULT_GEMM_MODE)
         set_gemm_mode(m if m != "f32" else DEFAULT_GEMM_MODE)
 
 

@@ -466,13 +466,15 @@ def train_epoch(all_query_time, epoch, model, trainer, optimizer, train_dataload
     this)."""
     tr_loss = tr_cl = tr_aug = 0.0
     model.train()                                              # :161 -- dropout on (EncoderTrainer reads model.training)
-    for i, batch in enumerate(train_dataloader):
-        if args.lrdecay == 1:
-            adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
-        if steps_trained_in_current_epoch > 0:
+    i = 0                                                      # counts PROCESSED batches only, as upstream: its `continue` (:165-167)
+    for batch in train_dataloader:                             # comes before `i += 1` / `step += 1`, so a skipped batch advances
+        if steps_trained_in_current_epoch > 0:                 # neither the lr-schedule index nor the accumulation counter
             steps_trained_in_current_epoch -= 1
             continue
+        if args.lrdecay == 1:
+            adjust_learning_rate(args, optimizer, epoch, args.learning_rate, i, len(train_dataloader))
         r = training_step(args, model, trainer, optimizer, batch, all_query_time, micro_step=i, sync=False)
+        i += 1
         tr_loss = tr_loss + r["loss"]; tr_cl = tr_cl + r["cl_loss"]; tr_aug = tr_aug + r["aug_loss"]   # device sums: no wait per step
         if r["stepped"]:                                       # an optimizer update (train_retriever.py:212-221)
             global_step += 1

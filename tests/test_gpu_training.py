@@ -258,15 +258,24 @@ def test_non_finite_gradient_stays_loud_in_the_deterministic_embedding_sum(dev):
     opt = training.AdamW(trainer.params, trainer.grads, lr=1e-3, flat_grads=trainer.flat_grads)
     opt.sumsq.zero_()
     assert not np.isfinite(float(trainer.flat_grads.double().pow(2).sum().sqrt()))
+    # the per-term bound follows the number of rows that meet in one table (2^18 / rows), so that NO run of same-sign
+    # contributions can wrap the 64-bit sum into a finite wrong value: one token in every position, upstream gradient 1e5 each --
+    # round 4's fixed 2^17 bound let 36 terms of ~2^61 wrap silently; now the step is poisoned (NaN), and a run of contributions
+    # inside the bound still sums exactly
+    same = torch.full((4, 9), 7, dtype=torch.int64, device=dev)
+    trainer.forward([same])
+    huge = trainer.backward(torch.full_like(emb, 1e5))["transformer.wte.weight"]
+    assert torch.isnan(huge).all() or torch.isfinite(huge).all() and huge[7].abs().max() > 1e3, "a wrapped fixed-point sum"
 
 
+@pytest.mark.parametrize("split_mode", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("via_step", [True, False])
-def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step):
+def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step, split_mode):
     """``r4d_adamw_step_f32`` writes the parameters through raw pointers, so torch's version counters do not
     move and the inference path's derived weights (transposed copies, bf16x3 planes -- default ON --, LayerNorm-folded decode
     weights) would stay at the values of the first validation.  Encode, take one optimizer step with a LARGE learning rate
     (through ``training_step`` and through a bare ``AdamW.step``), then the model's encode -- and one cached decode step -- must equal
-    the same calls on a fresh copy of the updated weights, with the bf16x3 GEMMs on."""
+    the same calls on a fresh copy of the updated weights -- under BOTH split arithmetics (each has its own plane cache)."""
     from oracle import gpt2_ref
     from rag4dyg_amd import ops, training
     from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
@@ -281,8 +290,8 @@ def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step):
     m = GPT2LMHeadModelRAG(cfg)
     m.load_state_dict(sd, strict=False)
     m = m.to(dev).eval()
-    was = ops.gemm_split3_enabled()
-    ops.set_gemm_split3(True)
+    was = ops.gemm_mode()
+    ops.set_gemm_mode(split_mode)                                  # BOTH plane caches: _h2_cache (f16x2) and _w3_cache (bf16x3)
     try:
         T = torch.from_numpy
         idx = T(g[tag + "_idx"])
@@ -315,7 +324,7 @@ def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step):
         fresh.transformer.prefill(kv2, input_ids=ids)
         want_dec = fresh.transformer.decode_step(kv2, pos0, input_ids=ids[:, -1])
     finally:
-        ops.set_gemm_split3(was)
+        ops.set_gemm_mode(was)
     moved = (after - before).abs().max().item() / before.abs().max().item()
     assert moved > 1e-2, f"the step did not move the embeddings ({moved:.2e}): the test would prove nothing"
     assert torch.equal(after, want), f"stale derived weights after the optimizer step: {(after - want).abs().max().item():.3e}"
