@@ -296,6 +296,39 @@ def scan_q32_shard8(index, shape, k, device):
     return out
 
 
+def scan_operating_points(index, shape, k, device, reps=20):
+    """N = 1 only: scan + top-k at the sizes the bench's steps REALLY run.  ``step_q256`` -- the 256 queries of a
+    step against the whole resident pool (N = 1); ``n8_rank_q2048_shard`` -- what ONE rank of the 8-GPU weak-scaling run does per step:
+    the 2,048 gathered queries against its 12,512-row shard.  HIP-event timed per kernel class; reported against the bf16x3 MFMA
+    ceiling (2,500 / 6 TFLOP/s of fp32-equivalent flop) AND against one read of the shard at the HBM peak -- not against SURVEY's
+    per-32-query ``B_score``, which would credit every 32-query block with its own read of the pool."""
+    from rag4dyg_amd.dist import shard_bounds
+    lib = _lib.load()
+    n, d = int(index.pool_hat.shape[0]), shape.n_embd
+    s0, e0 = shard_bounds(n, 8)[0]
+    out = {}
+    for name, Q, pool in (("step_q256", QB * 8, index.pool_hat), ("n8_rank_q2048_shard", QB * 64, index.pool_hat[s0:e0])):
+        q = ops.normalize_rows(torch.randn(Q, d, generator=torch.Generator().manual_seed(7)).to(device))
+        rows = int(pool.shape[0])
+        for _ in range(3):
+            ops.score_topk(q, pool, k, 0)
+        torch.cuda.synchronize()
+        lib.r4d_profile_enable(1)
+        for _ in range(reps):
+            ops.score_topk(q, pool, k, 0)
+        torch.cuda.synchronize()
+        prof = read_profile()
+        lib.r4d_profile_enable(0)
+        sc, tk = prof["pool_scan"], prof.get("topk", {"ms": 0.0, "launches": 1})
+        scan_s, topk_s = sc["ms"] * 1e-3 / reps, tk["ms"] * 1e-3 / reps
+        flop = 2.0 * Q * rows * d
+        out[name] = {"queries": Q, "pool_rows": rows, "d": d, "scan_kernel_us": round(scan_s * 1e6, 1), "topk_kernel_us": round(topk_s * 1e6, 1),
+                     "scan_TFLOPs_fp32_equiv": round(flop / scan_s / 1e12, 1), "frac_of_bf16x3_mfma_ceiling": round(flop / scan_s / 1e12 / 416.7, 3),
+                     "one_read_of_the_shard_GBps": round(4.0 * rows * d / scan_s / 1e9, 1),
+                     "frac_of_hbm_peak_one_read": round(4.0 * rows * d / scan_s / 1e9 / PEAK_HBM_GBS, 4)}
+    return out
+
+
 def gemm_zero_operand_probe(shape, rows, device, reps=20):
     """Outside the timed region, f16x2 only: the step's c_attn GEMM (rows x d x 3d) on N(0,1) operands and the SAME launch on all-zero
     operands -- identical instructions, addresses and bytes, no switching activity in the multipliers.  The ratio is what the clock
@@ -559,7 +592,13 @@ def main():
                     "bytes_per_launch": v["work"] / v["launches"]}
         return roof, kernels_
 
+    ops.take_range_flag()
     out, elapsed, elapsed_local = timed_run()
+    # range guard (include/r4d.h, ABI v6): the device word every encode / normalise of the WHOLE timed region ORs into, read once
+    # here (the steps themselves stay asynchronous): non-zero = a non-finite hidden state or an embedding that could not be normalised
+    range_word = ops.take_range_flag()
+    if range_word:
+        raise SystemExit(f"[bench] range guard word {range_word:#x} after the timed region: results are not valid")
 
     roofline, kernels = None, {}
     if not args.no_roofline:
@@ -593,11 +632,15 @@ def main():
             verify = verify_sharded(world, rank, device, index, out, model, q_batches, args, G, k, gather, elapsed_local)
         except Exception as e:                                       # noqa: BLE001
             verify = {"error": f"{type(e).__name__}: {e}"}
-    scan = scan8 = None
+    scan = scan8 = scan_ops = None
     if rank == 0 and not args.no_roofline:
         scan = scan_q32(index, shape, k, device)
         if world == 1 and int(index.pool_hat.shape[0]) >= 8 * 64:
             scan8 = scan_q32_shard8(index, shape, k, device)
+            try:
+                scan_ops = scan_operating_points(index, shape, k, device)
+            except Exception as e:                                   # noqa: BLE001
+                scan_ops = {"error": f"{type(e).__name__}: {e}"}
     power_probe = None
     if rank == 0 and world == 1 and not args.no_roofline and args.gemm == "f16x2":
         try:
@@ -671,7 +714,7 @@ def main():
             "extras": {"source_sha": source_sha(), "gemm": args.gemm,
                        "attention": ("f16x2 (q, k, v as h2 words, two v_mfma_f32_32x32x16_f16 per 8 elements; csrc/attention_h2.hip)"
                                      if args.gemm == "f16x2" and (shape.n_embd // shape.n_head) in (128, 256) else "exact f32 (v_mfma_f32_32x32x2_f32)"),
-                       "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "gemm_zero_operand_probe": power_probe, "verify": verify,
+                       "range_guard_word_after_timed_region": range_word, "exact_f32": exact, "bf16x3": other_s3, "scan_q32": scan, "scan_q32_shard8": scan8, "scan_operating_points": scan_ops, "gemm_zero_operand_probe": power_probe, "verify": verify,
                        "length_bucketed": bucketed,
                        "encoder_algorithmic_TFLOPs_per_gpu": round(enc_flop / elapsed / 1e12, 2),
                        "pool_encode_seqs_per_s_per_gpu": None if args.random_pool else round(P / pool_encode_s, 1),

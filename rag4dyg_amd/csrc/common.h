@@ -74,7 +74,7 @@ struct ProfScope {
     X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
     X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
     X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \
-    X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_DMA, "scan:short shard, LDS-DMA staged") X(SCAN_RING, "scan:long shard, LDS-DMA ring") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)") X(SCAN_BF16X3, "scan:bf16x3 operands") X(SCAN_F32, "scan:exact-f32 operands")  \
+    X(SCAN_SHORT, "scan:short shard (even rows, two tiles in flight)") X(SCAN_DMA, "scan:short shard, LDS-DMA staged") X(SCAN_RING, "scan:long shard, LDS-DMA ring") X(SCAN_GEMM, "scan:tiled GEMM (Q > 64 or other d)") X(SCAN_TILED, "scan:128x256 tiles in the scan kernels' arithmetic (Q >= 64)") X(SCAN_BF16X3, "scan:bf16x3 operands") X(SCAN_F32, "scan:exact-f32 operands")  \
     X(TOPK_ONE_WG, "topk:one workgroup per row") X(TOPK_TICKET, "topk:cross-workgroup ticket merge")                      \
     X(TOPK_MULTI, "topk:second launch over candidates") X(TOPK_F64, "topk:f64 rows")                                      \
     X(EMBED_LN4, "embed+layernorm:16-byte lanes") X(EMBED_GENERIC, "embed+layernorm:generic") X(LN4_2, "layernorm:ln4<2>") X(LN4_4, "layernorm:ln4<4>") X(LN4_8, "layernorm:ln4<8>") X(LN_GENERIC, "layernorm:generic") \
@@ -153,6 +153,7 @@ bool gemm_s3_supported(int M, int K, int N);
 int launch_gemm_s3(const S3Args& a, hipStream_t stream);
 bool gemm_s3_f32b_supported(int M, int K, int N);
 int launch_gemm_s3_f32b(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, int epilogue, hipStream_t stream);
+int launch_gemm_s3_scan_order(const float* q_hat, const float* pool_hat, float* scores, int Q, int N, int d, int ng, hipStream_t stream);
 // w element (n, k) at w[k * ld_k + n * ld_n] -> planes [3][N][K] bf16 (hi, mid, lo)
 // gemm_h2.hip: the same contract on the fp16 matrix cores, two fp16 terms per operand and THREE products (planes [2][N][K])
 bool gemm_h2_supported(int M, int K, int N);

@@ -114,7 +114,18 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------- the GEMM
 // BF32: the second operand is NOT pre-split -- Bp points at fp32 rows [N][K] (k-contiguous, row stride K) that are split on the
 // fly like A (the pool of the retrieval scoring GEMM: 4 bytes per element read instead of 6, no plane copy to keep)
-template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS, int EPI, bool BF32 = false>
+//
+// SCAN = NG > 0 (with BF32; the retrieval scoring GEMM): the ARITHMETIC OF THE POOL-SCAN KERNELS of score.hip, value for value, so that a
+// score does not depend on whether its query travelled in a 32-query scan block or in a tile of this GEMM (one scoring
+// arithmetic: tests/test_gpu_ops.py::test_scores_and_topk_do_not_depend_on_query_batching stays torch.equal):
+//   * the scan splits the contraction over KW = K / (32 NG) wavefronts, wave w owning the 128-byte lines w, w + KW, ... of every
+//     row, each wave accumulating its NG lines from zero and the KW partial sums then added in the order w = 0 .. KW-1: here the
+//     k-tiles (= lines) are visited in exactly that order -- (w, g) -> line g KW + w -- the accumulator is folded into a second
+//     one (`fin`) and cleared after every NG k-tiles;
+//   * within a line, MFMA step s of lane half h holds k = 16 s + 4 h + {0..3} and 16 s + 8 + 4 h + {0..3} (the scan's two
+//     16-byte loads per step): the staging loads fetch those two pieces, 32 bytes apart, instead of 8 consecutive k;
+//   * same split (split3_pair == scan_split_pair), same six products in the same order, queries as the MFMA's first operand.
+template <int BM, int BN, int WGM, int WGN, int NBUF, int NRS, int EPI, bool BF32 = false, int SCAN = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kernel(
     const float* __restrict__ Ag, const unsigned short* __restrict__ Bp, float* __restrict__ Cg,
     const float* __restrict__ biasg, const float* __restrict__ residg, const S3Shape g) {
@@ -150,13 +161,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
-        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + c * 8) * 4;
+        a_off[i] = (min(m0 + row, g.M - 1) * g.lda + (SCAN ? (c >> 1) * 16 + (c & 1) * 4 : c * 8)) * 4;
         a_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
         const int idx = tid + i * NTHREADS, row = idx >> 2, c = idx & 3;
-        b_off[i] = (min(n0 + row, g.N - 1) * g.K + c * 8) * (BF32 ? 4 : 2);
+        b_off[i] = (min(n0 + row, g.N - 1) * g.K + (SCAN ? (c >> 1) * 16 + (c & 1) * 4 : c * 8)) * (BF32 ? 4 : 2);
         b_dst[i] = row * 4 + (c ^ ((row >> 2) & 3));
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -168,17 +179,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
     // iterations before they are split and stored (at K = 512 the A rows of a tile come from beyond the XCD's L2, one
     // iteration of flight time does not cover that latency)
     u32x4s ra[NRS][NIA][2], rb[NRS][NIB][3];            // BF32: rb[..][0..1] = the 8 fp32 of the item, split at the LDS store
+    static_assert(SCAN == 0 || BF32, "scan order: with the fp32 second operand only");
+    constexpr int P2 = SCAN ? 32 : 16;                                // byte distance of an item's two 16-byte pieces
+    const int scan_kw = SCAN ? nkt / (SCAN ? SCAN : 1) : 1;           // wavefronts the scan kernels split this K over
 #define S3_LOAD(RS, KT)                                                                            \
     {                                                                                              \
-        const int kt_ = min((KT), nkt - 1);                                                        \
+        const int kq_ = min((KT), nkt - 1);                                                        \
+        const int kt_ = SCAN ? (kq_ % (SCAN ? SCAN : 1)) * scan_kw + kq_ / (SCAN ? SCAN : 1) : kq_;   /* iteration -> line g KW + w */ \
         _Pragma("unroll") for (int i = 0; i < NIA; ++i) {                                          \
             ra[RS][i][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], kt_ * (BK * 4), 0); \
-            ra[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + 16, kt_ * (BK * 4), 0); \
+            ra[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i] + P2, kt_ * (BK * 4), 0); \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                          \
             if (BF32) {                                                                            \
                 rb[RS][i][0] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 4), 0); \
-                rb[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i] + 16, kt_ * (BK * 4), 0); \
+                rb[RS][i][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i] + P2, kt_ * (BK * 4), 0); \
             } else {                                                                               \
                 _Pragma("unroll") for (int p = 0; p < 3; ++p)                                      \
                     rb[RS][i][p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], kt_ * (BK * 2) + p * g.plane_bytes, 0); \
@@ -230,13 +245,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16s fin[SCAN ? TM : 1][SCAN ? TN : 1];                       // SCAN: the sum of the finished slices' partial sums
+    if constexpr (SCAN != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fin[i][j][r] = 0.f;
+    }
 
 #define S3_MFMA(A_, B_, I_, J_) \
     acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, A_), __builtin_bit_cast(bf16x8s, B_), acc[I_][J_], 0, 0, 0)
     // fragment registers, two sets: the reads of k-step s+1 travel under the MFMAs of k-step s
-    u32x4s fa[2][TM][3], fb[2][TN][3];
-#define S3_FRAGS(SET, STG, S)                                                                      \
+    // (SCAN: ONE set -- the second accumulator takes the registers -- a fragment is re-read as soon as the last MFMA that uses it has
+    //  issued: program order and the register dependences give the progressive refill, the other wavefront of the SIMD covers the rest)
+    u32x4s fa[SCAN ? 1 : 2][TM][3], fb[SCAN ? 1 : 2][TN][3];
+#define S3_FRAGS(SET_, STG, S)                                                                     \
     {                                                                                              \
+        constexpr int SET = SCAN ? 0 : (SET_);                                                     \
         const u32x4s* st_ = lds + (STG) * STAGE;                                                   \
         const int fo_ = (S) ? f_off1 : f_off0;                                                     \
         /* in the order the MFMAs want them: lo(A) . hi(B) first */                                \
@@ -248,8 +275,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[SET][j][1] = (S3_DBG & 1) ? dbg_frag : st_[fb_base + 1 * B_PLANE + j * 128 + fo_]; \
     }
     /* smallest partial products first; consecutive MFMAs go to different accumulators */
-#define S3_MFMAS(SET)                                                                              \
+#define S3_MFMAS(SET_)                                                                             \
     {                                                                                              \
+        constexpr int SET = SCAN ? 0 : (SET_);                                                     \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][2], fb[SET][j][0], i, j); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][0], fb[SET][j][2], i, j); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) S3_MFMA(fa[SET][i][1], fb[SET][j][1], i, j); \
@@ -293,11 +321,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
         S3_FRAGS(0, CUR, 0)                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (!(S3_DBG & 2)) S3_STORE(RS_, WR)                                                       \
-        S3_FRAGS(1, CUR, 1)                                                                        \
+        if (!SCAN) S3_FRAGS(1, CUR, 1)                                                             \
         S3_MFMAS(0)                                                                                \
+        if (SCAN) S3_FRAGS(0, CUR, 1)       /* one fragment set: k-step 1 is read into the registers k-step 0 leaves, in program order */ \
         _Pragma("unroll") for (int m_ = 0; m_ < NMF; ++m_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-            if (m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+            if (!SCAN && m_ < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              \
+            if (SCAN && m_ >= TM * TN && m_ < TM * TN + NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
             if (m_ >= NMF - 2 * NDW && ((NMF - 1 - m_) & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
         }                                                                                          \
@@ -309,6 +339,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
             if (m_ < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (SCAN && (kt % (SCAN ? SCAN : 1)) == (SCAN ? SCAN : 1) - 1) {   /* a slice ends: fold its partial sum, start the next from zero */ \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) { fin[SCAN ? i : 0][SCAN ? j : 0][r] += acc[i][j][r]; acc[i][j][r] = 0.f; } \
+        }                                                                                          \
         if (!(S3_DBG & 4)) __syncthreads();                                                        \
     }
     int kt = 0;
@@ -340,6 +374,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_s3_kerne
 #undef S3_STORE
 #undef S3_LOAD
 
+    if constexpr (SCAN != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = fin[i][j];
+    }
 #if S3_DBG & 32
     {   // ablation: no epilogue at all (one conditional store keeps the accumulators alive)
         float ssum = 0.f;
@@ -809,6 +849,29 @@ int launch_gemm_s3_f32b(const float* A, const float* B, float* C, int M, int N, 
         hipLaunchKernelGGL((gemm_s3_kernel<128, 256, 2, 4, 2, 1, EPI_NONE, true>), dim3(tiles), dim3(512), 0, stream, A, Bp, C, nullptr, nullptr, sh);
     else { set_error("gemm_s3_f32b: epilogue %d has no instantiation", epilogue); return R4D_ERR_INVALID; }
     R4D_CHECK_LAUNCH("gemm_s3_f32b");
+    return R4D_OK;
+}
+
+// The scoring GEMM in the pool-scan kernels' arithmetic (SCAN template parameter): S = (q_hat . pool_hat^T + 1) / 2 for Q >= 64, bit for
+// bit the scores pool_scan_*_kernel<KW, NG> writes (score.hip), with the pool read Q / 128 times instead of Q / 32 times and every
+// element split once per 128 x 256 tile instead of once per wavefront that touches it.  ng = lines per wavefront of the scan variant
+// of this d (d == 32 KW NG).  +1 = no instantiation.
+int launch_gemm_s3_scan_order(const float* q_hat, const float* pool_hat, float* scores, int Q, int N, int d, int ng, hipStream_t stream) {
+    if (!gemm_s3_f32b_supported(Q, d, N) || ng < 2 || ng > 4 || (d / 32) % ng != 0) return 1;      // (ng == 1, d <= 128: the fold after every k-tile spills; the 32-query blocks keep those)
+    if ((((uintptr_t)q_hat | (uintptr_t)pool_hat) & 15u) != 0 || d % 4 != 0) return 1;
+    R4D_BRANCH(SCAN_TILED);
+    const int tiles = cdiv(Q, 128) * cdiv(N, 256);
+    S3Shape sh;
+    sh.M = Q; sh.N = N; sh.K = d; sh.lda = d; sh.ldc = N; sh.ldr = N; sh.plane_bytes = 0;
+    const unsigned short* Bp = reinterpret_cast<const unsigned short*>(pool_hat);
+#define S3_SCAN_LAUNCH_(NG_) hipLaunchKernelGGL((gemm_s3_kernel<128, 256, 2, 4, 2, 1, EPI_HALF_PLUS, true, NG_>), dim3(tiles), dim3(512), 0, stream, q_hat, Bp, scores, nullptr, nullptr, sh)
+    switch (ng) {
+        case 2: S3_SCAN_LAUNCH_(2); break;
+        case 3: S3_SCAN_LAUNCH_(3); break;
+        default: S3_SCAN_LAUNCH_(4); break;
+    }
+#undef S3_SCAN_LAUNCH_
+    R4D_CHECK_LAUNCH("gemm_s3_scan_order");
     return R4D_OK;
 }
 

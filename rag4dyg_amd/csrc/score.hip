@@ -855,6 +855,19 @@ static int launch_pool_scan(const float* qhat, const float* pool, int Q, int N, 
     if (d != 32 && d != 64 && d != 128 && d != 256 && d != 384 && d != 512 && d != 768 && d != 1024) return 1;   // no variant
     // algorithmic bytes (SURVEY 8d B_score): pool read once per 32 queries + queries + score rows out
     ProfScope prof(PK_POOL_SCAN, 4.0 * N * d * cdiv(Q, 32) + 4.0 * Q * d + 4.0 * (double)Q * N, s);
+    // Q >= 64 on the split arithmetic: 128 x 256 tiles of gemm_s3.hip in THIS file's arithmetic (same slices, same k slots, same
+    // products, same order: bit-identical scores) -- the pool is read Q / 128 times instead of Q / 32 times and an element is split once
+    // per tile instead of once per wavefront that touches it (round 5; R4D_SCAN_TILED=0 keeps the 32-query blocks for every Q)
+    static int tiled = -1;
+    if (tiled < 0) { const char* e = getenv("R4D_SCAN_TILED"); tiled = e ? atoi(e) : 1; }
+    // (measured, tools/scan_q_bench.py, scan + top-10, d 512: 256 x 100k 347 -> 248 us, 2,048 x 12,512 417 -> 232 us, 128 x 100k 173 -> 128 us;
+    //  below ~0.75 tiles per CU the blocks win: 64 x 12,512 is 23 us in blocks, 53 us as 49 tiles)
+    if (tiled && Q >= 64 && g_gemm_split3 && (long long)cdiv(Q, 128) * cdiv(N, 256) >= 192) {
+        const int ng = d == 256 ? 2 : d == 384 ? 3 : d == 512 ? (kw8 ? 2 : 4) : d == 768 ? 3 : d == 1024 ? 4 : 1;
+        if (nzero > 0) R4D_HIP(hipMemsetAsync(zero_d, 0, (size_t)nzero * sizeof(unsigned), s));     // the scan kernels clear the top-k ticket counters themselves
+        const int rc = launch_gemm_s3_scan_order(qhat, pool, scores, Q, N, d, ng, s);
+        if (rc <= 0) return rc;
+    }
     switch (d) {
         case 32:   R4D_BRANCH(SCAN_1_1); return launch_scan_variant<1, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);
         case 64:   R4D_BRANCH(SCAN_2_1); return launch_scan_variant<2, 1>(qhat, pool, Q, N, scores, zero_d, nzero, s);

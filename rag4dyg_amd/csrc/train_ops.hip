@@ -216,18 +216,19 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 //   * dwpe: the rows of position t are row t of every sequence of a batch -- a plain column sum over the sequences in a fixed
 //     order, one thread per (t, column), the batches of a step one launch after the other;
 //   * dwte: which rows share a token is data dependent, so the contributions are added as 64-bit FIXED-POINT integers
-//     (value * 2^44, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
-//     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 5.7e-14, range +-5.2e5.
-//     A NON-FINITE contribution, or one beyond +-`max_abs`, has no fixed-point image.  `max_abs` = min(2^17, 2^18 / M) for the
+//     (value * 2^40, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
+//     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 9.1e-13 (round 5: was 2^-44).
+//     A NON-FINITE contribution, or one beyond +-`max_abs`, has no fixed-point image.  `max_abs` = min(2^17, 2^22 / M) for the
 //     M token rows that add into one table (launch_embedding_bwd): at most M contributions can meet in one element, each below
-//     max_abs 2^44, so their sum stays below 2^62 and CANNOT wrap the 64 bits (round 4 bounded the term at 2^17 alone: four
-//     same-sign terms at the limit wrapped unnoticed -- ADVICE r4).  At the 80k rows of a retriever step the bound is 3.3 per
-//     element, three orders above any gradient a clipped run produces.  Such a contribution
+//     max_abs 2^40, so their sum stays below 2^62 and CANNOT wrap the 64 bits (round 4 bounded the term at 2^17 alone with a 2^44
+//     scale: four same-sign terms at the limit wrapped unnoticed -- ADVICE r4).  At the 30k-80k rows of a retriever step the bound
+//     is 50-140 per element (a first cut at 2^18 / M = 3-9 poisoned real steps of the UCI_13 run: temperature 0.1 puts single
+//     contributions near 10).  Such a contribution
 //     sets the POISON word behind the table and the conversion then writes NaN into the whole
 //     gradient -- a diverged step stays as loud as with float atomics (NaN gradient norm, NaN parameters after the clip)
 //     instead of turning into a finite, wrong update.  Contributions below 1e-10 lose relative precision (the
 //     resolution is absolute); the training configurations of the reference's scripts sit eight orders above that.
-constexpr double EMB_FIX = 17592186044416.0;            // 2^44
+constexpr double EMB_FIX = 1099511627776.0;             // 2^40
 constexpr float EMB_MAX_ABS = 131072.0f;                // 2^17
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                                             long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte,
@@ -468,7 +469,7 @@ int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int 
     const long long rows = (long long)B * T;
     if (rows <= 0) return R4D_OK;
     R4D_REQUIRE(table_rows >= rows, "embedding_bwd: table_rows %lld < rows %lld", table_rows, rows);
-    const float max_abs = fminf(EMB_MAX_ABS, 262144.0f / (float)table_rows);       // 2^62 / 2^44 / rows: the sum cannot wrap
+    const float max_abs = fminf(EMB_MAX_ABS, 4194304.0f / (float)table_rows);      // 2^62 / 2^40 / rows: the sum cannot wrap
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte, max_abs);
     R4D_CHECK_LAUNCH("embedding_bwd");
     hipLaunchKernelGGL(wpe_bwd_kernel, dim3((unsigned)(((long long)T * d + 255) / 256)), dim3(256), 0, s, dx, B, T, d, first_group, dwpe);

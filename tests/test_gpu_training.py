@@ -258,7 +258,7 @@ def test_non_finite_gradient_stays_loud_in_the_deterministic_embedding_sum(dev):
     opt = training.AdamW(trainer.params, trainer.grads, lr=1e-3, flat_grads=trainer.flat_grads)
     opt.sumsq.zero_()
     assert not np.isfinite(float(trainer.flat_grads.double().pow(2).sum().sqrt()))
-    # the per-term bound follows the number of rows that meet in one table (2^18 / rows), so that NO run of same-sign
+    # the per-term bound follows the number of rows that meet in one table (2^22 / rows), so that NO run of same-sign
     # contributions can wrap the 64-bit sum into a finite wrong value: one token in every position, upstream gradient 1e5 each --
     # round 4's fixed 2^17 bound let 36 terms of ~2^61 wrap silently; now the step is poisoned (NaN), and a run of contributions
     # inside the bound still sums exactly
