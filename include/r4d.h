@@ -247,6 +247,22 @@ int r4d_set_attention_h2(int32_t on);
 int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream);
 int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream);
 
+/* Pre-split activations (ABI v6, additive; csrc/gemm_h2p.hip).  In gemm mode 2 (f16x2) r4d_gpt2_encode_* keeps the INPUT rows of c_attn,
+ * c_fc and mlp.c_proj as "f16x2 lines" -- uint16 [rows][K/32][2][32]: per row and 32 consecutive k one 128-byte line of 32 hi = RN16(x/4)
+ * then 32 lo' = RN16((x/4 - hi) 2^11), the layout r4d_split2_planes_f16 gives the weights, 4 bytes per element like fp32 -- written by
+ * their producers (the LayerNorm kernels, the c_fc GELU epilogue), and both GEMM operands travel global -> LDS by DMA.  The results are
+ * those of the register-staged f16x2 GEMM bit for bit; r4d_set_gemm_h2p(0) selects that one again (returns the previous setting;
+ * process-wide like r4d_set_gemm_split3).  n_embd % 256 == 0, else the register-staged path.
+ * r4d_split2_lines_f16: x_d fp32 [rows,K] -> lines (tests, external producers).
+ * r4d_conv1d_h2p_f32: r4d_conv1d_h2_f32 with x given as lines; out_lines != 0 (epilogue 1 = gelu only): y_d receives lines [M][N/32][2][32].
+ * r4d_layernorm_lines_f32: r4d_layernorm_f32 whose output rows are lines (d % 256 == 0; what the encoder launches in this mode). */
+int r4d_set_gemm_h2p(int32_t on);
+int r4d_layernorm_lines_f32(const float* x_d, const float* w_d, const float* b_d, int32_t rows, int32_t d, float eps,
+                            uint16_t* y_lines_d, void* stream);
+int r4d_split2_lines_f16(const float* x_d, int64_t rows, int32_t K, uint16_t* lines_d, void* stream);
+int r4d_conv1d_h2p_f32(const uint16_t* x_lines_d, const uint16_t* planes_d, const float* bias_d, const float* residual_d, int32_t M,
+                       int32_t K, int32_t N, int32_t epilogue, int32_t out_lines, void* y_d, void* stream);
+
 /* Range guard (ABI v6, additive).  The f16x2 arithmetic has fp16's exponent range: an activation, q, k or v of magnitude >= 2^18
  * becomes inf in its first fp16 term and every hidden state downstream of it NaN -- and NaN scores are ordered below everything by
  * the selection, i.e. an ordinary-looking top-k of garbage.  r4d_set_range_flag registers ONE caller-owned

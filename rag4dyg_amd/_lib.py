@@ -72,6 +72,10 @@ PROTOTYPES = {
     "r4d_set_attention_fused": (c_int32, [c_int32]),
     "r4d_set_attention_h2": (c_int32, [c_int32]),
     "r4d_set_range_flag": (c_int32, [_P]),
+    "r4d_set_gemm_h2p": (c_int32, [c_int32]),
+    "r4d_layernorm_lines_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),
+    "r4d_split2_lines_f16": (c_int32, [_P, c_int64, c_int32, _P, _P]),
+    "r4d_conv1d_h2p_f32": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_pack_h2_words_f32": (c_int32, [_P, c_int64, _P, _P]),
     "r4d_attention_h2_f32": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_gpt2_decode_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32]),

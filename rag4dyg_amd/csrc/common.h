@@ -63,7 +63,7 @@ struct ProfScope {
     X(KC_128x128x16, "gemm_kc:128x128x16") X(KC_128x64x16, "gemm_kc:128x64x16") X(KC_64x64x32, "gemm_kc:64x64x32")       \
     X(KC_128x128x32, "tuning:gemm_kc:128x128x32") X(KC_ROWSPLIT, "gemm_kc:row-split (two launches)")                      \
     X(S3_128x256, "gemm_s3:128x256x32") X(S3_PERSISTENT, "gemm_s3:128x256x32 persistent (pipeline across tiles)") X(S3_128x128, "gemm_s3:128x128x32") X(S3_F32B, "gemm_s3:both operands split on the fly (scoring GEMM)") X(S3_TN, "gemm_s3tn:128x256x32 (weight gradients, transposing LDS reads)")      \
-    X(H2_128x256, "gemm_h2:128x256x32 (f16x2)") X(H2_128x128, "gemm_h2:128x128x32 (f16x2)") \
+    X(H2_128x256, "gemm_h2:128x256x32 (f16x2)") X(H2_128x128, "gemm_h2:128x128x32 (f16x2)") X(H2P_128x256, "gemm_h2p:128x256x32 (f16x2, A as lines, LDS-DMA)") X(H2P_128x128, "gemm_h2p:128x128x32 (f16x2, A as lines, LDS-DMA)") \
     X(F32_128x128, "gemm_f32:128x128") X(F32_128x64, "gemm_f32:128x64") X(F32_64x64, "gemm_f32:64x64")                   \
     X(F32_NT, "gemm_f32:B as [N,K]") X(F32_NN, "gemm_f32:B as [K,N]") X(TN_SPLITK, "gemm_tn:split-K") X(TN_SINGLE, "gemm_tn:one slice") \
     X(SK16_NG2, "skinny16:ng2") X(SK16_NG3, "skinny16:ng3") X(SK16_NG2_LN, "skinny16:ng2+layernorm") X(SK16_LN_FOLDED, "skinny16:LayerNorm pre-folded into the weight") X(SK16_NG3_LN, "skinny16:ng3+layernorm") \
@@ -159,6 +159,12 @@ int launch_gemm_s3_scan_order(const float* q_hat, const float* pool_hat, float* 
 bool gemm_h2_supported(int M, int K, int N);
 int launch_gemm_h2(const S3Args& a, hipStream_t stream);
 int launch_split2_planes(const float* w, int N, int K, long long ld_k, long long ld_n, unsigned short* planes, hipStream_t s);
+// gemm_h2p.hip: the same arithmetic with the A operand already split by its producer into f16x2 lines [M][K/32][2][32] fp16 (both
+// tiles staged by LDS-DMA); out_lines: the GELU epilogue writes lines [M][N/32][2][32] fp16 into a.C.  a.A is ignored.
+extern int g_gemm_h2p;
+bool gemm_h2p_supported(int M, int K, int N);
+int launch_gemm_h2p(const S3Args& a, const unsigned short* a_lines, bool out_lines, hipStream_t stream);
+int launch_split2_lines(const float* x, long long rows, int K, unsigned short* lines, hipStream_t s);
 extern int g_gemm_split3;             // Conv1D arithmetic (r4d_set_gemm_split3): 0 exact-f32 MFMA, 1 bf16x3 planes, 2 f16x2 planes (bf16x3 where a layer carries no f16 planes)
 // Conv1D dispatch shared by the encoder and the training forward (encoder.hip): skinny weight stream (decode), bf16x3 planes,
 // k-contiguous copy, reference layout -- in that order of preference
@@ -189,6 +195,8 @@ int topk_rows(const T* vals, const long long* idx_in, int rows, int n, long long
 // ------------------------------------------------------------------ encoder_ops.hip
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
                      hipStream_t s);
+bool layernorm_lines_supported(int d);
+int launch_layernorm_lines(const float* x, const float* w, const float* b, int rows, int d, float eps, unsigned short* y_lines, hipStream_t s);
 constexpr int ATT_MAXG = 16;
 // Up to ATT_MAXG right-padded batches handled by ONE launch of a row kernel (each batch keeps its own T): rows of the
 // batches are consecutive in x / y, sequences consecutive in the pooled output.  ids[g] / emb[g]: exactly one is set.
@@ -199,7 +207,7 @@ struct RowGroups {
     const float* emb[ATT_MAXG];
 };
 int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
-                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s);
+                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s, bool y_lines = false);
 int launch_causal_softmax(float* S, int nbh, int T, int ld, int row_tile, hipStream_t s);
 // decode step (one new position per sequence): x = (ids ? wte[id] : emb) + wpe[pos], y = LayerNorm(x)
 int launch_embed_pos_layernorm(const int64_t* ids, const float* emb, const int32_t* pos, const float* wte,

@@ -53,6 +53,17 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
     return launch_gemm_f32(g, s);
 }
 
+// Conv1D whose input rows are f16x2 LINES written by their producer (gemm_h2p.hip): f16x2 mode only; out_lines: the GELU epilogue
+// writes the result as lines too (c_fc -> mlp.c_proj)
+static int conv1d_lines(const unsigned short* x_lines, const unsigned short* w2h, const float* bias, const float* resid, int M, int K, int N,
+                        int epilogue, void* y, bool out_lines, hipStream_t s) {
+    S3Args a;
+    memset(&a, 0, sizeof(a));
+    a.planes = w2h; a.C = (float*)y; a.bias = bias; a.resid = resid;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
+    return launch_gemm_h2p(a, x_lines, out_lines, s);
+}
+
 static inline int tpad(int T) { return (T + 127) / 128 * 128; }
 
 // Attention._attn + split_heads/merge_heads (modeling_gpt2.py:140-175) as three launches over the packed
@@ -233,15 +244,23 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         const r4d_gpt2_layer& L = w->layers[l];
         R4D_REQUIRE(L.ln_1_w && L.c_attn_w && L.attn_proj_w && L.ln_2_w && L.c_fc_w && L.mlp_proj_w,
                     "gpt2: null weight in layer %d", l);
+        // f16x2 mode, round 5: the LayerNorms write their rows as f16x2 LINES, the c_fc GELU epilogue too, and c_attn / c_fc /
+        // mlp.c_proj take them through LDS-DMA (gemm_h2p.hip) -- the values of the register-staged gemm_h2 path, bit for bit
+        // (r4d_set_gemm_h2p(0) keeps that one); the buffers keep their size (4 bytes per element either way)
+        const bool lines = g_gemm_split3 == 2 && g_gemm_h2p && L.c_attn_h2 && L.c_fc_h2 && L.mlp_proj_h2 && layernorm_lines_supported(d) &&
+                           gemm_h2p_supported(M, d, 3 * d) && gemm_h2p_supported(M, d, 4 * d) && gemm_h2p_supported(M, 4 * d, d);
+        unsigned short* ln_lines = reinterpret_cast<unsigned short*>(ws.ln);
+        unsigned short* fc_lines = reinterpret_cast<unsigned short*>(ws.fc);
         if (l == 0) {
             for (int g0 = 0; g0 < n_groups; g0 += ATT_MAXG) {          // ATT_MAXG batches per launch
                 const RowGroups R = row_groups(groups, g0, n_groups);
                 const size_t r0 = groups[g0].row0;
                 rc = launch_embed_layernorm_groups(R, w->wte, w->wpe, cfg->vocab, d, L.ln_1_w, L.ln_1_b, cfg->ln_eps,
-                                                   ws.x + r0 * d, ws.ln + r0 * d, s);
+                                                   ws.x + r0 * d, ws.ln + r0 * d, s, lines);
                 if (rc) return rc;
             }
-        } else if ((rc = launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s))) {
+        } else if ((rc = lines ? launch_layernorm_lines(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ln_lines, s)
+                               : launch_layernorm(ws.x, L.ln_1_w, L.ln_1_b, M, d, cfg->ln_eps, ws.ln, s))) {
             return rc;
         }
         if (out_layers_d &&
@@ -260,7 +279,9 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             for (int j = g0; j < n_groups && j < g0 + ATT_MAXG; ++j) nseq += groups[j].B;
             if (nseq > 65535) words = false;
         }
-        if ((rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2))) return rc;
+        if (lines) rc = conv1d_lines(ln_lines, L.c_attn_h2, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, false, s);
+        else rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2);
+        if (rc) return rc;
         bool fused_done = false;
         if (words) {
             fused_done = true;
@@ -295,6 +316,12 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             }
         }
         if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.attn_proj_w3, L.attn_proj_h2))) return rc;
+        if (lines) {
+            if ((rc = launch_layernorm_lines(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ln_lines, s))) return rc;
+            if ((rc = conv1d_lines(ln_lines, L.c_fc_h2, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, fc_lines, true, s))) return rc;
+            if ((rc = conv1d_lines(fc_lines, L.mlp_proj_h2, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, false, s))) return rc;
+            continue;
+        }
         if ((rc = launch_layernorm(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ws.ln, s))) return rc;
         if ((rc = conv1d(ws.ln, L.c_fc_w, L.c_fc_wT, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, ws.fc, s, nullptr, false, L.c_fc_w3, L.c_fc_h2))) return rc;
         if ((rc = conv1d(ws.fc, L.mlp_proj_w, L.mlp_proj_wT, L.mlp_proj_b, ws.x, M, 4 * d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.mlp_proj_w3, L.mlp_proj_h2))) return rc;
@@ -556,6 +583,12 @@ int r4d_layernorm_f32(const float* x_d, const float* w_d, const float* b_d, int3
                       float* y_d, void* stream) {
     R4D_REQUIRE(x_d && w_d && b_d && y_d, "layernorm: null pointer");
     return launch_layernorm(x_d, w_d, b_d, rows, d, eps, y_d, (hipStream_t)stream);
+}
+
+int r4d_layernorm_lines_f32(const float* x_d, const float* w_d, const float* b_d, int32_t rows, int32_t d, float eps,
+                            uint16_t* y_lines_d, void* stream) {
+    R4D_REQUIRE(x_d && w_d && b_d && y_lines_d, "layernorm_lines: null pointer");
+    return launch_layernorm_lines(x_d, w_d, b_d, rows, d, eps, y_lines_d, (hipStream_t)stream);
 }
 
 int r4d_conv1d_f32(const float* x_d, const float* w_d, const float* w_t_d, const float* bias_d, const float* residual_d,

@@ -3,6 +3,7 @@
 // (no LDS, no atomics -> bitwise reproducible run to run).
 #include <string.h>
 #include "common.h"
+#include "h2.h"
 
 namespace r4d {
 
@@ -51,7 +52,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
 }
 
 // Same, 16 bytes per lane and instruction (d % 256 == 0): lane owns columns 4*lane + 256*i .. +3
-template <int NQ>
+// y as f16x2 LINES (gemm_h2p.hip; round 5): the four values a lane holds are four consecutive k of one 128-byte line -- 8 bytes of its hi
+// half, 8 bytes of its lo' half (64 bytes further): the same bytes as the fp32 row, split where they are produced
+__device__ __forceinline__ void store_lines4(float* y_rows, long long row, int d, int col, float a0, float a1, float a2, float a3) {
+    unsigned h0, l0, h1, l1;
+    split2_pair<true>(a0, a1, h0, l0);
+    split2_pair<true>(a2, a3, h1, l1);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(y_rows) + row * (long long)d * 4 + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(l0, l1);
+}
+
+template <int NQ, bool LINES = false>
 __global__ __launch_bounds__(256) void ln4_kernel(const float* __restrict__ x_in, int rows, int d, const float* __restrict__ w,
                                                   const float* __restrict__ b, float eps, float* __restrict__ y_out) {
     const int lane = threadIdx.x & 63;
@@ -79,9 +91,26 @@ __global__ __launch_bounds__(256) void ln4_kernel(const float* __restrict__ x_in
     for (int i = 0; i < NQ; ++i)
         if (i < nq) {
             const float4 ww = reinterpret_cast<const float4*>(w)[lane + 64 * i], bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
-            yr[64 * i] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
-                                     (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            const float4 y4 = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                          (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            if constexpr (LINES) store_lines4(y_out, row, d, 4 * lane + 256 * i, y4.x, y4.y, y4.z, y4.w);
+            else yr[64 * i] = y4;
         }
+}
+
+// LayerNorm whose output is the f16x2-line image of the normalised rows (the A operand of gemm_h2p.hip); d % 256 == 0
+bool layernorm_lines_supported(int d) { return d % 256 == 0 && d <= 64 * MAXV; }
+int launch_layernorm_lines(const float* x, const float* w, const float* b, int rows, int d, float eps, unsigned short* y_lines, hipStream_t s) {
+    R4D_REQUIRE(layernorm_lines_supported(d) && (((uintptr_t)x | (uintptr_t)y_lines | (uintptr_t)w | (uintptr_t)b) & 15) == 0,
+                "layernorm_lines: d=%d must be a multiple of 256 and the pointers 16-byte aligned", d);
+    if (rows <= 0) return R4D_OK;
+    ProfScope prof(PK_LAYERNORM, 8.0 * rows * d, s);            // bytes: read x + write the lines (4 bytes per element, as fp32)
+    float* y = reinterpret_cast<float*>(y_lines);
+    if (d <= 512) { R4D_BRANCH(LN4_2); hipLaunchKernelGGL((ln4_kernel<2, true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y); }
+    else if (d <= 1024) { R4D_BRANCH(LN4_4); hipLaunchKernelGGL((ln4_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y); }
+    else { R4D_BRANCH(LN4_8); hipLaunchKernelGGL((ln4_kernel<8, true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, w, b, eps, y); }
+    R4D_CHECK_LAUNCH("layernorm_lines");
+    return R4D_OK;
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int d, float eps, float* y,
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(256) void embed_ln_groups_kernel(const RowTable G, 
 
 // the same with 16-byte lanes (d % 256 == 0, every pointer 16-byte aligned): a quarter of the memory instructions of the 4-byte form,
 // which held this write-bound kernel at 2.5 TB/s (ln4_kernel's layout and reduction order)
-template <int NQ>
+template <int NQ, bool LINES = false>
 __global__ __launch_bounds__(256) void embed_ln4_groups_kernel(const RowTable G, const RowInputs in,
                                                                const float* __restrict__ wte, const float* __restrict__ wpe,
                                                                int vocab, int d, const float* __restrict__ w,
@@ -218,13 +247,15 @@ __global__ __launch_bounds__(256) void embed_ln4_groups_kernel(const RowTable G,
     for (int i = 0; i < NQ; ++i)
         if (i < nq) {
             const float4 ww = reinterpret_cast<const float4*>(w)[lane + 64 * i], bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
-            yr[64 * i] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
-                                     (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            const float4 y4 = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                          (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            if constexpr (LINES) store_lines4(y_out, row, d, 4 * lane + 256 * i, y4.x, y4.y, y4.z, y4.w);
+            else yr[64 * i] = y4;
         }
 }
 
 int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const float* wpe, int vocab, int d,
-                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s) {
+                                  const float* w, const float* b, float eps, float* x_out, float* y_out, hipStream_t s, bool y_lines) {
     R4D_REQUIRE(d % 64 == 0 && d <= 64 * MAXV, "embed: d=%d must be a multiple of 64 and <= %d", d, 64 * MAXV);
     R4D_REQUIRE(G.n >= 1 && G.n <= ATT_MAXG, "embed: %d batches per launch (max %d)", G.n, ATT_MAXG);
     const RowTable t = make_table(G);
@@ -237,6 +268,15 @@ int launch_embed_layernorm_groups(const RowGroups& G, const float* wte, const fl
     for (int g = 0; g < G.n; ++g) align |= (uintptr_t)in.emb[g];
     const bool vec = d % 256 == 0 && (align & 15) == 0;
     const dim3 grid((unsigned)cdiv(rows, 4));
+    if (y_lines) {                                               // y as f16x2 lines (layernorm_lines_supported(d) checked by the caller)
+        R4D_REQUIRE(vec, "embed: line output needs d %% 256 == 0 and 16-byte aligned pointers");
+        R4D_BRANCH(EMBED_LN4);
+        if (d <= 512) hipLaunchKernelGGL((embed_ln4_groups_kernel<2, true>), grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out);
+        else if (d <= 1024) hipLaunchKernelGGL((embed_ln4_groups_kernel<4, true>), grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out);
+        else hipLaunchKernelGGL((embed_ln4_groups_kernel<8, true>), grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out);
+        R4D_CHECK_LAUNCH("embed_layernorm");
+        return R4D_OK;
+    }
     if (vec && d <= 512) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<2>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }
     else if (vec && d <= 1024) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<4>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }
     else if (vec) { R4D_BRANCH(EMBED_LN4); hipLaunchKernelGGL(embed_ln4_groups_kernel<8>, grid, dim3(256), 0, s, t, in, wte, wpe, vocab, d, w, b, eps, x_out, y_out); }

@@ -134,6 +134,48 @@ def split2_planes(w, transposed=False):
     return planes
 
 
+def set_gemm_h2p(on):
+    """f16x2 mode: True (default) -- LayerNorm / GELU write their rows as f16x2 lines and the GEMMs stage both operands by LDS-DMA
+    (``csrc/gemm_h2p.hip``); False -- the register-staged ``gemm_h2`` kernels on fp32 activations.  Same bits either way.
+    Returns the previous setting."""
+    return bool(_lib.load().r4d_set_gemm_h2p(1 if on else 0))
+
+
+def split2_lines(x):
+    """fp32 rows [..., K] -> their f16x2 lines, int16 [rows, K/32, 2, 32] (fp16 bit patterns of x/4: ``[:, :, 0]`` hi, ``[:, :, 1]`` lo'):
+    the A operand of :func:`conv1d_h2p` (what the LayerNorm kernels and the c_fc epilogue write in f16x2 mode)."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    out = torch.empty(rows, K // 32, 2, 32, dtype=torch.int16, device=x.device)
+    check(_lib.load().r4d_split2_lines_f16(_dev(x, torch.float32, "x"), rows, K, out.data_ptr(), _stream()), "split2_lines")
+    return out
+
+
+def layernorm_lines(x, w, b, eps=1e-5):
+    """:func:`layernorm` whose output rows are f16x2 lines [rows, d/32, 2, 32] (d % 256 == 0)."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty(rows, d // 32, 2, 32, dtype=torch.int16, device=x.device)
+    check(_lib.load().r4d_layernorm_lines_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"), _dev(b, torch.float32, "b"),
+                                              rows, d, eps, y.data_ptr(), _stream()), "layernorm_lines")
+    return y
+
+
+def conv1d_h2p(x_lines, planes, bias, epilogue="none", residual=None, out_lines=False):
+    """:func:`conv1d_h2` with the input given as f16x2 lines (:func:`split2_lines`), both operands staged by LDS-DMA; bit-identical
+    results.  ``out_lines`` (gelu only): the result as lines [M, N/32, 2, 32] instead of fp32 [M, N]."""
+    N, K = planes.shape[0], planes.shape[1] * 32
+    M = x_lines.shape[0]
+    epi = {"none": 0, "gelu": 1, "residual": 2}[epilogue]
+    y = (torch.empty(M, N // 32, 2, 32, dtype=torch.int16, device=x_lines.device) if out_lines
+         else torch.empty(M, N, dtype=torch.float32, device=x_lines.device))
+    rp = _dev(residual, torch.float32, "residual") if residual is not None else None
+    bp = _dev(bias, torch.float32, "bias") if bias is not None else None
+    check(_lib.load().r4d_conv1d_h2p_f32(_dev(x_lines, torch.int16, "x_lines"), _dev(planes, torch.int16, "planes"), bp, rp, M, K, N, epi,
+                                         int(bool(out_lines)), y.data_ptr(), _stream()), "conv1d_h2p")
+    return y
+
+
 def conv1d_h2(x, planes, bias, epilogue="none", residual=None):
     """:func:`conv1d` on the fp16 matrix cores at fp32 accuracy (two fp16 terms per operand, three partial products, two fp32
     accumulator sets); ``planes`` from :func:`split2_planes`.  |x| < 2^18."""

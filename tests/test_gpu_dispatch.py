@@ -45,7 +45,9 @@ def test_every_dispatcher_branch_is_exercised(dev):
         x, w, b = rnd(M, K).to(dev), (rnd(K, N) * 0.05).to(dev), rnd(N).to(dev)
         rows = min(M, 256)
         ref = (x[:rows].double() @ w.double() + b.double()).cpu().numpy()
-        if planes == "h2":
+        if planes == "h2p":
+            y = ops.conv1d_h2p(ops.split2_lines(x), ops.split2_planes(w), b)
+        elif planes == "h2":
             y = ops.conv1d_h2(x, ops.split2_planes(w), b)
         elif planes:
             y = ops.conv1d_s3(x, ops.split3_planes(w), b)
@@ -62,6 +64,8 @@ def test_every_dispatcher_branch_is_exercised(dev):
     conv_check(4096, 512, 128, wt=False, planes=True)        # gemm_s3 128 x 128 (one column tile of 128)
     conv_check(4096, 512, 1536, wt=False, planes="h2")       # gemm_h2 128 x 256
     conv_check(4096, 512, 128, wt=False, planes="h2")        # gemm_h2 128 x 128
+    conv_check(4096, 512, 1536, wt=False, planes="h2p")      # gemm_h2p 128 x 256 (A as f16x2 lines, LDS-DMA)
+    conv_check(4096, 512, 128, wt=False, planes="h2p")       # gemm_h2p 128 x 128
     h = rnd(9, 48).to(dev)                                    # B as [N,K] with K % 32 != 0: reference-layout kernel, NT form
     wte = rnd(50, 48).to(dev)
     assert rel_err(ops.lm_logits(h, wte).cpu().numpy(), (h.double() @ wte.double().t()).cpu().numpy()) < 2e-6
@@ -149,6 +153,7 @@ def test_every_dispatcher_branch_is_exercised(dev):
     finally:
         ops.set_gemm_mode("bf16x3")
     scan(80, 3000, 512)          # Q > 64: the scan again, three blocks of 32 queries (one scoring arithmetic)
+    scan(128, 50000, 512)        # Q >= 64 and >= 192 tiles: 128 x 256 tiles of gemm_s3 in the scan kernels' arithmetic
     scan(7, 300, 96)             # no scan variant for d = 96: tiled GEMM, bf16x3 operands split on the fly
     scan(7, 300, 80)             # ... and d % 32 != 0: the exact-f32 tiled GEMM
     for rows, n, k, dt in ((3, 900, 7, torch.float32), (2, 100000, 10, torch.float32), (2, 300000, 64, torch.float32),

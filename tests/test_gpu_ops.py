@@ -995,3 +995,68 @@ def test_encoder_max_context_and_determinism(dev):
     ref = gpt2_ref.gpt2_forward(sd, ids, 2, want_logits=False)["hidden"]
     assert rel_err(r1["hidden"].cpu().numpy(), ref.numpy()) < 2e-5
     assert rel_err(r1["meanpool"].cpu().numpy(), ref.mean(dim=1).numpy()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- pre-split activations (gemm_h2p.hip)
+@pytest.mark.parametrize("M,K,N", [(4096, 512, 1536), (1000, 512, 2048), (777, 2048, 512), (333, 768, 2304), (129, 64, 96), (5000, 3072, 768),
+                                   (40, 512, 512), (2, 256, 1024)])
+def test_conv1d_h2p_lines_equals_the_register_staged_f16x2_gemm_bit_for_bit(dev, M, K, N):
+    """csrc/gemm_h2p.hip (round 5): the A operand as f16x2 LINES -- bit for bit ``hi = RN16(x/4)``,
+    ``lo' = RN16((x/4 - hi) 2^11)`` in the layout of the weight planes -- both tiles staged by LDS-DMA: every epilogue must give the
+    BITS of ``conv1d_h2`` on the fp32 rows (interior and edge tiles, both tile widths, K down to two k-tiles); the GELU epilogue's
+    line output must be the lines of ``conv1d_h2``'s fp32 GELU output; LayerNorm's line output the lines of ``layernorm``'s rows.
+    Three launches give the same bits."""
+    from rag4dyg_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * 1.7 + 0.3).to(dev)
+    w = (torch.randn(K, N, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    planes = ops.split2_planes(w)
+    lines = ops.split2_lines(x)
+    # the line format itself, against fp16 round-to-nearest-even in torch
+    h_ref = (x / 4).half()
+    l_ref = ((x / 4 - h_ref.float()) * 2048.0).half()
+    assert torch.equal(lines[:, :, 0].reshape(M, K).view(torch.float16), h_ref) and torch.equal(lines[:, :, 1].reshape(M, K).view(torch.float16), l_ref)
+    for epi, r in (("none", None), ("gelu", None), ("residual", res)):
+        want = ops.conv1d_h2(x, planes, b, epi, r)
+        got = ops.conv1d_h2p(lines, planes, b, epi, r)
+        assert torch.equal(got, want), (epi, (got - want).abs().max().item())
+        assert all(torch.equal(ops.conv1d_h2p(lines, planes, b, epi, r), got) for _ in range(2)), epi
+    if N % 32 == 0:
+        want_l = ops.split2_lines(ops.conv1d_h2(x, planes, b, "gelu"))
+        got_l = ops.conv1d_h2p(lines, planes, b, "gelu", out_lines=True)
+        assert torch.equal(got_l, want_l)
+    if K % 256 == 0 and K <= 2048:
+        lw, lb = (1 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.1 * torch.randn(K, generator=g)).to(dev)
+        assert torch.equal(ops.layernorm_lines(x, lw, lb), ops.split2_lines(ops.layernorm(x, lw, lb)))
+
+
+@pytest.mark.parametrize("L,H,d,V", [(2, 2, 512, 300), (2, 6, 768, 200), (3, 2, 256, 150), (1, 2, 1024, 90), (2, 2, 128, 80)])
+def test_encoder_with_presplit_activations_equals_register_staged_path(dev, L, H, d, V):
+    """The whole encoder in f16x2 mode with LayerNorm / GELU writing f16x2 lines and the LDS-DMA GEMMs (default) against the same
+    mode with ``set_gemm_h2p(False)`` (round 4's path): hidden states and mean-pooled embeddings ``torch.equal``, for one batch and
+    for a fused group of ragged batches (d = 128 has no line kernels: both settings take the same path)."""
+    from oracle import gpt2_ref
+    from rag4dyg_amd import ops
+    from rag4dyg_amd.gpt2 import GPT2Config, GPT2LMHeadModelRAG
+    was = ops.gemm_mode()
+    sd = gpt2_ref.make_state_dict(L, d, V, n_positions=256, seed=d + L, random_affine=True)
+    m = GPT2LMHeadModelRAG(GPT2Config(vocab_size=V, n_positions=256, n_ctx=256, n_embd=d, n_layer=L, n_head=H))
+    m.load_state_dict(sd, strict=False); m.tie_weights()
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.randint(0, V, (B, T), generator=g).to(dev) for B, T in ((32, 77), (32, 130), (5, 200), (32, 9))]
+    try:
+        ops.set_gemm_mode("f16x2")
+        outs = {}
+        for on in (True, False):
+            ops.set_gemm_h2p(on)
+            one = m.transformer.encode(input_ids=batches[1], want_hidden=True, want_meanpool=True)
+            grp = m.transformer.encode_groups(batches, want_hidden=True, want_meanpool=True)
+            outs[on] = (one["hidden"].clone(), one["meanpool"].clone(), grp["hidden"].clone(), grp["meanpool"].clone())
+        for a, b in zip(outs[True], outs[False]):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (a - b).abs().max().item()
+    finally:
+        ops.set_gemm_h2p(True)
+        ops.set_gemm_mode(was)
