@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void pack_h2_words_kernel(const float* __restr
 
 template <int HD>
 __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H,
-                                                                                  int ntq, float qscale, float* __restrict__ out) {
+                                                                                  int ntq, float qscale, float* __restrict__ out, int out_lines) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // O^T tiles per wave (1 or 2): tile j = columns wid * CW + 32 j + lane
     constexpr int NSTEP = HD / 8;                      // 16-byte K loads (and Q reads) per key row: 8 elements per MFMA pair
@@ -264,13 +264,27 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
     for (int q = wid; q < 32; q += 4) {
         if (q0 + q >= T) break;
         float* dst = out + (rowb + q0 + q) * d + (long long)h * HD;
-        for (int c = lane * 4; c < HD; c += 256)
-            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(&Os[q * LDO + c]);
+        for (int c = lane * 4; c < HD; c += 256) {
+            const float4 o4 = *reinterpret_cast<const float4*>(&Os[q * LDO + c]);
+            if (out_lines) {
+                // the merged-head row as f16x2 LINES (gemm_h2p.hip: attn.c_proj stages them by LDS-DMA): the lane's four values
+                // are four consecutive k of one 128-byte line -- 8 bytes of its hi half, 8 of its lo' half; same bytes as fp32
+                unsigned h0, l0, h1, l1;
+                split2_pair<true>(o4.x, o4.y, h0, l0);
+                split2_pair<true>(o4.z, o4.w, h1, l1);
+                const int col = h * HD + c;
+                unsigned char* ld = reinterpret_cast<unsigned char*>(out) + (rowb + q0 + q) * (long long)d * 4 + (col >> 5) * 128 + (col & 31) * 2;
+                *reinterpret_cast<uint2*>(ld) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(ld + 64) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4*>(dst + c) = o4;
+            }
+        }
     }
 }
 
 template <int HD>
-static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, hipStream_t s) {
+static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
     const size_t lds = ((size_t)32 * (HD + 4) + 32 * 132 + 256) * 4;       // >= the [32][HD+4] output tile
     if (lds > 64 * 1024) {
         static bool raised = false;                     // (one process drives one device: include/r4d.h, PROCESS MODEL)
@@ -287,7 +301,7 @@ static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double
     const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
     R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
     hipLaunchKernelGGL((attn_h2_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
-                       (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out);      // both pre-scales undone in the logits
+                       (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out, out_lines);      // both pre-scales undone in the logits
     R4D_CHECK_LAUNCH("attn_h2");
     return R4D_OK;
 }
@@ -299,8 +313,9 @@ bool attention_h2_supported(int H, int d) {
 }
 
 // Attention of n <= ATT_MAXG batches in one launch (launch_attention_fused_groups's contract) on h2 words
+// out_lines: `out` receives the merged-head rows as f16x2 lines [rows][d/32][2][32] fp16 (d % 32 == 0) instead of fp32 [rows][d]
 int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
-                               float* out, hipStream_t s) {
+                               float* out, hipStream_t s, bool out_lines) {
     R4D_REQUIRE(qkv && out, "attention_h2: null pointer");
     R4D_REQUIRE(attention_h2_supported(H, d), "attention_h2: head_dim %d has no instantiation (128 / 256)", H > 0 ? d / H : 0);
     R4D_REQUIRE(n >= 1 && n <= ATT_MAXG, "attention_h2: %d batches per launch (max %d)", n, ATT_MAXG);
@@ -320,9 +335,9 @@ int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const 
     }
     for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
     R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention_h2: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
-    if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128>(qkv, G, Tmax, flop, H, d, out, s); }
+    if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     R4D_BRANCH(ATT_H2_256);
-    return launch_ah2<256>(qkv, G, Tmax, flop, H, d, out, s);
+    return launch_ah2<256>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s);
 }
 
 int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s) {

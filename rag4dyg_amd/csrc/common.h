@@ -239,7 +239,7 @@ struct AttnGroups {
 // gemm_h2's EPI_H2WORDS epilogue or launch_pack_h2_words); head_dim 128 / 256 (attention_h2_supported)
 bool attention_h2_supported(int H, int d);
 int launch_attention_h2_groups(const unsigned* qkv_words, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
-                               float* out, hipStream_t s);
+                               float* out, hipStream_t s, bool out_lines = false);
 int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s);
 int dbgflag_att_h2();
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation

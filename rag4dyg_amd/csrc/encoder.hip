@@ -282,6 +282,8 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         if (lines) rc = conv1d_lines(ln_lines, L.c_attn_h2, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, false, s);
         else rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2);
         if (rc) return rc;
+        // ... and with them the attention output: attn_h2_kernel writes its merged-head rows as lines for attn.c_proj
+        const bool att_lines = words && lines && L.attn_proj_h2 && gemm_h2p_supported(M, d, d);
         bool fused_done = false;
         if (words) {
             fused_done = true;
@@ -290,7 +292,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
                 long long r0[ATT_MAXG];
                 const int n = n_groups - g0 < ATT_MAXG ? n_groups - g0 : ATT_MAXG;
                 for (int j = 0; j < n; ++j) { Bs[j] = groups[g0 + j].B; Ts[j] = groups[g0 + j].T; r0[j] = (long long)groups[g0 + j].row0; }
-                if ((rc = launch_attention_h2_groups(reinterpret_cast<const unsigned*>(qkv), n, Bs, Ts, r0, H, d, ws.att, s))) return rc;
+                if ((rc = launch_attention_h2_groups(reinterpret_cast<const unsigned*>(qkv), n, Bs, Ts, r0, H, d, ws.att, s, att_lines))) return rc;
             }
         } else if (g_attention_fused != 0) {             // all batches of the call in ceil(n/16) fused launches
             fused_done = true;
@@ -315,7 +317,9 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
                 if ((rc = attention(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws.att + G.row0 * d, ws.scores, s))) return rc;
             }
         }
-        if ((rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.attn_proj_w3, L.attn_proj_h2))) return rc;
+        if (att_lines) rc = conv1d_lines(reinterpret_cast<const unsigned short*>(ws.att), L.attn_proj_h2, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, false, s);
+        else rc = conv1d(ws.att, L.attn_proj_w, L.attn_proj_wT, L.attn_proj_b, ws.x, M, d, d, EPI_RESIDUAL, ws.x, s, nullptr, false, L.attn_proj_w3, L.attn_proj_h2);
+        if (rc) return rc;
         if (lines) {
             if ((rc = launch_layernorm_lines(ws.x, L.ln_2_w, L.ln_2_b, M, d, cfg->ln_eps, ln_lines, s))) return rc;
             if ((rc = conv1d_lines(ln_lines, L.c_fc_h2, L.c_fc_b, nullptr, M, d, 4 * d, EPI_GELU, fc_lines, true, s))) return rc;
