@@ -306,10 +306,233 @@ static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double
     return R4D_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- head_dim 32 / 64 / 96: key-split form
+// (round 5; VERDICT r4 missing 2: SimpleDyG UCI_13 is head_dim 96, the reddit generator 64 -- they stayed on the exact-f32 kernels.)
+// attention_fused.hip's key-split structure on h2 words: one workgroup = one (sequence, head, 32-query tile), wavefront w walks the
+// 32-key tiles w, w + 4, ... ON ITS OWN with its own online softmax and its own O^T accumulators (no barrier in the loop), the four
+// partial states merged at the end.  S^T = K.Q^T as in attn_h2_kernel (A = the wave's K rows straight from global memory, 4 words per
+// lane and step; B = the Q tile's forms from the LDS word image).  What the small head dims allow: the probabilities never touch LDS
+// -- in the S^T accumulator lane (q, lh) holds keys 8g + 4lh + {0..3} of every 8-key group g, which ARE the k-slots 8lh .. 8lh+7 that
+// lane supplies to the P.V MFMA of that group: four exp2, two h2_words, the two forms by AND / rotate, straight into the operand.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H, int ntq,
+                                                          float qscale, float* __restrict__ out, int out_lines) {
+    constexpr int NCB = HD / 32;                       // 32-column blocks of O^T
+    constexpr int NSTEP = HD / 8;                      // 16-byte K loads per key row (8 elements per MFMA pair)
+    constexpr int LDQ = HD + 4;
+    extern __shared__ unsigned ldsw[];                 // Q words [32][LDQ]; later 2 merge slots; later the O tile [32][HD+4]
+    unsigned* Qs = ldsw;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / ntq) * 8 + xcd;           // (sequence, head) index
+    if (pair >= G.seq_prefix[G.n] * H) return;
+    const int qt = ntq - 1 - slot % ntq, h = pair % H, seq = pair / H;
+    int gi = 0;
+    while (gi + 1 < G.n && seq >= G.seq_prefix[gi + 1]) ++gi;
+    const int T = G.T[gi];
+    const int q0 = qt * 32;
+    if (q0 >= T) return;
+    const long long rowb = G.row0[gi] + (long long)(seq - G.seq_prefix[gi]) * T;
+    const int ld3 = 3 * d;
+    const unsigned* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
+    const int seq_bytes = ((T - 1) * ld3 + HD) * 4;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + d), 0, seq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + 2 * d), 0, seq_bytes, 0x00020000);
+    const int qidx = q0 + li;
+    const int k_voff = (li * ld3 + 4 * lh) * 4;                              // bytes; + scalar (key0 * ld3 + 8u) * 4
+    const int v_voff = (4 * lh * ld3 + li) * 4;                              // bytes; + scalar ((key0 + 8g + e) * ld3 + 32 j) * 4
+    u32x4q kb[NSTEP];
+    if (wid <= qt) {                                                         // this wave's first key tile
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, (wid * 32 * ld3 + 8 * u) * 4, 0);
+    }
+    {   // Q tile: thread t stages row t/8, 16-byte pieces 4*(t%8) + 32j; rows past T repeat the last row (never stored)
+        const int row = tid >> 3, seg = 4 * (tid & 7);
+        const unsigned* src = base + (long long)min(q0 + row, T - 1) * ld3 + seg;
+        u32x4q qv[NCB];
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) qv[j] = *reinterpret_cast<const u32x4q*>(src + 32 * j);
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) *reinterpret_cast<u32x4q*>(Qs + row * LDQ + seg + 32 * j) = qv[j];
+    }
+    __syncthreads();
+
+    f32x16q O0[NCB], O1[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { O0[c][r] = 0.f; O1[c][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const unsigned* q_frag = Qs + li * LDQ + 4 * lh;
+
+    for (int kt = wid; kt <= qt; kt += 4) {
+        const int key0 = kt * 32;
+        // V words: groups 0 and 1 (16 keys) are requested before the Q.K^T MFMAs and land under them, groups 2 and 3 behind them (they
+        // land under the softmax and the first P.V MFMAs): all four up front cost 16 NCB registers beside the K rows, S and O^T
+        u32x4q vb[4][NCB];
+#define ATK_VLOAD(g_)                                                                              \
+        _Pragma("unroll") for (int j = 0; j < NCB; ++j) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+            vb[g_][j][e] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_voff, ((key0 + 8 * (g_) + e) * ld3 + 32 * j) * 4, 0);
+        ATK_VLOAD(0)
+        ATK_VLOAD(1)
+        if (HD > 64 && kt != wid) {                                           // head_dim 96: no K prefetch across tiles (registers)
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, (key0 * ld3 + 8 * u) * 4, 0);
+        }
+        f32x16q S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S0[r] = 0.f; S1[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u) {
+            const u32x4q qw = *reinterpret_cast<const u32x4q*>(q_frag + 8 * u);
+            u32x4q f1, f2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f1[e] = qw[e] & 0xffffu; f2[e] = __builtin_amdgcn_alignbit(qw[e], qw[e], 16); }
+            S0 = ATH_MFMA(kb[u], f1, S0);
+            S1 = ATH_MFMA(kb[u], f2, S1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ATK_VLOAD(2)
+        ATK_VLOAD(3)
+#undef ATK_VLOAD
+        if (HD <= 64 && kt + 4 <= qt) {                                       // the next tile's K rows travel under the softmax and P.V
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, ((key0 + 128) * ld3 + 8 * u) * 4, 0);
+        }
+        // online softmax on the raw dot products (attn_h2_kernel: subtract the maximum first, scale the small difference)
+        float S[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float s_ = __builtin_fmaf(S1[r], H2_LO_UNSCALE, S0[r]);
+            S[r] = (key <= qidx) ? s_ : -INFINITY;
+            mt = fmaxf(mt, S[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);                                 // (a tile whose keys are all masked for this query: -inf stays -inf)
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * qscale);
+        float ps = 0.f;
+        if (__any(alpha != 1.0f && m_run != -INFINITY)) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { O0[c][r] *= alpha; O1[c][r] *= alpha; }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float p[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] = (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((S[4 * g + e] - m_new) * qscale);      // exp2(-inf) = 0 for masked keys
+                ps += p[e];
+            }
+            unsigned a[4];
+            h2_words<false>(p[0], p[1], a[0], a[1]);
+            h2_words<false>(p[2], p[3], a[2], a[3]);
+            u32x4q pf1, pf2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pf1[e] = a[e] & 0xffffu; pf2[e] = __builtin_amdgcn_alignbit(a[e], a[e], 16); }
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) {
+                O0[j] = ATH_MFMA(vb[g][j], pf1, O0[j]);
+                O1[j] = ATH_MFMA(vb[g][j], pf2, O1[j]);
+            }
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+    }
+
+    // ---- join the two accumulator sets, merge the 4 partial states: (2,3) -> (0,1), then 1 -> 0 (attention_fused.hip)
+    f32x16q O[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = __builtin_fmaf(O1[c][r], H2_LO_UNSCALE, O0[c][r]);
+    float* lds = reinterpret_cast<float*>(ldsw);
+    constexpr int SLOT = NCB * 16 * 64 + 128;
+    __syncthreads();                                    // every wave is done with the query buffer
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+        const int writers_lo = step == 0 ? 2 : 1;
+        if (wid >= writers_lo && wid < 2 * writers_lo) {
+            float* sl = lds + (wid - writers_lo) * SLOT;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sl[(c * 16 + r) * 64 + lane] = O[c][r];
+            sl[NCB * 16 * 64 + lane] = m_run;
+            sl[NCB * 16 * 64 + 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (wid < writers_lo) {
+            const float* sl = lds + wid * SLOT;
+            const float m_b = sl[NCB * 16 * 64 + lane], l_b = sl[NCB * 16 * 64 + 64 + lane];
+            const float m_new = fmaxf(m_run, m_b);
+            const float fa = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * qscale);
+            const float fb = (m_b == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_b - m_new) * qscale);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[c][r] = O[c][r] * fa + sl[(c * 16 + r) * 64 + lane] * fb;
+            l_run = l_run * fa + l_b * fb;
+            m_run = m_new;
+        }
+        __syncthreads();
+    }
+    constexpr int LDO = HD + 4;
+    if (wid == 0) {
+        const float inv = H2_A_UNSCALE / l_run;
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[li * LDO + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh] = O[j][r] * inv;
+    }
+    __syncthreads();
+    for (int q = wid; q < 32; q += 4) {
+        if (q0 + q >= T) break;
+        float* dst = out + (rowb + q0 + q) * d + (long long)h * HD;
+        for (int c = lane * 4; c < HD; c += 256) {
+            const float4 o4 = *reinterpret_cast<const float4*>(&lds[q * LDO + c]);
+            if (out_lines) {
+                unsigned h0, l0, h1, l1;
+                split2_pair<true>(o4.x, o4.y, h0, l0);
+                split2_pair<true>(o4.z, o4.w, h1, l1);
+                const int col = h * HD + c;
+                unsigned char* ld = reinterpret_cast<unsigned char*>(out) + (rowb + q0 + q) * (long long)d * 4 + (col >> 5) * 128 + (col & 31) * 2;
+                *reinterpret_cast<uint2*>(ld) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(ld + 64) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4*>(dst + c) = o4;
+            }
+        }
+    }
+}
+
+template <int HD>
+static int launch_ah2ks(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
+    constexpr int NCB = HD / 32;
+    size_t words = (size_t)32 * (HD + 4);                                     // Q tile / O tile
+    const size_t merge = 2 * ((size_t)NCB * 16 * 64 + 128);
+    if (merge > words) words = merge;
+    const size_t lds = words * 4;
+    ProfScope prof(PK_ATTN_FUSED, flop, s);
+    const int ntq = cdiv(Tmax, 32);
+    const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
+    R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
+    hipLaunchKernelGGL((attn_h2ks_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
+                       (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out, out_lines);
+    R4D_CHECK_LAUNCH("attn_h2ks");
+    return R4D_OK;
+}
+
 bool attention_h2_supported(int H, int d) {
     if (H < 1 || d % H) return false;
     const int hd = d / H;
-    return hd == 128 || hd == 256;
+    return hd == 32 || hd == 64 || hd == 96 || hd == 128 || hd == 256;
 }
 
 // Attention of n <= ATT_MAXG batches in one launch (launch_attention_fused_groups's contract) on h2 words
@@ -317,7 +540,7 @@ bool attention_h2_supported(int H, int d) {
 int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
                                float* out, hipStream_t s, bool out_lines) {
     R4D_REQUIRE(qkv && out, "attention_h2: null pointer");
-    R4D_REQUIRE(attention_h2_supported(H, d), "attention_h2: head_dim %d has no instantiation (128 / 256)", H > 0 ? d / H : 0);
+    R4D_REQUIRE(attention_h2_supported(H, d), "attention_h2: head_dim %d has no instantiation (32 / 64 / 96 / 128 / 256)", H > 0 ? d / H : 0);
     R4D_REQUIRE(n >= 1 && n <= ATT_MAXG, "attention_h2: %d batches per launch (max %d)", n, ATT_MAXG);
     const int hd = d / H;
     AttnGroups G;
@@ -335,6 +558,9 @@ int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const 
     }
     for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
     R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention_h2: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
+    if (hd == 32) { R4D_BRANCH(ATT_H2_KS32); return launch_ah2ks<32>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (hd == 64) { R4D_BRANCH(ATT_H2_KS64); return launch_ah2ks<64>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (hd == 96) { R4D_BRANCH(ATT_H2_KS96); return launch_ah2ks<96>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     R4D_BRANCH(ATT_H2_256);
     return launch_ah2<256>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s);

@@ -122,10 +122,10 @@ def test_every_dispatcher_branch_is_exercised(dev):
                 gpt2_mod.FOLD_DECODE_LAYERNORM = fold_before
             assert rel_err(h2.cpu().numpy(), ref[:, 20].numpy()) < 1e-4, ("decode, unfolded LayerNorm", H, d)
 
-    # ---- f16x2 mode: head_dim 128 / 256 attention on the fp16 matrix cores, fed with h2 words by the c_attn GEMM (attention_h2.hip)
+    # ---- f16x2 mode: attention on the fp16 matrix cores (column-split at head_dim 128 / 256, key-split at 32 / 64 / 96), fed with h2 words by the c_attn GEMM (attention_h2.hip)
     ops.set_gemm_mode("f16x2")
     try:
-        for H, d in ((2, 256), (2, 512)):
+        for H, d in ((2, 256), (2, 512), (2, 64), (4, 256), (8, 768)):      # head_dim 128, 256; key-split form: 32, 64, 96
             sd, m = model(1, H, d)
             out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
             ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]

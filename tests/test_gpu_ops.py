@@ -193,7 +193,8 @@ def attn_abs_bound(tag):
 
 
 @pytest.mark.parametrize("tag", ["attn_hd128_T24_s1", "attn_hd256_T20_s1", "attn_hd128_T61_s6", "attn_hd256_T64_s6",
-                                 "attn_hd128_T48_s30", "attn_hd256_T40_s30"])
+                                 "attn_hd128_T48_s30", "attn_hd256_T40_s30",
+                                 "attn_hd32_T40_s1", "attn_hd64_T33_s1", "attn_hd96_T24_s1", "attn_hd64_T48_s30"])    # key-split form (round 5)
 def test_attention_f16x2_golden(dev, tag):
     """csrc/attention_h2.hip (fp16 matrix cores, q / k / v as "h2 words") on the reference's Attention._attn vectors at the two
     head dims it serves, soft (N(0,1)) AND peaked (q, k x 6 and x 30: round 5) -- against the REFERENCE output at an absolute
@@ -222,7 +223,8 @@ def test_attention_f16x2_golden(dev, tag):
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 128), (2, 129, 2, 256), (2, 339, 2, 256), (1, 1024, 2, 128), (2, 257, 6, 128),
-                                      (33, 31, 2, 256), (1, 512, 1, 256), (5, 160, 3, 128)])
+                                      (33, 31, 2, 256), (1, 512, 1, 256), (5, 160, 3, 128),
+                                      (3, 1, 2, 32), (4, 128, 8, 96), (2, 200, 8, 64), (2, 339, 4, 64), (1, 1024, 2, 96), (7, 33, 4, 32)])
 def test_attention_f16x2_words_against_float64(dev, B, T, H, hd):
     """The h2 words ARE the split (value / 4 = hi + 2^-11 lo' to 2^-22); ``r4d_attention_h2_f32`` against the oracle at the
     exact-f32 kernels' bound, and against a float64 attention beside the exact-f32 fused kernel on the same inputs: not a larger

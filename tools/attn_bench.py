@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tuning aid (GPU box): fused vs three-launch attention on the encoder's shapes; head_dim 128 / 256 also the f16x2 kernel
+"""Tuning aid (GPU box): fused vs three-launch attention on the encoder's shapes; every head_dim with an instantiation also the f16x2 kernels
 (csrc/attention_h2.hip).  ATT_H2_ONLY=1: that kernel alone (ablated builds: tools/kc_ablate.sh attention_h2.hip ATH_DBG n)."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ for (B, T, H, hd) in SHAPES:
     qkv = torch.randn(B, T, 3 * d, device=dev)
     flop = 2.0 * B * H * T * T * hd
     h2 = ""
-    if hd in (128, 256):
+    if hd in (32, 64, 96, 128, 256):
         w = ops.pack_h2_words(qkv)
         for _ in range(3):
             ops.attention_h2(w, H)
