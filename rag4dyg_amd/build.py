@@ -89,7 +89,7 @@ def check_handoff_lowering(src):
 PACKED_F32_FILES = ("gemm_h2.hip", "attention_h2.hip")
 PACKED_F32_FORMS = {
     "v_pk_mul_f32 V, V, S op_sel_hi:[1,0]", "v_pk_mul_f32 V, S, V op_sel_hi:[0,1]", "v_pk_mul_f32 V, V, S", "v_pk_mul_f32 V, S, V",
-    "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,1]", "v_pk_fma_f32 V, S, V, V op_sel_hi:[0,1,1]",
+    "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,1]", "v_pk_fma_f32 V, S, V, V op_sel_hi:[0,1,1]", "v_pk_fma_f32 V, V, S, V", "v_pk_fma_f32 V, S, V, V",
     "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]",
     "v_pk_fma_f32 V, V, S, V op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]",
     "v_pk_fma_f32 V, S, V, V op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]",

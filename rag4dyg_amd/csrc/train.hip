@@ -120,14 +120,22 @@ static int check_groups(const r4d_gpt2_config* cfg, int n_groups, const int64_t*
 // y[M,N] = epilogue(x[M,K] . W[K,N] + bias)   (Conv1D.forward, modeling_utils.py:1267-1271).  `wT` (nullable): the caller's
 // CURRENT [N,K] copy of the weight (refreshed after every optimizer step) -> the k-contiguous kernel; else the reference layout
 static int fwd_linear(const float* x, const float* w, const float* wT, const float* bias, const float* resid, int M, int K, int N,
-                      int epi, float* y, hipStream_t s, const unsigned short* w3 = nullptr) {
-    return conv1d(x, w, wT, bias, resid, M, K, N, epi, y, s, nullptr, false, w3);     // bf16x3 planes > [N,K] copy > reference layout
+                      int epi, float* y, hipStream_t s, const unsigned short* w3 = nullptr, const unsigned short* w2h = nullptr) {
+    return conv1d(x, w, wT, bias, resid, M, K, N, epi, y, s, nullptr, false, w3, w2h);     // f16x2 planes (mode 2) > bf16x3 planes > [N,K] copy > reference layout
 }
 // dx[M,K] = dy[M,N] . W[K,N]^T : W's rows are k(N)-contiguous, i.e. W IS the [N' = K, K' = N] operand of the fast kernel;
 // `w3t` (nullable): its bf16x3 planes [3][K][N] -> the bf16 matrix cores at fp32 accuracy
 // `gelu_pre` (bf16x3 path only): dx = (dy . W^T) * gelu_new'(gelu_pre), gelu_pre [M,K]
+// `h2t` (nullable; round 5): its f16x2 lines [K][N/32][2][32] -> the fp16 matrix cores, three products per fp32 product (gemm mode 2)
 static int bwd_data(const float* dy, const float* w, int M, int K, int N, float* dx, hipStream_t s, const unsigned short* w3t = nullptr,
-                    const float* gelu_pre = nullptr) {
+                    const float* gelu_pre = nullptr, const unsigned short* h2t = nullptr) {
+    if (h2t && g_gemm_split3 == 2 && gemm_h2_supported(M, N, K)) {
+        S3Args a;
+        memset(&a, 0, sizeof(a));
+        a.A = dy; a.planes = h2t; a.C = dx; a.M = M; a.N = K; a.K = N; a.lda = N; a.ldc = K; a.ldr = K;
+        a.epilogue = gelu_pre ? EPI_GELU_GRAD : EPI_NONE; a.resid = gelu_pre;
+        return launch_gemm_h2(a, s);
+    }
     if (w3t && g_gemm_split3 && gemm_s3_supported(M, N, K)) {
         S3Args a;
         memset(&a, 0, sizeof(a));
@@ -328,28 +336,28 @@ int r4d_gpt2_train_forward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weight
             if ((rc = launch_dropout(x_in, nullptr, (long long)M * d, x_in, dc.embd_p, dc.key, R4D_DROPOUT_SITE_EMBD, 0, s))) return rc;
             if ((rc = launch_layernorm(x_in, Lw.ln_1_w, Lw.ln_1_b, M, d, cfg->ln_eps, ln1, s))) return rc;
         }
-        if ((rc = fwd_linear(ln1, Lw.c_attn_w, Lw.c_attn_wT, Lw.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s, Lw.c_attn_w3))) return rc;
+        if ((rc = fwd_linear(ln1, Lw.c_attn_w, Lw.c_attn_wT, Lw.c_attn_b, nullptr, M, d, 3 * d, EPI_NONE, qkv, s, Lw.c_attn_w3, Lw.c_attn_h2))) return rc;
         for (const TrainGroup& G : gs)
             if ((rc = attn_fwd(qkv + G.row0 * 3 * d, G.B, G.T, H, d, ws + t.P[l] + G.p0, att + G.row0 * d, s, dc.attn_p, dc.key,
                                4u * l + 0u, G.p0, ws + t.dP))) return rc;
         float* branch = ws + t.dy;                                   // a backward temporary, free during the forward
         if (dc.resid_p > 0.f) {                                      // x + resid_dropout(c_proj(a)), :194,229
-            if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, nullptr, M, d, d, EPI_NONE, branch, s, Lw.attn_proj_w3))) return rc;
+            if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, nullptr, M, d, d, EPI_NONE, branch, s, Lw.attn_proj_w3, Lw.attn_proj_h2))) return rc;
             if ((rc = launch_dropout(branch, x_in, (long long)M * d, x_mid, dc.resid_p, dc.key, 4u * l + 1u, 0, s))) return rc;
-        } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s, Lw.attn_proj_w3))) return rc;
+        } else if ((rc = fwd_linear(att, Lw.attn_proj_w, Lw.attn_proj_wT, Lw.attn_proj_b, x_in, M, d, d, EPI_RESIDUAL, x_mid, s, Lw.attn_proj_w3, Lw.attn_proj_h2))) return rc;
         if ((rc = launch_layernorm(x_mid, Lw.ln_2_w, Lw.ln_2_b, M, d, cfg->ln_eps, ln2, s))) return rc;
         if (g_train_fuse_gelu && Lw.c_fc_w3 && g_gemm_split3 && gemm_s3_supported(M, d, 4 * d)) {
             // one launch: f = gelu_new(v) and the pre-activation v (kept for the backward pass) both leave the GEMM's epilogue
-            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, pre, M, d, 4 * d, EPI_GELU_KEEP, f, s, Lw.c_fc_w3))) return rc;
+            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, pre, M, d, 4 * d, EPI_GELU_KEEP, f, s, Lw.c_fc_w3, Lw.c_fc_h2))) return rc;
         } else {
-            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s, Lw.c_fc_w3))) return rc;
+            if ((rc = fwd_linear(ln2, Lw.c_fc_w, Lw.c_fc_wT, Lw.c_fc_b, nullptr, M, d, 4 * d, EPI_NONE, pre, s, Lw.c_fc_w3, Lw.c_fc_h2))) return rc;
             if ((rc = launch_gelu_fwd(pre, (long long)M * 4 * d, f, s))) return rc;
         }
         float* x_next = l + 1 < cfg->n_layer ? ws + t.x_in[l + 1] : ws + t.x_out;
         if (dc.resid_p > 0.f) {                                      // x + dropout(c_proj(act(c_fc(x)))), :212,233
-            if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s, Lw.mlp_proj_w3))) return rc;
+            if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, nullptr, M, 4 * d, d, EPI_NONE, branch, s, Lw.mlp_proj_w3, Lw.mlp_proj_h2))) return rc;
             if ((rc = launch_dropout(branch, x_mid, (long long)M * d, x_next, dc.resid_p, dc.key, 4u * l + 2u, 0, s))) return rc;
-        } else if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s, Lw.mlp_proj_w3))) return rc;
+        } else if ((rc = fwd_linear(f, Lw.mlp_proj_w, Lw.mlp_proj_wT, Lw.mlp_proj_b, x_mid, M, 4 * d, d, EPI_RESIDUAL, x_next, s, Lw.mlp_proj_w3, Lw.mlp_proj_h2))) return rc;
     }
     return launch_lnf_meanpool_groups(R, ws + t.x_out, w->ln_f_w, w->ln_f_b, d, cfg->ln_eps, nullptr, out_meanpool_d,
                                       ws + t.pool_scratch, s);
@@ -396,13 +404,13 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
         if ((rc = bwd_weight(f, dbr, M, 4 * d, d, Lg.mlp_proj_w, Lg.mlp_proj_b, xT, red, s))) return rc;
         if (g_train_fuse_gelu && Lw.mlp_proj_w3t && g_gemm_split3 && gemm_s3_supported(M, d, 4 * d)) {
             // d(pre) = (d(branch) . Wp^T) * gelu_new'(pre): the derivative is applied in the GEMM's epilogue
-            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t, pre))) return rc;
+            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t, pre, Lw.mlp_proj_h2t))) return rc;
         } else {
-            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t))) return rc;                    // d(f)
+            if ((rc = bwd_data(dbr, Lw.mlp_proj_w, M, 4 * d, d, dbig, s, Lw.mlp_proj_w3t, nullptr, Lw.mlp_proj_h2t))) return rc;                    // d(f)
             if ((rc = launch_gelu_bwd(pre, dbig, (long long)M * 4 * d, dbig, s))) return rc;              // d(pre), in place
         }
         if ((rc = bwd_weight(ln2, dbig, M, d, 4 * d, Lg.c_fc_w, Lg.c_fc_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dbig, Lw.c_fc_w, M, d, 4 * d, dy, s, Lw.c_fc_w3t))) return rc;                              // d(ln_2 out)
+        if ((rc = bwd_data(dbig, Lw.c_fc_w, M, d, 4 * d, dy, s, Lw.c_fc_w3t, nullptr, Lw.c_fc_h2t))) return rc;                              // d(ln_2 out)
         if ((rc = launch_ln_bwd(x_mid, Lw.ln_2_w, dy, dx, M, d, cfg->ln_eps, dx, Lg.ln_2_w, Lg.ln_2_b, red, 0, s))) return rc;   // dx = d(x_mid)
         // ---- attention: x_mid = x_in + attn(ln_1(x_in)) Wo + bo
         dbr = dx;
@@ -411,12 +419,12 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
             dbr = dbig;
         }
         if ((rc = bwd_weight(att, dbr, M, d, d, Lg.attn_proj_w, Lg.attn_proj_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dbr, Lw.attn_proj_w, M, d, d, dy, s, Lw.attn_proj_w3t))) return rc;                              // d(att), merged heads
+        if ((rc = bwd_data(dbr, Lw.attn_proj_w, M, d, d, dy, s, Lw.attn_proj_w3t, nullptr, Lw.attn_proj_h2t))) return rc;                              // d(att), merged heads
         for (const TrainGroup& G : gs)
             if ((rc = attn_bwd(qkv + G.row0 * 3 * d, ws + t.P[l] + G.p0, dy + G.row0 * d, G.B, G.T, H, d, dqkv + G.row0 * 3 * d,
                                ws + t.dP, ws + t.PT, s, dc.attn_p, dc.key, 4u * l + 0u, G.p0))) return rc;
         if ((rc = bwd_weight(ln1, dqkv, M, d, 3 * d, Lg.c_attn_w, Lg.c_attn_b, xT, red, s))) return rc;
-        if ((rc = bwd_data(dqkv, Lw.c_attn_w, M, d, 3 * d, dy, s, Lw.c_attn_w3t))) return rc;                            // d(ln_1 out)
+        if ((rc = bwd_data(dqkv, Lw.c_attn_w, M, d, 3 * d, dy, s, Lw.c_attn_w3t, nullptr, Lw.c_attn_h2t))) return rc;                            // d(ln_1 out)
         if ((rc = launch_ln_bwd(x_in, Lw.ln_1_w, dy, dx, M, d, cfg->ln_eps, dx, Lg.ln_1_w, Lg.ln_1_b, red, 0, s))) return rc;    // dx = d(x_in)
     }
     // embeddings: x_in[0] = drop(wte[ids] + wpe[0..T-1])

@@ -91,8 +91,9 @@ def test_training_step_forward_losses_equal_reference(dev, tag):
 
 
 @pytest.mark.parametrize("tag", ["ts_tiny", "ts_cfg2"])
-def test_training_step_gradients_equal_reference_autograd(dev, tag):
-    """Backward pass on the HIP kernels against the REFERENCE's autograd (G8: one train_epoch iteration, dropout 0): the
+def test_training_step_gradients_equal_reference_autograd(dev, tag, gemm_mode):
+    """(All three arithmetics -- f16x2: forward and data-gradient GEMMs on the fp16 matrix cores since round 5; bf16x3; exact f32.)
+    Backward pass on the HIP kernels against the REFERENCE's autograd (G8: one train_epoch iteration, dropout 0): the
     gradient norm of every parameter tensor and three tensors element-wise from the fixture, and EVERY tensor element-wise
     against the oracle's grad-enabled forward (itself pinned by the same fixture)."""
     from oracle import gpt2_ref, train_ref
@@ -335,8 +336,8 @@ def test_encode_after_optimizer_step_uses_the_updated_weights(dev, via_step, spl
                                            (3, 2, 256, 200, 5, (21, 33, 40)),      # hepth script shape (head_dim 128, d = 256)
                                            (1, 8, 512, 500, 3, (130, 9, 64)),      # reddit shape (head_dim 64), one batch > 128 positions
                                            (2, 4, 64, 60, 2, (25, 30, 22))])       # head_dim 16
-def test_training_gradients_other_shapes_equal_oracle(dev, L, H, d, V, B, Ts):
-    """The training forward + backward at the model shapes of the other reference scripts (wikiv2, hepth, reddit; ragged padded
+def test_training_gradients_other_shapes_equal_oracle(dev, L, H, d, V, B, Ts, gemm_mode):
+    """(All three arithmetics.)  The training forward + backward at the model shapes of the other reference scripts (wikiv2, hepth, reddit; ragged padded
     lengths, also above one 128-position attention tile) against the oracle's grad-enabled forward + CPU autograd (pinned by G8):
     embeddings, the loss and every parameter gradient element-wise (max-norm)."""
     from oracle import gpt2_ref, train_ref

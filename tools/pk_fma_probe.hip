@@ -50,6 +50,12 @@ __global__ __launch_bounds__(64) void probe(const _Float16* __restrict__ a, cons
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(u) : "v"(t), "s"(cp), "v"(x0));
             v = u;
         }
+        else if (FORM == 6) {     // a GENUINE SGPR pair (two different constants, default op_sel_hi): low half x c, high half x bias
+            unsigned long long cp = (unsigned long long)__builtin_bit_cast(unsigned, c) | ((unsigned long long)__builtin_bit_cast(unsigned, bias) << 32);
+            f32x2 u;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(u) : "v"(x1), "s"(cp), "v"(x0));
+            v = u;
+        }
         else if (FORM == 4) { v = (x0 - x1) * c; v = v * bias; v = x0 - v * c; }      // v_pk_mul with a broadcast SGPR, fma with negated operands (the A-split of gemm_h2's staging)
         else {                                                             // GELU on top (the variant that was not reproducible)
             v = (x1 * c + x0) * 4.0f + bias;
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(64) void probe(const _Float16* __restrict__ a, cons
     for (int r = 0; r < 16; ++r) {
         float x0 = acc0[r], x1 = acc1[r], cs = c;
         asm volatile("" : "+v"(x0), "+v"(x1), "+v"(cs));
-        float v = (FORM == 4 || FORM == 5) ? 0.f : __builtin_fmaf(x1, cs, x0);
+        float v = (FORM == 4 || FORM == 5 || FORM == 6) ? 0.f : __builtin_fmaf(x1, cs, x0);
+        if (FORM == 6) { float b2 = bias; asm volatile("" : "+v"(b2)); v = __builtin_fmaf(x1, (r & 1) ? b2 : cs, x0); }
         if (FORM == 5) { float t = x1 * cs; asm volatile("" : "+v"(t)); v = __builtin_fmaf(t, cs, -x0); }
         if (FORM == 4) { float b2 = bias; asm volatile("" : "+v"(b2)); v = (x0 - x1) * cs; v = v * b2; v = __builtin_fmaf(-v, cs, x0); }
         if (FORM == 1 || FORM == 3) v = __builtin_fmaf(v, 4.0f, bias);
@@ -140,6 +147,8 @@ int main() {
     bad += run<4, true>("sub, mul, negated fma, B.A", a, b, opk, osc, blocks);
     bad += run<5, false>("v_pk_mul V,V,S op_sel_hi:[1,0] + v_pk_fma V,V,S,V neg addend, A.B", a, b, opk, osc, blocks);
     bad += run<5, true>("v_pk_mul V,V,S op_sel_hi:[1,0] + v_pk_fma V,V,S,V neg addend, B.A", a, b, opk, osc, blocks);
+    bad += run<6, false>("v_pk_fma V,V,S,V with a genuine SGPR pair, A.B", a, b, opk, osc, blocks);
+    bad += run<6, true>("v_pk_fma V,V,S,V with a genuine SGPR pair, B.A", a, b, opk, osc, blocks);
     printf("%s\n", bad ? "MISMATCHES FOUND" : "all forms agree");
     return bad ? 1 : 0;
 }
