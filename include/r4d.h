@@ -98,12 +98,9 @@ typedef struct r4d_gpt2_layer {   /* device pointers, one struct per transformer
      * for the error analysis and the operand range: |activation| < 2^18, |weight| < 6e4). */
     const uint16_t* c_attn_h2;  const uint16_t* attn_proj_h2;
     const uint16_t* c_fc_h2;    const uint16_t* mlp_proj_h2;
-    /* TRAINING only, optional (ABI v6): the f16x2 lines of the same weights as the operand of the data-gradient GEMMs dx = dy . W^T
-     * (r4d_split2_planes_f16(w, K = out, N = in, transposed = 1): uint16 [in][out/32][2][32]); with them, the *_h2 planes and
-     * r4d_set_gemm_split3(2) the forward and data-gradient GEMMs of r4d_gpt2_train_* run on the fp16 matrix cores (the weight
-     * gradients keep the bf16x3 transposing kernel).  Refreshed by the caller after each optimizer step, like every plane set. */
-    const uint16_t* c_attn_h2t; const uint16_t* attn_proj_h2t;
-    const uint16_t* c_fc_h2t;   const uint16_t* mlp_proj_h2t;
+    /* (ABI v6: r4d_gpt2_train_forward_f32 uses the *_h2 planes too in mode 2 -- the FORWARD GEMMs of a training step on the fp16
+     * matrix cores; every gradient GEMM keeps bf16x3: a gradient operand needs fp32's exponent range.  Refreshed by the caller
+     * after each optimizer step, like every plane set.) */
 } r4d_gpt2_layer;
 
 typedef struct r4d_gpt2_weights {

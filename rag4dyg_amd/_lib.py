@@ -28,8 +28,7 @@ class GPT2LayerC(Structure):
                                          "c_attn_w3", "attn_proj_w3", "c_fc_w3", "mlp_proj_w3",
                                          "c_attn_w3t", "attn_proj_w3t", "c_fc_w3t", "mlp_proj_w3t",
                                          "c_attn_wTg", "c_attn_lnc", "c_fc_wTg", "c_fc_lnc",
-                                         "c_attn_h2", "attn_proj_h2", "c_fc_h2", "mlp_proj_h2",
-                                         "c_attn_h2t", "attn_proj_h2t", "c_fc_h2t", "mlp_proj_h2t")]
+                                         "c_attn_h2", "attn_proj_h2", "c_fc_h2", "mlp_proj_h2")]
 
 
 class GreedyStateC(Structure):

@@ -25,7 +25,7 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
                                   sk_counters_zeroed);
     // f16x2 planes present and selected: fp16 matrix cores, three products per fp32 product, fp32 accuracy (gemm_h2.hip).
     // NOT gated on M, like the bf16x3 branch below
-    if (w2h && g_gemm_split3 == 2 && (epilogue <= EPI_RESIDUAL || epilogue >= EPI_GELU_KEEP) && gemm_h2_supported(M, K, N)) {
+    if (w2h && g_gemm_split3 == 2 && (epilogue <= EPI_RESIDUAL || epilogue == EPI_GELU_KEEP || epilogue == EPI_H2WORDS) && gemm_h2_supported(M, K, N)) {
         S3Args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.planes = w2h; a.C = y; a.bias = bias; a.resid = resid;

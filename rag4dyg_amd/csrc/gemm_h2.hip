@@ -59,15 +59,6 @@ __device__ __forceinline__ float gelu_new_h2_1(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0)));
 }
 
-// d gelu_new / dx with the exponential of gelu_new_h2 (gemm_s3.hip's gelu_new_grad_s3, same instructions): tanh(u) = 1 - 2 / (1 + e^(2u))
-__device__ __forceinline__ float gelu_new_grad_h2(float x) {
-    const float c = 0.7978845608028654f;
-    const float x2 = x * x;
-    const float u2 = 2.0f * c * 1.4426950408889634f * x * __builtin_fmaf(x2, 0.044715f, 1.0f);     // 2u log2(e)
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * __builtin_fmaf(x2, 3.0f * 0.044715f, 1.0f);
-}
-
 struct H2Shape {
     int M, N, K, lda, ldc, ldr;
     int plane_bytes;          // N * K * 2: half the size of W's fp16 lines
@@ -310,7 +301,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
     // (c_attn 442 vs 430 us) and its GELU variant gave run-to-run different values in lanes 12-15 / 28-31 of each half-wave at some
     // shapes (scalar or packed arithmetic, with or without wait states; tools/h2_check.py now repeats every launch three times).
     constexpr float UNS = H2_A_UNSCALE;
-    constexpr bool USES_R = EPI == EPI_RESIDUAL || EPI == EPI_GELU_KEEP || EPI == EPI_GELU_GRAD;      // the second buffer is read or written
+    constexpr bool USES_R = EPI == EPI_RESIDUAL || EPI == EPI_GELU_KEEP;      // the second buffer is read (residual) or written (training forward: the pre-activation)
     float* __restrict__ C = Cg;
     const bool interior = (m0 + BM <= g.M) & (n0 + BN <= g.N);       // wave-uniform
     if (interior) {
@@ -327,7 +318,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float res[16];
-                if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD) {
+                if (EPI == EPI_RESIDUAL) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -345,9 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
                                                                   ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0);
                         }
                     }
-                    if (EPI == EPI_GELU_KEEP) v2 = gelu_new_h2(v2);
-                    else if (EPI == EPI_GELU_GRAD) { v2.x *= gelu_new_grad_h2(res[r2]); v2.y *= gelu_new_grad_h2(res[r2 + 1]); }
-                    if (EPI == EPI_GELU) v2 = gelu_new_h2(v2);
+                    if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v2 = gelu_new_h2(v2);
                     else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
                     else if (EPI == EPI_HALF_PLUS) { v2.x = (v2.x + 1.0f) / 2.0f; v2.y = (v2.y + 1.0f) / 2.0f; }     // train_retriever.py:438
                     const float vx = v2.x, vy = v2.y;     // (copies first: __builtin_bit_cast on an ext-vector ELEMENT reads element 0)
@@ -378,7 +367,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2_kerne
                 float v = __builtin_fmaf(acc1[i][j][r], H2_LO_UNSCALE, acc0[i][j][r]) * UNS + bias;
                 if (EPI == EPI_GELU_KEEP && row < g.M && col_ok) const_cast<float*>(residg)[(long long)row * g.ldr + col] = v;
                 if (EPI == EPI_GELU || EPI == EPI_GELU_KEEP) v = gelu_new_h2_1(v);
-                else if (EPI == EPI_GELU_GRAD) v *= gelu_new_grad_h2(residg[(long long)min(row, g.M - 1) * g.ldr + colc]);
                 else if (EPI == EPI_RESIDUAL) v += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
                 else if (EPI == EPI_HALF_PLUS) v = (v + 1.0f) / 2.0f;
                 else if (EPI == EPI_H2WORDS) { unsigned w0, w1; h2_words<true>(v, 0.f, w0, w1); v = __builtin_bit_cast(float, w0); }
@@ -404,7 +392,6 @@ static int launch_h2(const S3Args& a, int cls, hipStream_t stream) {
         case EPI_RESIDUAL: H2_LAUNCH_(EPI_RESIDUAL); break;
         case EPI_H2WORDS: H2_LAUNCH_(EPI_H2WORDS); break;
         case EPI_GELU_KEEP: H2_LAUNCH_(EPI_GELU_KEEP); break;
-        case EPI_GELU_GRAD: H2_LAUNCH_(EPI_GELU_GRAD); break;
         default: set_error("gemm_h2: epilogue %d has no instantiation", a.epilogue); return R4D_ERR_INVALID;
     }
 #undef H2_LAUNCH_
@@ -421,7 +408,7 @@ int launch_gemm_h2(const S3Args& a, hipStream_t stream) {
     R4D_REQUIRE(a.A && a.planes && a.C, "gemm_h2: null pointer");
     R4D_REQUIRE(gemm_h2_supported(a.M, a.K, a.N), "gemm_h2: unsupported shape M=%d K=%d N=%d (K %% 32 == 0 wanted)", a.M, a.K, a.N);
     R4D_REQUIRE(a.lda % 4 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_h2: alignment");
-    R4D_REQUIRE((a.epilogue != EPI_RESIDUAL && a.epilogue != EPI_GELU_KEEP && a.epilogue != EPI_GELU_GRAD) || a.resid,
+    R4D_REQUIRE((a.epilogue != EPI_RESIDUAL && a.epilogue != EPI_GELU_KEEP) || a.resid,
                 "gemm_h2: this epilogue needs the second buffer");
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("R4D_GEMM_H2_TILE"); forced = e ? atoi(e) : -1; }

@@ -173,11 +173,11 @@ class EncoderTrainer:
         # (ops.split3_planes; the bf16 matrix cores at fp32 accuracy); refreshed with the copies above
         self.use_s3 = ops.gemm_split3_enabled() and os.environ.get("R4D_TRAIN_SPLIT3", "1") != "0"
         self._w3, self._w3t = {}, {}
-        # f16x2 mode (round 5): f16x2 lines of the same weights -- [out, in/32, 2, 32] for the forward GEMMs, [in, out/32, 2, 32] for the
-        # data gradients -- the fp16 matrix cores with three products per fp32 product (csrc/gemm_h2.hip); the weight gradients keep
-        # the bf16x3 transposing kernel.  R4D_TRAIN_H2=0 keeps bf16x3 everywhere.
+        # f16x2 mode (round 5): f16x2 lines [out, in/32, 2, 32] of the same weights for the FORWARD GEMMs -- the fp16 matrix cores with
+        # three products per fp32 product (csrc/gemm_h2.hip).  Every gradient GEMM keeps bf16x3: a gradient operand (1e-5 .. 1e-8) needs
+        # fp32's exponent range (csrc/train.hip: bwd_data).  R4D_TRAIN_H2=0 keeps bf16x3 in the forward pass too.
         self.use_h2 = self.use_s3 and ops.gemm_mode() == "f16x2" and os.environ.get("R4D_TRAIN_H2", "1") != "0"
-        self._h2, self._h2t = {}, {}
+        self._h2 = {}
         if self.use_wt or self.use_s3:
             self.refresh_transposed()
 
@@ -204,9 +204,7 @@ class EncoderTrainer:
                     if self.use_h2:
                         if (i, f) not in self._h2:
                             self._h2[(i, f)] = torch.empty(N, K // 32, 2, 32, dtype=torch.int16, device=w.device)
-                            self._h2t[(i, f)] = torch.empty(K, N // 32, 2, 32, dtype=torch.int16, device=w.device)
                         _lib.check(lib.r4d_split2_planes_f16(w.data_ptr(), K, N, 0, self._h2[(i, f)].data_ptr(), stream), "split2_planes")
-                        _lib.check(lib.r4d_split2_planes_f16(w.data_ptr(), N, K, 1, self._h2t[(i, f)].data_ptr(), stream), "split2_planes")
 
     def _structs(self):
         tr = self.model.transformer
@@ -226,7 +224,6 @@ class EncoderTrainer:
                 for f, name in zip(fs, ("c_attn", "attn_proj", "c_fc", "mlp_proj")):
                     if (i, f) in self._h2:
                         setattr(layers[i], name + "_h2", self._h2[(i, f)].data_ptr())
-                        setattr(layers[i], name + "_h2t", self._h2t[(i, f)].data_ptr())
             glayers[i] = _lib.GPT2LayerGradsC(*[self.grads[f"transformer.h.{i}.{name}"].data_ptr() for _f, name in _LAYER_PARAMS])
         w = _lib.GPT2WeightsC(tr.wte.weight.data_ptr(), tr.wpe.weight.data_ptr(), tr.ln_f.weight.data_ptr(),
                               tr.ln_f.bias.data_ptr(), layers, None)
