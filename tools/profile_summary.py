@@ -74,10 +74,10 @@ def bench_class(k):
         return f"gemm_s3_{m.group(1)}x{m.group(2)}x32"
     if k.startswith("gemm_s3p_kernel"):                      # persistent form of the same tile: same bench.py class
         return "gemm_s3_128x256x32"
-    m = re.match(r"gemm_h2_kernel<(\d+), (\d+), ", k)
+    m = re.match(r"gemm_h2p?_kernel<(\d+), (\d+), ", k)          # gemm_h2p_kernel (A as f16x2 lines, LDS-DMA): the same tile, the same bench.py class
     if m:
         return f"gemm_h2_{m.group(1)}x{m.group(2)}x32"
-    if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel", "attn_h2_kernel")):
+    if k.startswith(("attn_colsplit_kernel", "attn_fused_kernel", "attn_h2_kernel", "attn_h2ks_kernel")):
         return "attn_fused"
     if k.startswith("ln4_kernel"):
         return "layernorm"
