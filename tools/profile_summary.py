@@ -69,6 +69,8 @@ def bench_class(k):
     m = re.match(r"gemm_f32_kc_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+(?:, \d+)?>", k)       # (+ epilogue kind)
     if m:
         return f"gemm_f32_kc_{m.group(1)}x{m.group(2)}x{m.group(3)}"
+    if re.match(r"gemm_s3_kernel<\d+, \d+, \d+, \d+, \d+, \d+, \d+, true, [1-9]", k):     # SCAN order: the scoring tiles of Q >= 64 (score.hip)
+        return "pool_scan"
     m = re.match(r"gemm_s3_kernel<(\d+), (\d+), ", k)
     if m:
         return f"gemm_s3_{m.group(1)}x{m.group(2)}x32"
