@@ -72,17 +72,19 @@ __device__ __forceinline__ void h2p_dma4(const void* base, unsigned v0, unsigned
 template <int N_> __device__ __forceinline__ void h2p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
 
 // OUT_LINES (with EPI_GELU): C is the f16x2-line image of the result, [M][N/32][2][32] fp16 (the A operand of the next GEMM)
-template <int BM, int BN, int EPI, bool OUT_LINES>
-__global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Bp,
+// WGM x WGN wavefronts: 2 x 4 (wave tile 64 x 64 at 128 x 256, two wavefronts per SIMD) or 2 x 2 (wave tile 64 x 128, ONE wavefront per
+// SIMD with the whole register file: 12 fragment reads per 24 MFMAs instead of 8 per 12 -- a quarter fewer LDS bytes per flop)
+template <int BM, int BN, int EPI, bool OUT_LINES, int WGM = 2, int WGN = 4>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kernel(const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Bp,
                                                           float* __restrict__ Cg, const float* __restrict__ biasg,
                                                           const float* __restrict__ residg, const H2PShape g) {
-    constexpr int WGM = 2, WGN = 4;
+    constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int STAGE = (BM + BN) * 8;                              // uint4 units: a row = 8 slots of 16 bytes (hi 0..3, lo' 4..7, XOR-ed)
     constexpr int NBUF = 3;
-    constexpr int NGA = BM / 64, NGB = BN / 64;                       // 8-row groups per wavefront and k-tile: 2 of A, 4 (2) of W
+    constexpr int NGA = BM / 8 / NW, NGB = BN / 8 / NW;               // 8-row groups per wavefront and k-tile: 2 of A, 4 (2) of W with 8 wavefronts
     constexpr int NDMA = NGA + NGB;
-    static_assert(BM == 128 && (BN == 256 || BN == 128) && TM >= 1 && TN >= 1, "tile");
+    static_assert(BM == 128 && (BN == 256 || BN == 128) && TM >= 1 && TN >= 1 && (NGA == 2 || NGA == 4) && (NGB == 2 || NGB == 4 || NGB == 8), "tile");
     __shared__ u32x4p lds[NBUF * STAGE];
 
     // XCD-aware grouped tile order (gemm_h2.hip)
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const unsigned short* 
 #pragma unroll
     for (int i = 0; i < NGA; ++i) {
         const int r = (wid * NGA + i) * 8 + lrow;                     // row of the A tile
-        va[i] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)(g.K * 4) + 16u * (unsigned)(lslot ^ ((r >> 1) & 7)) + 3072u - 1024u * i;
+        va[i] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)(g.K * 4) + 16u * (unsigned)(lslot ^ ((r >> 1) & 7)) + 3072u - 1024u * (i & 3);
     }
 #pragma unroll
     for (int i = 0; i < NGB; ++i) {
         const int r = (wid * NGB + i) * 8 + lrow;                     // row of the W tile
-        vb[i] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)(g.K * 4) + 16u * (unsigned)(lslot ^ ((r >> 1) & 7)) + 3072u - 1024u * i;
+        vb[i] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)(g.K * 4) + 16u * (unsigned)(lslot ^ ((r >> 1) & 7)) + 3072u - 1024u * (i & 3);
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned wid_s = __builtin_amdgcn_readfirstlane((unsigned)wid);     // wave-uniform: the DMA destinations live in SGPRs (M0)
@@ -122,8 +124,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const unsigned short* 
 #define H2P_ISSUE(KT, STG)                                                                         \
     {                                                                                              \
         const unsigned so_ = (unsigned)(STG) * (unsigned)(STAGE * 16);                             \
-        h2p_dma2(abase + (size_t)(KT) * 128, va[0], va[1], dst_a + so_);                           \
-        if constexpr (NGB == 4) h2p_dma4(bbase + (size_t)(KT) * 128, vb[0], vb[1], vb[2], vb[3], dst_b + so_); \
+        if constexpr (NGA == 4) h2p_dma4(abase + (size_t)(KT) * 128, va[0], va[1], va[2], va[3], dst_a + so_); \
+        else h2p_dma2(abase + (size_t)(KT) * 128, va[0], va[1], dst_a + so_);                      \
+        if constexpr (NGB == 8) {                                                                  \
+            h2p_dma4(bbase + (size_t)(KT) * 128, vb[0], vb[1], vb[2], vb[3], dst_b + so_);          \
+            h2p_dma4(bbase + (size_t)(KT) * 128, vb[4], vb[5], vb[6], vb[7], dst_b + so_ + 4096u);  /* same global base: only M0 moves */ \
+        } else if constexpr (NGB == 4) h2p_dma4(bbase + (size_t)(KT) * 128, vb[0], vb[1], vb[2], vb[3], dst_b + so_); \
         else h2p_dma2(bbase + (size_t)(KT) * 128, vb[0], vb[1], dst_b + so_);                       \
     }
 
@@ -350,7 +356,11 @@ static int launch_h2p(const S3Args& a, const unsigned short* a_lines, bool out_l
     ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
     H2PShape sh;
     sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.ldc = a.ldc; sh.ldr = a.ldr;
-#define H2P_LAUNCH_(E, OL) hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL>), dim3(tiles), dim3(512), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh)
+    static int w4 = -1;                                               // R4D_GEMM_H2P_W4=1: the 2 x 2 wave grid (one wavefront per SIMD) at 128 x 256
+    if (w4 < 0) { const char* e = getenv("R4D_GEMM_H2P_W4"); w4 = e ? atoi(e) : 0; }
+#define H2P_LAUNCH_(E, OL)                                                                         \
+    if (BN == 256 && w4) hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL, 2, (BN == 256 ? 2 : 4)>), dim3(tiles), dim3(64 * 2 * (BN == 256 ? 2 : 4)), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh); \
+    else hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL>), dim3(tiles), dim3(512), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh)
     if (out_lines) {
         if (a.epilogue != EPI_GELU) { set_error("gemm_h2p: line output exists for the GELU epilogue only"); return R4D_ERR_INVALID; }
         H2P_LAUNCH_(EPI_GELU, true);
