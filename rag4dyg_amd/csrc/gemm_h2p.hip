@@ -72,8 +72,11 @@ __device__ __forceinline__ void h2p_dma4(const void* base, unsigned v0, unsigned
 template <int N_> __device__ __forceinline__ void h2p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
 
 // OUT_LINES (with EPI_GELU): C is the f16x2-line image of the result, [M][N/32][2][32] fp16 (the A operand of the next GEMM)
-// WGM x WGN wavefronts: 2 x 4 (wave tile 64 x 64 at 128 x 256, two wavefronts per SIMD) or 2 x 2 (wave tile 64 x 128, ONE wavefront per
-// SIMD with the whole register file: 12 fragment reads per 24 MFMAs instead of 8 per 12 -- a quarter fewer LDS bytes per flop)
+// WGM x WGN wavefronts: 2 x 4 (wave tile 64 x 64 at 128 x 256, two wavefronts per SIMD).  The 2 x 2 grid (wave tile 64 x 128, ONE
+// wavefront per SIMD with the whole register file, 256 VGPRs + 256 AGPRs: 12 fragment reads per 24 MFMAs instead of 8 per 12, a
+// quarter fewer LDS bytes per flop) instantiates from the same template and was measured in round 5: bit-identical and 6-19 %
+// SLOWER (c_attn 389 vs 367 us, c_fc 568 vs 513, K 2048 484 vs 448 on the stand-alone probe): with one wavefront per SIMD nothing
+// runs under its barrier, its fragment waits and its epilogue.  Not launched.
 template <int BM, int BN, int EPI, bool OUT_LINES, int WGM = 2, int WGN = 4>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kernel(const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Bp,
                                                           float* __restrict__ Cg, const float* __restrict__ biasg,
@@ -356,11 +359,7 @@ static int launch_h2p(const S3Args& a, const unsigned short* a_lines, bool out_l
     ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
     H2PShape sh;
     sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.ldc = a.ldc; sh.ldr = a.ldr;
-    static int w4 = -1;                                               // R4D_GEMM_H2P_W4=1: the 2 x 2 wave grid (one wavefront per SIMD) at 128 x 256
-    if (w4 < 0) { const char* e = getenv("R4D_GEMM_H2P_W4"); w4 = e ? atoi(e) : 0; }
-#define H2P_LAUNCH_(E, OL)                                                                         \
-    if (BN == 256 && w4) hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL, 2, (BN == 256 ? 2 : 4)>), dim3(tiles), dim3(64 * 2 * (BN == 256 ? 2 : 4)), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh); \
-    else hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL>), dim3(tiles), dim3(512), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh)
+#define H2P_LAUNCH_(E, OL) hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL>), dim3(tiles), dim3(512), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh)
     if (out_lines) {
         if (a.epilogue != EPI_GELU) { set_error("gemm_h2p: line output exists for the GELU epilogue only"); return R4D_ERR_INVALID; }
         H2P_LAUNCH_(EPI_GELU, true);
