@@ -59,8 +59,12 @@ def child():
         elif epi == "residual":
             ref = ref + r[:rows].double()
         out = {}
-        for name, fn in (("h2", lambda: ops.conv1d_h2(x, planes2, b, epi, r)), ("s3", lambda: ops.conv1d_s3(x, planes, b, epi, r)),
+        lines = ops.split2_lines(x) if K % 32 == 0 else None          # A as f16x2 lines: the LDS-DMA form (gemm_h2p.hip), same bits as "h2"
+        for name, fn in (("h2p", (lambda: ops.conv1d_h2p(lines, planes2, b, epi, r)) if lines is not None else None),
+                         ("h2", lambda: ops.conv1d_h2(x, planes2, b, epi, r)), ("s3", lambda: ops.conv1d_s3(x, planes, b, epi, r)),
                          ("f32", lambda: ops.conv1d(x, w, b, epi, r, wt))):
+            if fn is None:
+                continue
             y = fn()
             d = (y[:rows].double() - ref).abs()
             out[name + "_maxnorm"] = float(d.max() / ref.abs().max())
