@@ -337,6 +337,27 @@ class GPT2Model(_PreTrained):
                               p(head) if head is not None and head.data_ptr() != self.wte.weight.data_ptr() else None)
         return c, w, layers
 
+    def _range_guarded(self, device, what, thunk):
+        """Run ``thunk()`` (one or more ``encode*`` calls) under the range guard (``include/r4d.h``, ABI v6): ONE read of the device
+        word afterwards; a non-finite hidden state in gemm mode "f16x2" (an activation beyond fp16's exponent range) re-runs the thunk
+        once under "bf16x3" with a RuntimeWarning, and ``R4DError`` if it comes up again or in any other mode."""
+        ops.range_flag(device).zero_()
+        out = thunk()
+        flag = ops.take_range_flag()
+        if flag & ops.RANGE_NONFINITE_HIDDEN and ops.gemm_mode() == "f16x2":
+            import warnings
+            warnings.warn(f"rag4dyg_amd: an activation left the fp16 range of the f16x2 arithmetic (non-finite hidden state); "
+                          f"re-running {what} with the bf16x3 GEMMs", RuntimeWarning, stacklevel=3)
+            ops.set_gemm_mode("bf16x3")
+            try:
+                out = thunk()
+                flag = ops.take_range_flag()
+            finally:
+                ops.set_gemm_mode("f16x2")
+        if flag & ops.RANGE_NONFINITE_HIDDEN:
+            raise _lib.R4DError(f"{what}: a non-finite hidden state reached ln_f (weights or inputs overflow fp32 itself, or hold NaN)")
+        return out
+
     @torch.no_grad()
     def encode(self, input_ids=None, inputs_embeds=None, want_hidden=True, want_meanpool=False, want_layers=False,
                want_qkv=False):
@@ -384,7 +405,8 @@ class GPT2Model(_PreTrained):
     def prefill(self, kv_cache, input_ids=None, inputs_embeds=None):
         """Full forward over a right-padded batch [B,T] that also fills rows [0,T) of ``kv_cache`` (the K / V columns of
         every layer's c_attn output -- the model's ``presents``, ``modeling_gpt2.py:187``).  Returns hidden [B,T,d]."""
-        r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_qkv=True)
+        src = input_ids if input_ids is not None else inputs_embeds
+        r = self._range_guarded(src.device, "prefill", lambda: self.encode(input_ids, inputs_embeds, want_hidden=True, want_qkv=True))
         d = self.config.n_embd
         T = r["qkv"].shape[2]
         if T > kv_cache.shape[2] or r["qkv"].shape[1] != kv_cache.shape[1]:
@@ -477,7 +499,9 @@ class GPT2Model(_PreTrained):
         groups = self.length_buckets(list(lens), max_buckets)
         idxs = [torch.tensor(g, dtype=torch.long, device=dev) for g in groups]
         tbs = [max(lens[i] for i in g) for g in groups]
-        r = self.encode_groups([src[ix, :tb] for ix, tb in zip(idxs, tbs)], embeds=input_ids is None, want_qkv=True)
+        # (range-guarded: the greedy loops take an argmax of whatever the logits hold -- a NaN prefill must not become token ids)
+        r = self._range_guarded(dev, "prefill_last", lambda: self.encode_groups([src[ix, :tb] for ix, tb in zip(idxs, tbs)],
+                                                                               embeds=input_ids is None, want_qkv=True))
         last_rows = [0] * B
         for g, ix, tb, r0 in zip(groups, idxs, tbs, r["row0"]):
             kv_cache[:, ix, :tb] = r["qkv"][:, r0:r0 + len(g) * tb, d:].view(-1, len(g), tb, 2 * d)
@@ -571,26 +595,11 @@ class GPT2Model(_PreTrained):
                 raise NotImplementedError(f"{name} is never passed on the encode-and-retrieve path "
                                           "(train_retriever.py:419,430; utils/model.py:222) and is not built")
         src = input_ids if input_ids is not None else inputs_embeds
-        if src is not None and src.is_cuda:
-            ops.range_flag(src.device).zero_()
-        r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states,
-                        want_qkv=self.output_past)
-        # range guard (include/r4d.h, ABI v6): the reference-shaped call hands tensors to arbitrary code, so it reads the word
-        # itself -- one f16x2 -> bf16x3 re-run with a warning, then R4DError; NaN hidden states are never returned
-        flag = ops.take_range_flag()
-        if flag & ops.RANGE_NONFINITE_HIDDEN and ops.gemm_mode() == "f16x2":
-            import warnings
-            warnings.warn("rag4dyg_amd: an activation left the fp16 range of the f16x2 arithmetic (non-finite hidden state); "
-                          "re-running this forward with the bf16x3 GEMMs", RuntimeWarning, stacklevel=2)
-            ops.set_gemm_mode("bf16x3")
-            try:
-                r = self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states,
-                                want_qkv=self.output_past)
-                flag = ops.take_range_flag()
-            finally:
-                ops.set_gemm_mode("f16x2")
-        if flag & ops.RANGE_NONFINITE_HIDDEN:
-            raise _lib.R4DError("forward: a non-finite hidden state reached ln_f (weights or inputs overflow fp32 itself, or hold NaN)")
+
+        def run():
+            return self.encode(input_ids, inputs_embeds, want_hidden=True, want_layers=self.output_hidden_states, want_qkv=self.output_past)
+        # range guard (include/r4d.h, ABI v6): the reference-shaped call hands tensors to arbitrary code, so it reads the word itself
+        r = self._range_guarded(src.device, "forward", run) if (src is not None and src.is_cuda) else run()
         outputs = (r["hidden"],)
         if self.output_past:
             outputs = outputs + (self._presents(r["qkv"]),)
