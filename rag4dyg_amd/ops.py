@@ -331,9 +331,19 @@ def normalize_rows(x):
     return out
 
 
+SCORE_TOPK_MAX_QUERIES = 65535      # queries per library call (a grid dimension); more are handed over in chunks
+
+
 def score_topk(q_hat, pool_hat, k, index_offset=0, want_scores=False):
-    """(S+1)/2 cosine scan of one pool shard + canonical top-k.  Returns (vals [Q,k], idx int64 [Q,k], scores|None)."""
+    """(S+1)/2 cosine scan of one pool shard + canonical top-k.  Returns (vals [Q,k], idx int64 [Q,k], scores|None).
+    Any number of queries: beyond ``SCORE_TOPK_MAX_QUERIES`` the call is made in chunks (a score does not depend on how the queries
+    are batched into calls, so the result is the one call's)."""
     Q, d = q_hat.shape
+    if Q > SCORE_TOPK_MAX_QUERIES:
+        parts = [score_topk(q_hat[s:s + SCORE_TOPK_MAX_QUERIES].contiguous(), pool_hat, k, index_offset, want_scores)
+                 for s in range(0, Q, SCORE_TOPK_MAX_QUERIES)]
+        return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
+                torch.cat([p[2] for p in parts]) if want_scores else None)
     N = pool_hat.shape[0]
     lib = _lib.load()
     ws = workspace(lib.r4d_score_topk_workspace_bytes(Q, N, k), q_hat.device, "score")

@@ -1062,3 +1062,16 @@ def test_encoder_with_presplit_activations_equals_register_staged_path(dev, L, H
     finally:
         ops.set_gemm_h2p(True)
         ops.set_gemm_mode(was)
+
+
+def test_score_topk_any_number_of_queries(dev, monkeypatch):
+    """``ops.score_topk`` hands more than ``SCORE_TOPK_MAX_QUERIES`` queries to the library in chunks (the limit is a grid dimension,
+    65,535; lowered here so that the test stays small): values, indices and scores identical to one call."""
+    from rag4dyg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    q = ops.normalize_rows(torch.randn(300, 256, generator=g).to(dev))
+    p = ops.normalize_rows(torch.randn(5000, 256, generator=g).to(dev))
+    v1, i1, s1 = ops.score_topk(q, p, 7, 100, want_scores=True)
+    monkeypatch.setattr(ops, "SCORE_TOPK_MAX_QUERIES", 128)
+    v2, i2, s2 = ops.score_topk(q, p, 7, 100, want_scores=True)
+    assert torch.equal(v1, v2) and torch.equal(i1, i2) and torch.equal(s1, s2)
