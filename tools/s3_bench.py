@@ -37,7 +37,12 @@ def child():
         planes = ops.split3_planes(w)
         planes2 = ops.split2_planes(w)
         if os.environ.get("S3_TIME_ONLY"):                     # ablated builds (tools/kc_ablate.sh gemm_s3.hip S3_DBG n): timing only
-            fn = (lambda: ops.conv1d_h2(x, planes2, b, epi, r)) if os.environ.get("S3_BENCH_KIND") == "h2" else (lambda: ops.conv1d_s3(x, planes, b, epi, r))
+            kind = os.environ.get("S3_BENCH_KIND")
+            if kind == "h2p":
+                lines_ = ops.split2_lines(x)
+                fn = lambda: ops.conv1d_h2p(lines_, planes2, b, epi, r, out_lines=(epi == "gelu"))      # as the encoder launches it
+            else:
+                fn = (lambda: ops.conv1d_h2(x, planes2, b, epi, r)) if kind == "h2" else (lambda: ops.conv1d_s3(x, planes, b, epi, r))
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
