@@ -906,7 +906,7 @@ def g12_real_wikiv2_reddit():
 # --------------------------------------------------------------------------- G13
 def g13_h2_attention_stress():
     """Reference-held vectors with HARD statistics at the head dims ``csrc/attention_h2.hip`` serves (G11 is
-    head_dim 64 and routes to the exact-f32 kernel).  Four cases, each the reference model on the real UCI_13/12 ids (first 256
+    head_dim 64 and routed to the exact-f32 kernel then).  Seven cases (the last three for the key-split kernel of head_dim 32 / 64 / 96), each the reference model on the real UCI_13/12 ids (first 256
     pool histories = 8 reference batches, all 110 test queries), as g10 does:
       hd128_plain    the TRAINED G10 tensors loaded with n_head = 1 (one head of 128);
       hd128_stress   the same after ``gpt2_ref.stress_transform`` (G11's transform);
@@ -933,9 +933,15 @@ def g13_h2_attention_stress():
             ch = [torch.tensor(e, dtype=torch.long) for e in examples[s:s + 32]]
             yield torch.nn.utils.rnn.pad_sequence(ch, batch_first=True, padding_value=pad)
     seeded = gpt2_ref.make_state_dict(2, 512, 1801, seed=2031, random_affine=True)
+    seeded96 = gpt2_ref.make_state_dict(2, 768, 1801, seed=2032, random_affine=True)
     cases = {"hd128_plain": (trained, 1), "hd128_stress": (gpt2_ref.stress_transform(trained), 1),
              "hd128_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(trained), 4.0), 1),
-             "hd256_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(seeded), 6.0), 2)}
+             "hd256_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(seeded), 6.0), 2),
+             # (later in round 5: the key-split f16x2 kernel's head dims -- the trained tensors as 2 heads of 64 and 4 heads of 32, and a
+             #  seeded L2 H8 d768 model = head_dim 96, the SimpleDyG UCI_13 shape -- appended: the earlier cases keep their values)
+             "hd64_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(trained), 4.0), 2),
+             "hd32_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(trained), 4.0), 4),
+             "hd96_peaked": (gpt2_ref.sharpen_attention(gpt2_ref.stress_transform(seeded96), 6.0), 8)}
     out = {}
     for tag, (sd, H) in cases.items():
         V, d = sd["transformer.wte.weight"].shape
@@ -967,7 +973,7 @@ def g13_h2_attention_stress():
                     f"{tag}:weight_checksums": sig, f"{tag}:attn_rowmax_median_p90": peak})
         print(f"    {tag}: L{L} H{H} d{d} -> head_dim {d // H}; attention row-max median / p90 per layer {peak.round(3).tolist()}; "
               f"query emb absmax {float(qe.abs().max()):.3f}; score range {float(S.min()):.4f} .. {float(S.max()):.4f}")
-    _save("g13_h2_attention_stress", seed_hd256=np.array(2031), pool_rows=np.array(256), **out)
+    _save("g13_h2_attention_stress", seed_hd256=np.array(2031), seed_hd96=np.array(2032), pool_rows=np.array(256), **out)
 
 
 def main():

@@ -106,16 +106,18 @@ def g13_state_dict(case, g=None):
     import torch
     from oracle import gpt2_ref
     g = g if g is not None else load_golden("g13_h2_attention_stress")
-    if case.startswith("hd128"):
+    if case.startswith(("hd128", "hd64", "hd32")):
         gw = load_golden("g10_trained_small")
         sd = {n[2:]: torch.from_numpy(gw[n]) for n in gw.files if n.startswith("w:")}
         sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    elif case.startswith("hd96"):
+        sd = gpt2_ref.make_state_dict(2, 768, 1801, seed=int(g["seed_hd96"]), random_affine=True)
     else:
         sd = gpt2_ref.make_state_dict(2, 512, 1801, seed=int(g["seed_hd256"]), random_affine=True)
     if case != "hd128_plain":
         sd = gpt2_ref.stress_transform(sd)
     if case.endswith("peaked"):
-        sd = gpt2_ref.sharpen_attention(sd, 4.0 if case.startswith("hd128") else 6.0)
+        sd = gpt2_ref.sharpen_attention(sd, 6.0 if case.startswith(("hd256", "hd96")) else 4.0)
     assert np.array_equal(gpt2_ref.weight_bit_checksums(sd), g[case + ":weight_checksums"]), \
         f"G13 {case}: the transforms no longer produce the fixture's weights"
     L, H, d, V, n_pos = (int(x) for x in g[case + ":cfg"])
