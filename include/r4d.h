@@ -402,6 +402,20 @@ int r4d_jaccard_ordered_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int3
                             const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz,
                             int32_t vocab, int32_t zero_diag, const int32_t* a_order_d,
                             const uint32_t* a_dense_d, const uint32_t* b_dense_d, double* out_d, void* stream);
+/* The same matrix with the schedule PREPARED ON THE DEVICE (round 5): the caller hands over the plain CSR sets and says
+ * which of the two schedule aids it wants; nothing is computed on the host and no torch op runs.
+ *   dense_split != 0: the 32 most frequent tokens -- counted over a strided sample of at most 2 x 512 sets, ties to the
+ *     smaller token id -- leave the lists for one membership word per set (the a_dense_d / b_dense_d of the entry above);
+ *     the remaining tokens are squeezed to the front of each set's own segment in a workspace copy of idx.
+ *   sort_rows != 0: the A rows are visited longest (remaining) list first (a_order_d above; ties in no particular order).
+ * Neither changes a value: out_d holds the bits r4d_jaccard_f64 writes.  The sets hold DISTINCT tokens (as
+ * get_input_seq / get_target_seq build them, retrieval_data_annotation.py:17-34).  workspace_d from
+ * r4d_jaccard_prepared_workspace_bytes (may be NULL when both flags are 0). */
+size_t r4d_jaccard_prepared_workspace_bytes(int32_t na, int32_t a_nnz, int32_t nb, int32_t b_nnz, int32_t vocab);
+int r4d_jaccard_prepared_f64(const int32_t* a_ptr_d, const int32_t* a_idx_d, int32_t na, int32_t a_nnz,
+                             const int32_t* b_ptr_d, const int32_t* b_idx_d, int32_t nb, int32_t b_nnz,
+                             int32_t vocab, int32_t zero_diag, int32_t dense_split, int32_t sort_rows,
+                             double* out_d, void* workspace_d, size_t workspace_bytes, void* stream);
 /* Per-row top-k (value descending, index ascending) of an f64 matrix: save_score_file_train,
  * retrieval_data_annotation.py:97-103 (topk=10).  ws from r4d_topk_f64_workspace_bytes. */
 size_t r4d_topk_f64_workspace_bytes(int32_t rows, int32_t n, int32_t k);

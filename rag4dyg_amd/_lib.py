@@ -113,6 +113,9 @@ PROTOTYPES = {
     "r4d_argsort_desc_f64": (c_int32, [_P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "r4d_jaccard_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_jaccard_ordered_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "r4d_jaccard_prepared_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "r4d_jaccard_prepared_f64": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                           c_size_t, _P]),
     "r4d_topk_f64_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "r4d_topk_f64": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "r4d_gpt2_train_workspace_bytes": (c_size_t, [POINTER(GPT2ConfigC), c_int32, POINTER(c_int32), POINTER(c_int32)]),

@@ -43,7 +43,7 @@ enum ProfClass {
     PK_GEMM_128x128_NN = 0, PK_GEMM_128x128_NT, PK_GEMM_128x64_NN, PK_GEMM_128x64_NT, PK_GEMM_64x64_NN,
     PK_GEMM_64x64_NT, PK_GEMM_KC_128x128x32, PK_GEMM_KC_128x128x16, PK_GEMM_KC_128x64x16, PK_GEMM_KC_64x64x32, PK_GEMM_S3_128x256, PK_GEMM_S3_128x128, PK_GEMM_S3TN, PK_GEMM_H2_128x256, PK_GEMM_H2_128x128, PK_GEMM_SKINNY, PK_GEMM_SKINNY_EPI,
     PK_EMBED_LN, PK_LAYERNORM, PK_SOFTMAX, PK_DECODE_ATTN, PK_GREEDY_ADVANCE,
-    PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_COUNT
+    PK_ATTN_FUSED, PK_LNF_MEANPOOL, PK_MEANPOOL_REDUCE, PK_NORMALIZE, PK_POOL_SCAN, PK_TOPK, PK_MERGE_TOPK, PK_RANK_COUNT, PK_JACCARD, PK_JACCARD_PREP, PK_COUNT
 };
 extern bool g_prof_on;
 void prof_begin_impl(int cls, double work, hipStream_t s);
@@ -81,6 +81,7 @@ struct ProfScope {
     X(LNF_8, "lnf_meanpool:<8>") X(LNF_16, "lnf_meanpool:<16>") X(LNF_32, "lnf_meanpool:<32>")                             \
     X(DEC_ATT_32, "decode_attention:<32>") X(DEC_ATT_64, "decode_attention:<64>")                                         \
     X(JAC_LDS, "jaccard:LDS table") X(JAC_MERGE, "jaccard:merge walk (vocab too large for LDS)")                          \
+    X(JAC_PREP_DENSE_LDS, "jaccard_prep:dense tokens, LDS histogram") X(JAC_PREP_DENSE_GLOBAL, "jaccard_prep:dense tokens, global histogram") X(JAC_PREP_ORDER, "jaccard_prep:rows longest first") \
     X(ARGSORT_ONE, "argsort:one chunk") X(ARGSORT_MULTI, "argsort:chunk sort + rank scatter")
 enum DispatchBranch {
 #define X(id, name) BR_##id,

@@ -28,7 +28,7 @@ static const char* kNames[PK_COUNT] = {
     "gemm_f32_128x128_nn", "gemm_f32_128x128_nt", "gemm_f32_128x64_nn",
     "gemm_f32_128x64_nt", "gemm_f32_64x64_nn", "gemm_f32_64x64_nt", "gemm_f32_kc_128x128x32", "gemm_f32_kc_128x128x16",
     "gemm_f32_kc_128x64x16", "gemm_f32_kc_64x64x32", "gemm_s3_128x256x32", "gemm_s3_128x128x32", "gemm_s3tn_128x256x32", "gemm_h2_128x256x32", "gemm_h2_128x128x32", "gemm_skinny", "gemm_skinny_epilogue", "embed_layernorm",
-    "layernorm", "causal_softmax", "decode_attention", "greedy_advance", "attn_fused", "lnf_partial", "meanpool_reduce", "normalize_rows", "pool_scan", "topk", "merge_topk", "argsort", "jaccard"};
+    "layernorm", "causal_softmax", "decode_attention", "greedy_advance", "attn_fused", "lnf_partial", "meanpool_reduce", "normalize_rows", "pool_scan", "topk", "merge_topk", "argsort", "jaccard", "jaccard_prep"};
 
 unsigned long long g_branch_hits[BR_COUNT];
 static const char* kBranchNames[BR_COUNT] = {

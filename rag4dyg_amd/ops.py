@@ -398,50 +398,12 @@ def argsort_desc(scores):
     return perm
 
 
-def _row_of_elements(ptr, nnz):
-    n = ptr.numel() - 1
-    return torch.repeat_interleave(torch.arange(n, device=ptr.device), (ptr[1:] - ptr[:-1]).long(), output_size=nnz)
-
-
-def dense_token_split(a_ptr, a_idx, b_ptr, b_idx, vocab, n_dense=32):
-    """Move the ``n_dense`` (<= 32) most frequent tokens of the two CSR set families out of the lists into one 32-bit
-    membership word per set (``r4d_jaccard_ordered_f64``'s a_dense / b_dense): the <|timeK|> tokens that get_input_seq keeps
-    (retrieval_data_annotation.py:17-20) sit in most input sets and would otherwise dominate the kernel's token walk.
-    Index bookkeeping only (torch ops on the device).  Returns ((a_ptr, a_idx, a_dense), (b_ptr, b_idx, b_dense))."""
-    dev = a_ptr.device
-    na_nnz, nb_nnz = int(a_ptr[-1].item()), int(b_ptr[-1].item())
-    ai, bi = a_idx[:na_nnz].long(), b_idx[:nb_nnz].long()
-    cnt = torch.bincount(ai, minlength=vocab) + torch.bincount(bi, minlength=vocab)
-    top = torch.topk(cnt, min(n_dense, vocab)).indices
-    top = top[cnt[top] > 0]
-    rank = torch.full((vocab,), -1, dtype=torch.int64, device=dev)
-    rank[top] = torch.arange(top.numel(), device=dev)
-
-    def split(ptr, idx, nnz):
-        n = ptr.numel() - 1
-        rows = _row_of_elements(ptr, nnz)
-        r = rank[idx]
-        dense = r >= 0
-        word = torch.zeros(n, dtype=torch.int64, device=dev)
-        word.index_add_(0, rows[dense], torch.ones_like(r[dense]) << r[dense])        # tokens are unique per set: sum == OR
-        keep = ~dense
-        counts = torch.zeros(n, dtype=torch.int64, device=dev)
-        counts.index_add_(0, rows[keep], torch.ones_like(rows[keep]))
-        new_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-        new_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        new_idx = idx[keep].to(torch.int32)
-        if new_idx.numel() == 0:
-            new_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-        return new_ptr.contiguous(), new_idx.contiguous(), word.to(torch.int32).contiguous()     # low 32 bits, wrapped
-
-    return split(a_ptr, ai, na_nnz), split(b_ptr, bi, nb_nnz)
-
-
 def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False, sort_rows=None, dense_split=None):
     """f64 [na,nb] Jaccard matrix of CSR sets (occurrence_matrix, retrieval_data_annotation.py:36-41).
-    ``dense_split``: the 32 most frequent tokens leave the lists for a per-set membership word (``dense_token_split``) --
-    same values, 2-3x fewer token steps on the input sets (ego + <|timeK|> + neighbours).  ``sort_rows``: the kernel visits
-    the A rows longest set first (``r4d_jaccard_ordered_f64``) -- same values, fewer padded token steps.
+    ``dense_split``: the 32 most frequent tokens leave the lists for a per-set membership word -- same values, 2-3x fewer token
+    steps on the input sets (ego + <|timeK|> + neighbours).  ``sort_rows``: the kernel visits the A rows longest set first --
+    same values, fewer padded token steps.  Both are prepared ON THE DEVICE by ``r4d_jaccard_prepared_f64`` (three small HIP
+    launches; until round 5 a dozen torch index ops that cost more GPU time than the kernel).
     Defaults: both only where they pay (sets averaging more than 4 tokens and >= 5*10^6 / 5*10^7 pairs; the 1.8-token output
     sets are bound by the division and the store: the extra lookups cost more than they save)."""
     na, nb = a_ptr.numel() - 1, b_ptr.numel() - 1
@@ -450,26 +412,21 @@ def jaccard(a_ptr, a_idx, b_ptr, b_idx, vocab, zero_diag=False, sort_rows=None, 
         a_idx = torch.zeros(1, dtype=torch.int32, device=a_ptr.device)
     if b_idx.numel() == 0:
         b_idx = torch.zeros(1, dtype=torch.int32, device=b_ptr.device)
-    _dev(a_ptr, torch.int32, "a_ptr"); _dev(a_idx, torch.int32, "a_idx"); _dev(b_ptr, torch.int32, "b_ptr"); _dev(b_idx, torch.int32, "b_idx")
     long_sets = a_idx.numel() > 4 * na
     if dense_split is None:
         dense_split = long_sets and na * nb >= 5_000_000
-    a_dense = b_dense = None
-    if dense_split and na > 0 and nb > 0:
-        (a_ptr, a_idx, a_dense), (b_ptr, b_idx, b_dense) = dense_token_split(a_ptr, a_idx, b_ptr, b_idx, int(vocab))
-    order = None
     if sort_rows is None:
-        sort_rows = long_sets and na * nb >= 50_000_000      # small problems: the argsort costs what it saves
-    if sort_rows and na > 1:
-        order = torch.argsort(a_ptr[1:] - a_ptr[:-1], descending=True, stable=True).to(torch.int32)
-    check(_lib.load().r4d_jaccard_ordered_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na,
-                                              a_idx.numel(), _dev(b_ptr, torch.int32, "b_ptr"),
-                                              _dev(b_idx, torch.int32, "b_idx"), nb, b_idx.numel(),
-                                              int(vocab), int(bool(zero_diag)),
-                                              order.data_ptr() if order is not None else None,
-                                              a_dense.data_ptr() if a_dense is not None else None,
-                                              b_dense.data_ptr() if b_dense is not None else None, out.data_ptr(), _stream()),
-          "jaccard")
+        sort_rows = long_sets and na * nb >= 50_000_000      # small problems: the ordering costs what it saves
+    lib = _lib.load()
+    ws = None
+    if dense_split or sort_rows:
+        ws = workspace(lib.r4d_jaccard_prepared_workspace_bytes(na, a_idx.numel(), nb, b_idx.numel(), int(vocab)), a_ptr.device,
+                       "jaccard")
+    check(lib.r4d_jaccard_prepared_f64(_dev(a_ptr, torch.int32, "a_ptr"), _dev(a_idx, torch.int32, "a_idx"), na, a_idx.numel(),
+                                       _dev(b_ptr, torch.int32, "b_ptr"), _dev(b_idx, torch.int32, "b_idx"), nb, b_idx.numel(),
+                                       int(vocab), int(bool(zero_diag)), int(bool(dense_split)), int(bool(sort_rows)),
+                                       out.data_ptr(), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                       _stream()), "jaccard")
     return out
 
 

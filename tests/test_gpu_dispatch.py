@@ -166,9 +166,10 @@ def test_every_dispatcher_branch_is_exercised(dev):
         S = torch.rand(2, n, generator=g).to(dev)
         assert np.array_equal(ops.argsort_desc(S).cpu().numpy(), np.argsort(-S.cpu().numpy(), axis=1, kind="stable"))
 
-    # ---- Jaccard: LDS token table / merge walk (vocabulary too large for LDS)
+    # ---- Jaccard: LDS token table / merge walk (vocabulary too large for LDS); device-side preparation: dense tokens counted
+    # in LDS / in global memory (vocabulary beyond 36,864), rows longest first
     rng = np.random.default_rng(3)
-    for vocab in (200, 30000):
+    for vocab in (200, 30000, 40000):
         sets = [sorted(set(rng.integers(0, vocab, rng.integers(0, 9)).tolist())) for _ in range(70)]
         ptr = np.zeros(71, np.int32)
         ptr[1:] = np.cumsum([len(s) for s in sets])
@@ -176,6 +177,9 @@ def test_every_dispatcher_branch_is_exercised(dev):
         out = ops.jaccard(torch.from_numpy(ptr).to(dev), torch.from_numpy(ix).to(dev), torch.from_numpy(ptr).to(dev),
                           torch.from_numpy(ix).to(dev), vocab).cpu().numpy()
         ref = np.array([[len(set(a) & set(b)) / len(set(a) | set(b)) if a and b else 0.0 for b in sets] for a in sets])
+        assert np.array_equal(out, ref), vocab
+        out = ops.jaccard(torch.from_numpy(ptr).to(dev), torch.from_numpy(ix).to(dev), torch.from_numpy(ptr).to(dev),
+                          torch.from_numpy(ix).to(dev), vocab, dense_split=True, sort_rows=True).cpu().numpy()
         assert np.array_equal(out, ref), vocab
 
     ops.set_gemm_mode(mode_before)

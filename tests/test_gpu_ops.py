@@ -904,9 +904,47 @@ def test_jaccard_edge_cases_and_merge_fallback(dev):
     for dn in (False, True):
         got = ops.jaccard(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), vocab, zero_diag=True, dense_split=dn, sort_rows=dn)
         assert np.array_equal(got.cpu().numpy(), ref), dn
-    (ap2, ai2, ad), _ = ops.dense_token_split(cu(ptr, dev), cu(idx, dev), cu(ptr, dev), cu(idx, dev), vocab)
-    words = ad.cpu().numpy().view(np.uint32)
-    assert all(bin(int(w)).count("1") + int(ap2[i + 1] - ap2[i]) == len(sets[i]) for i, w in enumerate(words))   # nothing lost
+
+
+def test_jaccard_device_side_preparation_never_changes_a_value(dev):
+    """``r4d_jaccard_prepared_f64`` (round 5): the dense-token pick (sampled LDS / global histogram, 32 argmax rounds), the in-place
+    squeeze of the lists and the longest-first visiting order are schedule aids -- every combination must give the bits of the
+    plain kernel, which the test above pins to the oracle.  Cases: more sets than the sample takes (stride 3), a vocabulary beyond
+    the LDS histogram (global counts, merge walk), fewer than 32 distinct tokens, sets that are entirely dense / empty, lists of
+    more than 1,023 sparse tokens (the order kernel's last bin), A != B."""
+    from rag4dyg_amd import ops
+    from oracle import jaccard_ref
+    rng = np.random.default_rng(11)
+
+    def csr(sets):
+        ptr = np.zeros(len(sets) + 1, np.int32); ptr[1:] = np.cumsum([len(s_) for s_ in sets])
+        return ptr, np.asarray([x for s_ in sets for x in s_] or [0], np.int32)
+
+    def input_like(n, vocab, n_time=12, max_sparse=7):
+        return [sorted(set(rng.choice(n_time, rng.integers(0, n_time + 1), replace=False).tolist()
+                           + rng.integers(n_time, vocab, rng.integers(0, max_sparse)).tolist())) for _ in range(n)]
+
+    cases = {"sampled": (input_like(5000, 400), input_like(300, 400), 400),
+             "global_hist": (input_like(200, 40000), input_like(333, 40000), 40000),
+             "few_tokens": ([sorted(set(rng.integers(0, 10, rng.integers(0, 6)).tolist())) for _ in range(150)],) * 2 + (10,),
+             "long_lists": ([sorted(rng.choice(3000, int(k), replace=False).tolist()) for k in (1500, 0, 1023, 1024, 5, 2900, 64, 65)] * 9,
+                            input_like(100, 3000, 40, 30), 3000)}
+    cases["sampled"][0][3] = list(range(12)); cases["sampled"][0][4] = []
+    for name, (sa, sb, vocab) in cases.items():
+        (ap, ai), (bp, bi) = csr(sa), csr(sb)
+        same = sa is sb
+        plain = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(bp, dev), cu(bi, dev), vocab, zero_diag=same, dense_split=False, sort_rows=False)
+        rows = slice(0, 40)
+        _, _, ref = jaccard_ref.jaccard_csr(*csr(sa[rows]), bp, bi)
+        got40 = plain[rows].cpu().numpy().copy()
+        if same:
+            ref[np.arange(40), np.arange(40)] = 0.0
+        assert np.array_equal(got40, ref), name
+        for dn, sr in ((True, False), (False, True), (True, True)):
+            got = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(bp, dev), cu(bi, dev), vocab, zero_diag=same, dense_split=dn, sort_rows=sr)
+            assert torch.equal(got.view(torch.int64), plain.view(torch.int64)), (name, dn, sr)
+        again = ops.jaccard(cu(ap, dev), cu(ai, dev), cu(bp, dev), cu(bi, dev), vocab, zero_diag=same, dense_split=True, sort_rows=True)
+        assert torch.equal(again.view(torch.int64), plain.view(torch.int64)), name
 
 
 def test_jaccard_every_small_quotient_is_correctly_rounded(dev):

@@ -120,7 +120,9 @@ def jaccard():
         na, nb = t[a + "_ptr"].numel() - 1, t[b + "_ptr"].numel() - 1
         wall, pr = profile(lambda: ops.jaccard(t[a + "_ptr"], t[a + "_idx"], t[b + "_ptr"], t[b + "_idx"], vocab, zd), 20)
         j = pr["jaccard"]
+        prep = pr.get("jaccard_prep")
         emit(component="jaccard", case=name, pairs=na * nb, kernel_us=round(j["us"], 2), pairs_per_s=round(na * nb / (j["us"] * 1e-6)),
+             prep_us=round(prep["us"], 2) if prep else 0.0, call_wall_us=round(wall * 1e6, 1),
              roofline={"bound": "hbm", "achieved": round(j["gbs"], 1), "peak": PEAK, "unit": "GB/s", "frac": round(j["gbs"] / PEAK, 4)})
     # CPU baseline: the reference's single-thread double loop on a bounded sample of the same sets
     lists = [g["tr_out_idx"][g["tr_out_ptr"][i]:g["tr_out_ptr"][i + 1]].tolist() for i in range(len(g["tr_out_ptr"]) - 1)]
@@ -136,8 +138,10 @@ def jaccard():
         P, I = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
         wall, pr = profile(lambda: ops.jaccard(P, I, P, I, sh.v0, True), 5)
         j = pr["jaccard"]
+        prep = pr.get("jaccard_prep")
         emit(component="jaccard", case=f"synthetic 20000 x 20000 {kind} (mean size {idx.size / 20000:.1f})", pairs=4e8,
              kernel_us=round(j["us"], 1), pairs_per_s=round(4e8 / (j["us"] * 1e-6)),
+             prep_us=round(prep["us"], 2) if prep else 0.0, call_wall_us=round(wall * 1e6, 1),
              roofline={"bound": "hbm", "achieved": round(j["gbs"], 1), "peak": PEAK, "unit": "GB/s", "frac": round(j["gbs"] / PEAK, 4)})
 
 
