@@ -36,7 +36,8 @@ int launch_transpose(const float* in, int rows, int cols, long long ld_in, long 
                      long long stride_out, int nbatch, hipStream_t s);
 int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int d, int vocab, unsigned long long* acc_wte, float* dwpe,
                          int first_group, long long table_rows, hipStream_t s);
-int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, float* out, hipStream_t s);
+int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, long long table_rows, float* out, hipStream_t s);
+int launch_embedding_absmax(const float* dx, long long n, unsigned long long* acc_wte, long long table_elems, hipStream_t s);
 int launch_meanpool_bwd(const float* d_pool, long long rows, int T, int d, float* dh, hipStream_t s);
 
 static inline int tpad128(int T) { return (T + 127) / 128 * 128; }
@@ -92,7 +93,7 @@ static TrainLayout layout(const r4d_gpt2_config* cfg, const TrainGroup* gs, int 
     const size_t cs = colsum_scratch_floats((long long)t.M, 4 * t.d);
     if (cs > red) red = cs;
     t.red = take(red);
-    t.emb_acc = take((size_t)cfg->vocab * d * 2 + 2);   // + one 64-bit poison word behind the table
+    t.emb_acc = take((size_t)cfg->vocab * d * 2 + 4);   // + two 64-bit words behind the table: poison, max |contribution|
     t.total = off;
     return t;
 }
@@ -428,11 +429,12 @@ int r4d_gpt2_train_backward_f32(const r4d_gpt2_config* cfg, const r4d_gpt2_weigh
         return rc;
     // deterministic sums (train_ops.hip): tokens through a 64-bit fixed-point table, positions as ordered column sums
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + t.emb_acc);
-    R4D_HIP(hipMemsetAsync(acc, 0, ((size_t)cfg->vocab * d + 1) * sizeof(unsigned long long), s));       // table + poison word
+    R4D_HIP(hipMemsetAsync(acc, 0, ((size_t)cfg->vocab * d + 2) * sizeof(unsigned long long), s));       // table + poison word + max word
     R4D_HIP(hipMemsetAsync(gr->wpe, 0, (size_t)cfg->n_positions * d * sizeof(float), s));
+    if ((rc = launch_embedding_absmax(dx, (long long)M * d, acc, (long long)cfg->vocab * d, s))) return rc;      // the scale follows the data
     for (const TrainGroup& G : gs)
         if ((rc = launch_embedding_bwd(dx + G.row0 * d, G.ids, G.B, G.T, d, cfg->vocab, acc, gr->wpe, 0, (long long)M, s))) return rc;
-    return launch_embedding_fix_to_f32(acc, (long long)cfg->vocab * d, gr->wte, s);
+    return launch_embedding_fix_to_f32(acc, (long long)cfg->vocab * d, (long long)M, gr->wte, s);
 }
 
 }  // extern "C"

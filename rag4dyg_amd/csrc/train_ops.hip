@@ -216,36 +216,58 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 //   * dwpe: the rows of position t are row t of every sequence of a batch -- a plain column sum over the sequences in a fixed
 //     order, one thread per (t, column), the batches of a step one launch after the other;
 //   * dwte: which rows share a token is data dependent, so the contributions are added as 64-bit FIXED-POINT integers
-//     (value * 2^40, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
-//     same bits every time; a second kernel converts the touched table back to fp32.  Resolution 9.1e-13 (round 5: was 2^-44).
-//     A NON-FINITE contribution, or one beyond +-`max_abs`, has no fixed-point image.  `max_abs` = min(2^17, 2^22 / M) for the
-//     M token rows that add into one table (launch_embedding_bwd): at most M contributions can meet in one element, each below
-//     max_abs 2^40, so their sum stays below 2^62 and CANNOT wrap the 64 bits (round 4 bounded the term at 2^17 alone with a 2^44
-//     scale: four same-sign terms at the limit wrapped unnoticed -- ADVICE r4).  At the 30k-80k rows of a retriever step the bound
-//     is 50-140 per element (a first cut at 2^18 / M = 3-9 poisoned real steps of the UCI_13 run: temperature 0.1 puts single
-//     contributions near 10).  Such a contribution
-//     sets the POISON word behind the table and the conversion then writes NaN into the whole
-//     gradient -- a diverged step stays as loud as with float atomics (NaN gradient norm, NaN parameters after the clip)
-//     instead of turning into a finite, wrong update.  Contributions below 1e-10 lose relative precision (the
-//     resolution is absolute); the training configurations of the reference's scripts sit eight orders above that.
-constexpr double EMB_FIX = 1099511627776.0;             // 2^40
-constexpr float EMB_MAX_ABS = 131072.0f;                // 2^17
+//     (value * 2^S, round to nearest): integer addition is associative, the atomics can land in any order and the sum is the
+//     same bits every time; a second kernel converts the touched table back to fp32.
+//     THE SCALE FOLLOWS THE DATA (round 5, second form): a pre-pass takes max |dx| over the step's token rows (a maximum does not
+//     depend on the order either: same bits every run) and S = 62 - ceil(log2 M) - e with max < 2^e, M = the token rows that add
+//     into the table: every term is below 2^(62 - ceil(log2 M)), at most M of them meet in one element, so the sum stays below
+//     2^62 and CANNOT wrap -- whatever the magnitudes (a fixed 2^17 bound with a 2^44 scale let four same-sign terms
+//     wrap unnoticed).  Resolution 2^-(61 - ceil(log2 M)) of the largest contribution: 2^-44 at 131,072 rows, twenty bits below
+//     fp32's own.  (The first form of this round kept a 2^40 scale and bounded a term by 2^22 / M = 50-140, poisoning the step
+//     beyond it: correct, but a bound the reference does not have.  This form has none.)
+//     A NON-FINITE contribution has no fixed-point image: the maximum is then Inf / NaN, the POISON word behind the table is set and
+//     the conversion writes NaN into the whole gradient -- a diverged step stays as loud as with float atomics (NaN gradient norm,
+//     NaN parameters after the clip) instead of turning into a finite, wrong update.
+constexpr int EMB_SUM_BITS = 62;
+__device__ __forceinline__ int emb_scale_exp(unsigned max_bits, int lg_rows) {          // S: |g| 2^S M < 2^62 for every |g| <= max
+    const int e = (int)((max_bits >> 23) & 255u) - 126;                                  // max < 2^e (exponent field 0: a subnormal)
+    return EMB_SUM_BITS - lg_rows - e;
+}
+// max |x| as the bit pattern of a non-negative float (NaN counts as Inf); *max_bits zeroed by the caller
+__global__ __launch_bounds__(256) void embedding_absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ max_bits) {
+    unsigned m = 0u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        const unsigned b = (v <= 3.402823466e38f) ? __float_as_uint(v) : 0x7f800000u;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_bits, m);
+}
+// acc_wte: [vocab * d] sums, then the poison word, then the max word (low 32 bits)
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                                             long long rows, int d, int vocab, unsigned long long* __restrict__ acc_wte,
-                                                            float max_abs) {
+                                                            int lg_rows) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    const long long n = (long long)vocab * d;
+    const unsigned mb = (unsigned)acc_wte[n + 1];
+    if (mb >= 0x7f800000u) {                                                       // some contribution of this step is NaN / Inf
+        if (row == 0 && lane == 0) atomicOr(acc_wte + n, 1ull);
+        return;
+    }
     const long long id = ids[row];
     if (id < 0 || id >= vocab) return;
-    bool poison = false;
+    const int S = emb_scale_exp(mb, lg_rows);
     for (int c = lane; c < d; c += 64) {
-        const float g = dx[row * d + c];
-        if (!(fabsf(g) <= max_abs)) { poison = true; continue; }                  // NaN, Inf or out of range
-        const long long q = __double2ll_rn((double)g * EMB_FIX);
+        const long long q = __double2ll_rn(ldexp((double)dx[row * d + c], S));
         atomicAdd(acc_wte + id * d + c, (unsigned long long)q);
     }
-    if (__ballot(poison) != 0ull && lane == 0) atomicOr(acc_wte + (long long)vocab * d, 1ull);
 }
 // dwpe[t, c] (+)= sum over the B sequences of dx[b * T + t, c], b ascending; `first`: overwrite instead of add
 __global__ __launch_bounds__(256) void wpe_bwd_kernel(const float* __restrict__ dx, int B, int T, int d, int first, float* __restrict__ dwpe) {
@@ -255,9 +277,12 @@ __global__ __launch_bounds__(256) void wpe_bwd_kernel(const float* __restrict__ 
     for (int b = 0; b < B; ++b) s += dx[(long long)b * T * d + i];
     dwpe[i] = first ? s : dwpe[i] + s;
 }
-__global__ __launch_bounds__(256) void embedding_fix_to_f32_kernel(const unsigned long long* __restrict__ acc, long long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void embedding_fix_to_f32_kernel(const unsigned long long* __restrict__ acc, long long n, int lg_rows,
+                                                                   float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = acc[n] ? __builtin_nanf("") : (float)((double)(long long)acc[i] * (1.0 / EMB_FIX));     // acc[n]: the poison word
+    if (i >= n) return;
+    const unsigned mb = (unsigned)acc[n + 1];
+    out[i] = (acc[n] || mb >= 0x7f800000u) ? __builtin_nanf("") : (float)ldexp((double)(long long)acc[i], -emb_scale_exp(mb, lg_rows));
 }
 
 // dh[row, :] = d_pool[seq(row), :] / T   (torch.mean(h, dim=1) backward, train_retriever.py:181-183)
@@ -461,6 +486,20 @@ int launch_transpose(const float* in, int rows, int cols, long long ld_in, long 
     R4D_CHECK_LAUNCH("transpose");
     return R4D_OK;
 }
+static int emb_lg_rows(long long table_rows) {
+    int lg = 0;
+    while ((1LL << lg) < table_rows) ++lg;
+    return lg;
+}
+// once per backward call, before the batches: max |dx| over ALL token rows of the step into the max word behind the table
+// (`acc_wte` [vocab * d] + poison word + max word, zeroed by the caller)
+int launch_embedding_absmax(const float* dx, long long n, unsigned long long* acc_wte, long long table_elems, hipStream_t s) {
+    if (n <= 0) return R4D_OK;
+    const unsigned grid = (unsigned)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    hipLaunchKernelGGL(embedding_absmax_kernel, dim3(grid), dim3(256), 0, s, dx, n, reinterpret_cast<unsigned*>(acc_wte + table_elems + 1));
+    R4D_CHECK_LAUNCH("embedding_absmax");
+    return R4D_OK;
+}
 // one batch [B, T] of a step: token part into the fixed-point table `acc_wte` [vocab, d] (zeroed by the caller once per step),
 // position part into dwpe rows [0, T) (`first_group`: the step's first batch overwrites, later ones add -- in call order)
 // `table_rows`: ALL token rows that add into this table before it is converted (every batch of the backward call)
@@ -469,16 +508,16 @@ int launch_embedding_bwd(const float* dx, const int64_t* ids, int B, int T, int 
     const long long rows = (long long)B * T;
     if (rows <= 0) return R4D_OK;
     R4D_REQUIRE(table_rows >= rows, "embedding_bwd: table_rows %lld < rows %lld", table_rows, rows);
-    const float max_abs = fminf(EMB_MAX_ABS, 4194304.0f / (float)table_rows);      // 2^62 / 2^40 / rows: the sum cannot wrap
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte, max_abs);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dx, ids, rows, d, vocab, acc_wte,
+                       emb_lg_rows(table_rows));
     R4D_CHECK_LAUNCH("embedding_bwd");
     hipLaunchKernelGGL(wpe_bwd_kernel, dim3((unsigned)(((long long)T * d + 255) / 256)), dim3(256), 0, s, dx, B, T, d, first_group, dwpe);
     R4D_CHECK_LAUNCH("wpe_bwd");
     return R4D_OK;
 }
-int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, float* out, hipStream_t s) {
+int launch_embedding_fix_to_f32(const unsigned long long* acc, long long n, long long table_rows, float* out, hipStream_t s) {
     if (n <= 0) return R4D_OK;
-    hipLaunchKernelGGL(embedding_fix_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, n, out);
+    hipLaunchKernelGGL(embedding_fix_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, n, emb_lg_rows(table_rows), out);
     R4D_CHECK_LAUNCH("embedding_fix_to_f32");
     return R4D_OK;
 }

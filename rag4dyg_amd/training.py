@@ -14,6 +14,7 @@ counter-based generator (the reference's torch RNG stream cannot be reproduced),
 import math
 import os
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -560,6 +561,10 @@ def train(args, train_dataset, model, tokenizer):
                                                    steps_to_skip)
         tr_loss = ep_loss            # the reference resets tr_loss every epoch (train_retriever.py:158): its logged / returned
                                      # "train_loss" is the LAST epoch's summed loss over the cumulative step count (:303, :354)
+        if not math.isfinite(ep_loss):   # the reference trains on in silence; here the validation below refuses NaN weights
+            warnings.warn(f"rag4dyg_amd: epoch {epoch}: the summed training loss is {ep_loss} (contrastive {cl}, augmentation {au}) -- "
+                          f"e.g. the argparse default --lambda_decay -1 makes the time decay exp(+|dt|) overflow; the reference's "
+                          f"scripts pass 0.0001", RuntimeWarning)
         val_metrics, val_loss = test(epoch, args, model, tokenizer, evaluate=True)
         score = val_metrics['hit@3']
         print(f"epoch {epoch}: train_loss {tr_loss / max(global_step, 1):.5f} (cl {cl:.4f} aug {au:.4f}) val_loss {float(val_loss):.5f} "

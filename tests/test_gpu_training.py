@@ -259,14 +259,23 @@ def test_non_finite_gradient_stays_loud_in_the_deterministic_embedding_sum(dev):
     opt = training.AdamW(trainer.params, trainer.grads, lr=1e-3, flat_grads=trainer.flat_grads)
     opt.sumsq.zero_()
     assert not np.isfinite(float(trainer.flat_grads.double().pow(2).sum().sqrt()))
-    # the per-term bound follows the number of rows that meet in one table (2^22 / rows), so that NO run of same-sign
-    # contributions can wrap the 64-bit sum into a finite wrong value: one token in every position, upstream gradient 1e5 each --
-    # round 4's fixed 2^17 bound let 36 terms of ~2^61 wrap silently; now the step is poisoned (NaN), and a run of contributions
-    # inside the bound still sums exactly
+    # NO run of same-sign contributions may wrap the 64-bit sum into a finite wrong value (round 4's fixed 2^17 bound
+    # with a 2^44 scale let 36 terms of ~2^61 wrap silently).  The fixed-point scale now follows max |contribution| of the step
+    # and the number of rows, so every magnitude has an image: one token in every position, upstream gradient 1e5 / 1e-20 / 1e30
+    # each -- the sums are finite, linear in the upstream gradient (the scale is a power of two) and the same bits on a second run
     same = torch.full((4, 9), 7, dtype=torch.int64, device=dev)
     trainer.forward([same])
-    huge = trainer.backward(torch.full_like(emb, 1e5))["transformer.wte.weight"]
-    assert torch.isnan(huge).all() or torch.isfinite(huge).all() and huge[7].abs().max() > 1e3, "a wrapped fixed-point sum"
+    unit = trainer.backward(torch.ones_like(emb))["transformer.wte.weight"].clone()
+    assert torch.isfinite(unit).all() and unit[7].abs().max() > 0 and float(unit[:7].abs().max()) == 0.0 == float(unit[8:].abs().max())
+    for scale in (1e5, 1e-20, 1e30):
+        trainer.forward([same])
+        big = trainer.backward(torch.full_like(emb, scale))["transformer.wte.weight"].clone()
+        assert torch.isfinite(big).all(), scale
+        rel = ((big[7].double() - scale * unit[7].double()).abs().max() / (scale * unit[7].double().abs().max())).item()
+        assert rel < 1e-5, (scale, rel)                                  # the encoder backward is linear in its upstream gradient
+        trainer.forward([same])
+        again = trainer.backward(torch.full_like(emb, scale))["transformer.wte.weight"]
+        assert torch.equal(again, big), scale
 
 
 @pytest.mark.parametrize("split_mode", ["f16x2", "bf16x3"])
@@ -660,6 +669,35 @@ def test_real_uci13_training_two_epochs(dev, tmp_path, monkeypatch):
     assert all(np.isfinite([float(x) for e in ep for x in e[1:]])) and aug[1] < 0.3 * aug[0], ep
     assert 0.0 < float(ep[1][5]) < 1.0 and "test_metrics best epoch" in log and "test_metrics last epoch" in log
     assert (out / "checkpoint-1" / "pytorch_model.bin").exists()
+
+
+def test_training_run_that_diverges_to_nan_is_loud(dev, tmp_path, monkeypatch):
+    """The argparse DEFAULT ``--lambda_decay -1`` (the reference's scripts pass 0.0001) turns the time decay of ``CLtime_loss``
+    (``train/train_retriever.py:48-52``) into exp(+|dt|) = inf on the UCI_13 query times: NaN loss, NaN weights after the first
+    update -- in the reference too, which then validates and ranks with them in silence.  Here the epoch's loss raises a
+    ``RuntimeWarning`` and the validation pass refuses the weights (range guard): no metrics, no ``*.gen`` file
+    from NaN scores.  (``tools/annotation_e2e.py`` timed the evaluation of such checkpoints in round 4 without noticing.)"""
+    import importlib.util
+    import io
+    from contextlib import redirect_stdout
+    from conftest import REPO
+    from rag4dyg_amd import _lib
+    import main_retriever
+    spec = importlib.util.spec_from_file_location("train_uci13_demo", os.path.join(REPO, "tools", "train_uci13_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    base, ret = demo.build_workdir(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    out = tmp_path / "out"
+    argv = (f"--dataset UCI_13 --timestamp 12 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
+            f"--train_data_file {base}/train.link_prediction --eval_data_file {base}/val.link_prediction "
+            f"--eval_data_gt_file {ret}/val_score.retrieval --test_data_file {base}/test.link_prediction "
+            f"--test_data_gt_file {ret}/test_score.retrieval --n_layer 2 --n_head 2 --n_embed 128 --block_size 512 --seed 42 --topK 5 "
+            f"--train_pair_data_file {ret}/train_index.retrieval --max_steps 3 --per_gpu_train_batch_size 16 --do_train --patience 50").split()
+    with pytest.warns(RuntimeWarning, match="summed training loss"), pytest.raises(_lib.R4DError, match="non-finite"):
+        with redirect_stdout(io.StringIO()):
+            main_retriever.main(argv)
+    assert not list(tmp_path.rglob("*.gen"))
 
 
 # ------------------------------------------------------------------------------------------------ dropout (training mode)

@@ -41,6 +41,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.r4d_argsort_workspace_bytes(4, 2048, 4) <= 512                    # one chunk: sorted in LDS, no scratch
     assert lib.r4d_argsort_workspace_bytes(4, 100000, 4) >= 4 * 49 * 2048 * 8
     assert lib.r4d_argsort_workspace_bytes(4, 100000, 8) >= 4 * 49 * 2048 * 12
+    need = lib.r4d_jaccard_prepared_workspace_bytes(3965, 56000, 305, 4300, 11901)      # rank + counts + both idx copies + len / dense / order
+    assert 4 * (56000 + 4300) + 5 * 11901 + 12 * 3965 + 8 * 305 <= need < 2 * (4 * (56000 + 4300) + 5 * 11901 + 12 * 3965 + 8 * 305)
+    assert lib.r4d_jaccard_prepared_workspace_bytes(0, 0, 0, 0, 1) > 0 and lib.r4d_jaccard_prepared_workspace_bytes(-1, 0, 0, 0, 1) == 0
 
 
 def test_deepcopy_and_pickle_follow_their_own_lm_head():

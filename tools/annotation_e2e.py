@@ -92,7 +92,11 @@ def run_retriever():
     from rag4dyg_amd.tokenizer import get_model_tokenizer            # noqa: F401
     # a checkpoint to evaluate: random-init UCI_13 configuration saved in the reference layout
     out = os.path.join(root, "out")
-    argv = (f"--dataset UCI_13 --timestamp 12 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
+    # the flags of scripts/train_retriever/train_retriever_UCI_13.sh: the argparse DEFAULT --lambda_decay -1 turns the time decay
+    # exp(-lambda |dt|) into exp(+109) = inf on these query times (NaN loss in the reference as well); since round 5 the range
+    # guard refuses to evaluate the NaN checkpoints such a run leaves (round 4 timed the evaluation of NaN weights without noticing)
+    argv = (f"--dataset UCI_13 --timestamp 12 --eta 0.8 --gamma 0.4 --temperature 0.1 --alpha 1 --lambda_decay 0.0001 --lrdecay 1 "
+            f"--warmup_steps 0 --learning_rate 1e-5 --output_dir {out} --model_type gpt2 --model_name_or_path gpt2 "
             f"--train_data_file {base}/train.link_prediction --eval_data_file {base}/val.link_prediction "
             f"--eval_data_gt_file {ret}/val_score.retrieval --test_data_file {base}/test.link_prediction "
             f"--test_data_gt_file {ret}/test_score.retrieval --n_layer 4 --n_head 2 --n_embed 512 --block_size 512 --seed 42 --topK 5 "
