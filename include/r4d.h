@@ -247,6 +247,17 @@ int r4d_set_attention_fused(int32_t mode);
  * r4d_pack_h2_words_f32: x_d fp32 [n] -> words_d uint32 [n] (what the GEMM epilogue writes; for tests and external producers).
  * r4d_attention_h2_f32: r4d_attention_f32 on words: qkv_words_d [B*T, 3d] -> a_d fp32 [B*T, d]; head_dim 128 / 256 only. */
 int r4d_set_attention_h2(int32_t on);
+/* KEY-BLOCKED K (round 5, head_dim 128 / 256): row-major K costs every K load instruction of the attention 32 cache lines (each lane
+ * its own key row, 32 bytes of each line used); in the key-blocked image -- [ceil(rows / 32)][n_head][head_dim / 8][2][32][4] uint32:
+ * for every 32 consecutive token rows, head and 8-element step one contiguous 1 KB chunk [half][row & 31][4 words] -- the same
+ * instruction reads 8-10 whole lines (a third off the head_dim-256 launch).  Inside the encoder the LDS-DMA c_attn GEMM writes the
+ * image directly (r4d_set_attention_kblk(0) keeps row-major K; returns the previous setting; env R4D_ATT_KBLK=0 does the same).
+ * r4d_pack_kblk_words builds it from row-major qkv words (tests, external producers); r4d_attention_h2_kblk_f32 is
+ * r4d_attention_h2_f32 reading K from it (the K columns of qkv_words_d are not read) -- bit-identical results. */
+int r4d_set_attention_kblk(int32_t on);
+int r4d_pack_kblk_words(const uint32_t* qkv_words_d, int64_t rows, int32_t n_head, int32_t d, uint32_t* kblk_d, void* stream);
+int r4d_attention_h2_kblk_f32(const uint32_t* qkv_words_d, const uint32_t* kblk_d, int32_t B, int32_t T, int32_t n_head, int32_t d,
+                              float* a_d, void* stream);
 int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream);
 int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream);
 

@@ -71,6 +71,9 @@ PROTOTYPES = {
                                                 POINTER(c_int32), POINTER(c_int32), _P, _P, _P, _P, c_size_t, _P]),
     "r4d_set_attention_fused": (c_int32, [c_int32]),
     "r4d_set_attention_h2": (c_int32, [c_int32]),
+    "r4d_set_attention_kblk": (c_int32, [c_int32]),
+    "r4d_pack_kblk_words": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P]),
+    "r4d_attention_h2_kblk_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "r4d_set_range_flag": (c_int32, [_P]),
     "r4d_set_gemm_h2p": (c_int32, [c_int32]),
     "r4d_layernorm_lines_f32": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),

@@ -25,7 +25,7 @@
 #include "h2.h"
 
 #ifndef ATH_DBG
-#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills, bit 5 every second K / V refill only (half the traffic)
+#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills, bit 5 every second K / V refill only (half the traffic), bit 6 K loads as eight WHOLE 128-byte lines per instruction (lane-linear addresses, wrong operands: what a key-blocked K layout would cost the vector-memory path)
 #endif
 
 #ifndef ATH_KD
@@ -61,8 +61,15 @@ __global__ __launch_bounds__(256) void pack_h2_words_kernel(const float* __restr
 
 #define ATH_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8q, A_), __builtin_bit_cast(f16x8q, B_), C_, 0, 0, 0)
 
-template <int HD>
-__global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H,
+// KBLK: the K words come from the KEY-BLOCKED image `kblk` that the c_attn epilogue writes beside qkv (gemm_h2p.hip, EPI_H2WORDS with
+// kb_hd set) instead of from the K columns of qkv: for every 32 consecutive token ROWS (global row index, blocks of 32), head and
+// 8-element step u one contiguous 1 KB chunk [half h][row & 31][4 words] -- exactly the 64 x 16 bytes one K load instruction of a
+// wavefront fetches.  Row-major K costs that instruction 32 cache lines (each lane its own key row, 32 bytes of each line used);
+// blocked it is 8-10 whole lines.  PMC on the row-major form (round 5): TA busy 71 %, 14.5 tag lookups per load instruction, L1 hit
+// rate 75 % = every line fetched once and looked up four times; with whole lines the head_dim-256 launch takes a third less.
+template <int HD, bool KBLK>
+__global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn_h2_kernel(const unsigned* __restrict__ qkv, const unsigned* __restrict__ kblk,
+                                                                                  const AttnGroups G, int d, int H,
                                                                                   int ntq, float qscale, float* __restrict__ out, int out_lines) {
     constexpr int CW = HD / 4;                         // head columns owned by one wave
     constexpr int VW = CW / 32;                        // O^T tiles per wave (1 or 2): tile j = columns wid * CW + 32 j + lane
@@ -91,16 +98,29 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
     const int ld3 = 3 * d;
     const unsigned* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
     const int seq_bytes = ((T - 1) * ld3 + HD) * 4;    // one head's K (or V) rows of this sequence, as a byte range
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + d), 0, seq_bytes, 0x00020000);
+    // K: row-major -- this head's K columns of the sequence's rows; key-blocked -- from the block that holds the sequence's first row
+    // to the end of the block that holds its last one (block = 32 rows x d words; this head's chunks start hh * NSTEP KB into a block)
+    const int roff = (int)(rowb & 31);
+    const unsigned* kbase = KBLK ? kblk + (rowb >> 5) * (long long)(32 * d) + h * (HD / 8) * 256 : base + d;
+    const int kbytes = KBLK ? (((roff + T - 1) >> 5) + 1) * (d * 128) - h * (HD / 8) * 1024 : seq_bytes;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(kbase), 0, kbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + 2 * d), 0, seq_bytes, 0x00020000);
     const int qidx = q0 + li;
     const int key_limit = min(T, q0 + 32);             // keys >= key_limit are masked for every query of the tile
-    const int k_voff = ((32 * wid + li) * ld3 + 4 * lh) * 4;                 // bytes; + scalar (st0 * ld3 + 8u) * 4
+    const int gl = roff + 32 * wid + li;               // key-blocked: this lane's key of super-tile 0, counted from the first block's row 0
+    const int k_voff = KBLK ? (gl >> 5) * (d * 128) + (lh * 32 + (gl & 31)) * 16
+                     : (ATH_DBG & 64) ? (32 * wid * ld3) * 4 + 16 * lane : ((32 * wid + li) * ld3 + 4 * lh) * 4;   // bytes; + scalar (super-tile, step)
+    constexpr int K_STEP = (KBLK || (ATH_DBG & 64)) ? 1024 : 32;             // bytes between a lane's consecutive K loads
+    const int k_tile = KBLK ? d * 4 : ld3 * 4;                                // bytes per key of super-tile advance (st0 keys = st0 / 32 blocks)
+    // (V: measured and taken out -- one 16-byte load per lane (key 4lh + (li & 3) x four columns: eight whole lines per instruction
+    //  instead of four 4-byte loads of two lines each) followed by a 4 x 4 transpose inside the quad, 16 DPP / select instructions per
+    //  column tile: head_dim 256 102 -> 119 us, head_dim 128 218 -> 208 us at B 128, T 277 / 300: the VALU work costs more than the
+    //  vector-memory path gains)
     const int v_voff = (4 * lh * ld3 + wid * CW + li) * 4;                   // bytes; + scalar ((st0 + 8s + c) * ld3 + 32 j) * 4
     u32x4q kb[KD];
     if (wid * 32 < key_limit) {
 #pragma unroll
-        for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, 32 * u, 0);
+        for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, K_STEP * u, 0);
     }
     {   // Q tile: thread t stages row t/8, 16-byte pieces 4*(t%8) + 32j; rows past T repeat the last row (never stored)
         const int row = tid >> 3, seg = 4 * (tid & 7);
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
             f32x16q S0, S1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S0[r] = 0.f; S1[r] = 0.f; }
-            const int k_soff = st0 * ld3 * 4;
+            const int k_soff = st0 * k_tile;
             u32x4q qb[QP];
 #pragma unroll
             for (int u = 0; u < QP; ++u) qb[u] = *reinterpret_cast<const u32x4q*>(q_frag + 8 * u);
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
                 S1 = ATH_MFMA(kw, f2, S1);
                 if (u + QP < NSTEP) qb[u % QP] = *reinterpret_cast<const u32x4q*>(q_frag + 8 * (u + QP));
                 if (!(ATH_DBG & 8) && !((ATH_DBG & 32) && (u & 1)) && u + KD < NSTEP)  // refill AFTER the slot's MFMAs in program order: no register copies
-                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + 32 * (u + KD), 0);
+                    kb[u % KD] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, k_soff + K_STEP * (u + KD), 0);
                 // pinned: the step's eight VALU, its two MFMAs, then the Q read of step u + QP and the K load of step u + KD
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -215,9 +235,9 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
         // ---- O^T[c][q] += sum over the valid keys of this super-tile of V[key][c] * P[q][key], 8 keys per group:
         // lane half lh handles keys 8s + 4lh + c (c = 0..3) -- the four words of its ds_read_b128 of each P form
         if (!(ATH_DBG & 8) && st0 + 128 + wid * 32 < key_limit) {         // this wave's K rows of the next super-tile
-            const int kn_soff = (st0 + 128) * ld3 * 4;
+            const int kn_soff = (st0 + 128) * k_tile;
 #pragma unroll
-            for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + 32 * u, 0);
+            for (int u = 0; u < KD; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, kn_soff + K_STEP * u, 0);
         }
         // the P words of group s + 1 are read before the MFMAs of group s (a group is 2 VW MFMAs: 64-128 cycles, the LDS latency);
         // group 16 does not exist: its read stays inside the allocation (LDP = 132, then `red`) and is never used
@@ -283,13 +303,13 @@ __global__ __launch_bounds__(256, HD >= 256 ? ATH_OCC256 : ATH_OCC128) void attn
     }
 }
 
-template <int HD>
-static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
+template <int HD, bool KBLK>
+static int launch_ah2(const unsigned* qkv, const unsigned* kblk, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
     const size_t lds = ((size_t)32 * (HD + 4) + 32 * 132 + 256) * 4;       // >= the [32][HD+4] output tile
     if (lds > 64 * 1024) {
         static bool raised = false;                     // (one process drives one device: include/r4d.h, PROCESS MODEL)
         if (!raised) {
-            if (hipFuncSetAttribute((const void*)attn_h2_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)attn_h2_kernel<HD, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 set_error("attention_h2: cannot raise the dynamic LDS limit");
                 return R4D_ERR_HIP;
             }
@@ -300,7 +320,7 @@ static int launch_ah2(const unsigned* qkv, const AttnGroups& G, int Tmax, double
     const int ntq = cdiv(Tmax, 32);
     const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
     R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
-    hipLaunchKernelGGL((attn_h2_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
+    hipLaunchKernelGGL((attn_h2_kernel<HD, KBLK>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, kblk, G, d, H, ntq,
                        (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out, out_lines);      // both pre-scales undone in the logits
     R4D_CHECK_LAUNCH("attn_h2");
     return R4D_OK;
@@ -537,8 +557,9 @@ bool attention_h2_supported(int H, int d) {
 
 // Attention of n <= ATT_MAXG batches in one launch (launch_attention_fused_groups's contract) on h2 words
 // out_lines: `out` receives the merged-head rows as f16x2 lines [rows][d/32][2][32] fp16 (d % 32 == 0) instead of fp32 [rows][d]
+// kblk (nullable; head_dim 128 / 256 only): the key-blocked K image (attn_h2_kernel) -- the K columns of `qkv` are then not read
 int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
-                               float* out, hipStream_t s, bool out_lines) {
+                               float* out, hipStream_t s, bool out_lines, const unsigned* kblk) {
     R4D_REQUIRE(qkv && out, "attention_h2: null pointer");
     R4D_REQUIRE(attention_h2_supported(H, d), "attention_h2: head_dim %d has no instantiation (32 / 64 / 96 / 128 / 256)", H > 0 ? d / H : 0);
     R4D_REQUIRE(n >= 1 && n <= ATT_MAXG, "attention_h2: %d batches per launch (max %d)", n, ATT_MAXG);
@@ -561,9 +582,34 @@ int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const 
     if (hd == 32) { R4D_BRANCH(ATT_H2_KS32); return launch_ah2ks<32>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (hd == 64) { R4D_BRANCH(ATT_H2_KS64); return launch_ah2ks<64>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (hd == 96) { R4D_BRANCH(ATT_H2_KS96); return launch_ah2ks<96>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
-    if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    R4D_REQUIRE(!kblk || hd == 128 || hd == 256, "attention_h2: the key-blocked K image exists for head_dim 128 / 256 only");
+    if (hd == 128 && kblk) { R4D_BRANCH(ATT_H2_128_KBLK); return launch_ah2<128, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (kblk) { R4D_BRANCH(ATT_H2_256_KBLK); return launch_ah2<256, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     R4D_BRANCH(ATT_H2_256);
-    return launch_ah2<256>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s);
+    return launch_ah2<256, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s);
+}
+
+// K columns of row-major qkv words -> the key-blocked image (what gemm_h2p's epilogue writes directly; tests, external producers)
+__global__ __launch_bounds__(256) void pack_kblk_words_kernel(const unsigned* __restrict__ qkv, long long M, int H, int d, unsigned* __restrict__ kblk) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // one thread per 4 words (16 bytes) of the image
+    const long long n4 = (M + 31) / 32 * 32 * (long long)(d / 4);
+    if (i >= n4) return;
+    const int hd = d / H, nstep = hd / 8;
+    const int slot = (int)(i & 63);                                     // [half][row & 31]
+    const long long chunk = i >> 6;                                     // (block * H + head) * nstep + u
+    const int u = (int)(chunk % nstep), head = (int)((chunk / nstep) % H);
+    const long long row = (chunk / nstep / H) * 32 + (slot & 31);
+    u32x4q v = {0u, 0u, 0u, 0u};
+    if (row < M) v = *reinterpret_cast<const u32x4q*>(qkv + row * 3 * d + d + head * hd + 8 * u + 4 * (slot >> 5));
+    reinterpret_cast<u32x4q*>(kblk)[i] = v;
+}
+int launch_pack_kblk_words(const unsigned* qkv, long long M, int H, int d, unsigned* kblk, hipStream_t s) {
+    R4D_REQUIRE(qkv && kblk && M >= 1 && H >= 1 && d % H == 0 && (d / H == 128 || d / H == 256), "pack_kblk_words: bad arguments (head_dim 128 / 256)");
+    const long long n4 = (M + 31) / 32 * 32 * (long long)(d / 4);
+    hipLaunchKernelGGL(pack_kblk_words_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, qkv, M, H, d, kblk);
+    R4D_CHECK_LAUNCH("pack_kblk_words");
+    return R4D_OK;
 }
 
 int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s) {
@@ -583,6 +629,17 @@ extern "C" {
 
 int r4d_pack_h2_words_f32(const float* x_d, int64_t n, uint32_t* words_d, void* stream) {
     return launch_pack_h2_words(x_d, n, words_d, (hipStream_t)stream);
+}
+
+int r4d_pack_kblk_words(const uint32_t* qkv_words_d, int64_t rows, int32_t n_head, int32_t d, uint32_t* kblk_d, void* stream) {
+    return launch_pack_kblk_words(qkv_words_d, rows, n_head, d, kblk_d, (hipStream_t)stream);
+}
+
+int r4d_attention_h2_kblk_f32(const uint32_t* qkv_words_d, const uint32_t* kblk_d, int32_t B, int32_t T, int32_t n_head, int32_t d,
+                              float* a_d, void* stream) {
+    R4D_REQUIRE(B >= 1 && T >= 1 && kblk_d, "attention_h2_kblk: B=%d T=%d", B, T);
+    const long long row0 = 0;
+    return launch_attention_h2_groups(qkv_words_d, 1, &B, &T, &row0, n_head, d, a_d, (hipStream_t)stream, false, kblk_d);
 }
 
 int r4d_attention_h2_f32(const uint32_t* qkv_words_d, int32_t B, int32_t T, int32_t n_head, int32_t d, float* a_d, void* stream) {

@@ -70,7 +70,7 @@ struct ProfScope {
     X(SK16_SPLITK, "skinny16:split-K last-arriver") X(SK8_NG2, "skinny8:ng2") X(SK8_NG3, "skinny8:ng3")                    \
     X(SK8_LN, "tuning:skinny8:+layernorm") X(SK8_SPLITK, "skinny8:split-K + epilogue launch") X(SK_PLAIN, "skinny:plain + epilogue launch") \
     X(ATT_KS32, "attention:key-split hd32") X(ATT_KS64, "attention:key-split hd64") X(ATT_CS96, "attention:column-split hd96") \
-    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256") X(ATT_H2_KS32, "attention:f16x2 key-split hd32") X(ATT_H2_KS64, "attention:f16x2 key-split hd64") X(ATT_H2_KS96, "attention:f16x2 key-split hd96") X(ATT_H2_128, "attention:f16x2 hd128") X(ATT_H2_256, "attention:f16x2 hd256")                              \
+    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256") X(ATT_H2_KS32, "attention:f16x2 key-split hd32") X(ATT_H2_KS64, "attention:f16x2 key-split hd64") X(ATT_H2_KS96, "attention:f16x2 key-split hd96") X(ATT_H2_128, "attention:f16x2 hd128") X(ATT_H2_256, "attention:f16x2 hd256") X(ATT_H2_128_KBLK, "attention:f16x2 hd128, key-blocked K") X(ATT_H2_256_KBLK, "attention:f16x2 hd256, key-blocked K")                              \
     X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
     X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
     X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \
@@ -149,6 +149,7 @@ struct S3Args {
     const float* A; const unsigned short* planes; float* C;
     const float* bias; const float* resid;
     int M, N, K, lda, ldc, ldr, epilogue;
+    unsigned* kblk; int kb_hd;        // gemm_h2p, EPI_H2WORDS, N = 3 d: columns [d, 2d) go to the key-blocked K image instead (kb_hd = head_dim; 0 = off)
 };
 bool gemm_s3_supported(int M, int K, int N);
 int launch_gemm_s3(const S3Args& a, hipStream_t stream);
@@ -240,7 +241,10 @@ struct AttnGroups {
 // gemm_h2's EPI_H2WORDS epilogue or launch_pack_h2_words); head_dim 128 / 256 (attention_h2_supported)
 bool attention_h2_supported(int H, int d);
 int launch_attention_h2_groups(const unsigned* qkv_words, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
-                               float* out, hipStream_t s, bool out_lines = false);
+                               float* out, hipStream_t s, bool out_lines = false, const unsigned* kblk = nullptr);
+// the key-blocked K image of h2 words (attention_h2.hip: attn_h2_kernel<HD, true>): [ceil(M / 32)][H][hd / 8][2][32][4] uint32
+int launch_pack_kblk_words(const unsigned* qkv_words, long long M, int H, int d, unsigned* kblk, hipStream_t s);
+static inline size_t kblk_words(size_t M, int d) { return (M + 31) / 32 * 32 * (size_t)d; }
 int launch_pack_h2_words(const float* x, long long n, unsigned* words, hipStream_t s);
 int dbgflag_att_h2();
 // attention_fused.hip: R4D_OK / error, or +1 when head_dim has no fused instantiation

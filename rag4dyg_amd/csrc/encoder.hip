@@ -1,6 +1,7 @@
 // C-ABI entry points of the GPT-2 encoder: orchestration of the gfx950 kernels, no device allocation,
 // everything enqueued on the caller's stream (graph-capturable).  See include/r4d.h for the contract.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "common.h"
@@ -55,12 +56,14 @@ int conv1d(const float* x, const float* w, const float* wT, const float* bias, c
 
 // Conv1D whose input rows are f16x2 LINES written by their producer (gemm_h2p.hip): f16x2 mode only; out_lines: the GELU epilogue
 // writes the result as lines too (c_fc -> mlp.c_proj)
+// kblk / kb_hd (c_attn with the h2-word epilogue only): the K third goes to the key-blocked image of attention_h2.hip
 static int conv1d_lines(const unsigned short* x_lines, const unsigned short* w2h, const float* bias, const float* resid, int M, int K, int N,
-                        int epilogue, void* y, bool out_lines, hipStream_t s) {
+                        int epilogue, void* y, bool out_lines, hipStream_t s, unsigned* kblk = nullptr, int kb_hd = 0) {
     S3Args a;
     memset(&a, 0, sizeof(a));
     a.planes = w2h; a.C = (float*)y; a.bias = bias; a.resid = resid;
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.ldr = N; a.epilogue = epilogue;
+    a.kblk = kblk; a.kb_hd = kb_hd;
     return launch_gemm_h2p(a, x_lines, out_lines, s);
 }
 
@@ -73,6 +76,7 @@ static inline int tpad(int T) { return (T + 127) / 128 * 128; }
 // the 256 MB Infinity Cache between the launches.
 int g_attention_fused = -1;           // -1 auto (by head_dim), 0 three launches, 1 fused wherever instantiated
 int g_attention_h2 = 1;               // r4d_set_attention_h2: in f16x2 mode, head_dim 128 / 256 on the fp16 matrix cores (attention_h2.hip)
+static int g_attention_kblk = -1;     // tuning aid, read once: R4D_ATT_KBLK=0 keeps the row-major K words (the key-blocked image needs the LDS-DMA c_attn)
 
 static int attention(const float* qkv, int B, int T, int H, int d, float* a_out, float* scores, hipStream_t s) {
     // Measured on MI355X (tools/attn_bench.py, B=128, T=128..300): the fused kernels are 1.15-2.7x faster than the
@@ -125,6 +129,7 @@ static RowGroups row_groups(const Group* groups, int g0, int n_groups) {
 
 struct Workspace {
     float *x, *ln, *qkv, *att, *fc, *scores, *pool;
+    unsigned* kblk;       // key-blocked K words of the f16x2 attention (attention_h2.hip): ceil32(M) x d
     size_t bytes;
 };
 static Workspace carve(void* base, size_t M, size_t score_floats, size_t pool_floats, int d) {
@@ -138,6 +143,7 @@ static Workspace carve(void* base, size_t M, size_t score_floats, size_t pool_fl
     w.x = take(M * d); w.ln = take(M * d); w.qkv = take(M * 3 * d); w.att = take(M * d); w.fc = take(M * 4 * d);
     w.scores = take(score_floats);
     w.pool = take(pool_floats);
+    w.kblk = reinterpret_cast<unsigned*>(take(kblk_words(M, d)));
     w.bytes = off;
     return w;
 }
@@ -171,6 +177,11 @@ int r4d_fold_layernorm_f32(const float* wT_d, const float* ln_w_d, const float* 
 int r4d_set_gemm_split3(int32_t mode) { g_gemm_split3 = mode == 2 ? 2 : (mode != 0); return R4D_OK; }
 int r4d_get_gemm_split3(void) { return g_gemm_split3; }
 int r4d_set_range_flag(uint32_t* flag_d) { g_range_flag = flag_d; return R4D_OK; }
+int r4d_set_attention_kblk(int32_t on) {
+    const int prev = g_attention_kblk < 0 ? 1 : g_attention_kblk;
+    g_attention_kblk = on != 0;
+    return prev;
+}
 int r4d_set_attention_h2(int32_t on) {
     const int prev = g_attention_h2;
     g_attention_h2 = on != 0;
@@ -279,7 +290,16 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
             for (int j = g0; j < n_groups && j < g0 + ATT_MAXG; ++j) nseq += groups[j].B;
             if (nseq > 65535) words = false;
         }
-        if (lines) rc = conv1d_lines(ln_lines, L.c_attn_h2, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, false, s);
+        // ... and its K third as the key-blocked image the head_dim 128 / 256 kernel loads by whole cache lines (attention_h2.hip)
+        if (g_attention_kblk < 0) { const char* e = getenv("R4D_ATT_KBLK"); g_attention_kblk = e ? atoi(e) != 0 : 1; }
+        const bool kblk = words && lines && g_attention_kblk && (d / H == 128 || d / H == 256);
+        if (kblk && (M & 31) &&        // the last block's rows past M are never written: keep them finite (they are masked keys at most)
+            hipMemsetAsync(ws.kblk + (size_t)(M / 32) * 32 * d, 0, (size_t)32 * d * sizeof(unsigned), s) != hipSuccess) {
+            set_error("gpt2: memset of the key-block tail failed");
+            return R4D_ERR_HIP;
+        }
+        if (lines) rc = conv1d_lines(ln_lines, L.c_attn_h2, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, false, s,
+                                     kblk ? ws.kblk : nullptr, kblk ? d / H : 0);
         else rc = conv1d(ws.ln, L.c_attn_w, L.c_attn_wT, L.c_attn_b, nullptr, M, d, 3 * d, words ? EPI_H2WORDS : EPI_NONE, qkv, s, nullptr, false, L.c_attn_w3, L.c_attn_h2);
         if (rc) return rc;
         // ... and with them the attention output: attn_h2_kernel writes its merged-head rows as lines for attn.c_proj
@@ -292,7 +312,8 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
                 long long r0[ATT_MAXG];
                 const int n = n_groups - g0 < ATT_MAXG ? n_groups - g0 : ATT_MAXG;
                 for (int j = 0; j < n; ++j) { Bs[j] = groups[g0 + j].B; Ts[j] = groups[g0 + j].T; r0[j] = (long long)groups[g0 + j].row0; }
-                if ((rc = launch_attention_h2_groups(reinterpret_cast<const unsigned*>(qkv), n, Bs, Ts, r0, H, d, ws.att, s, att_lines))) return rc;
+                if ((rc = launch_attention_h2_groups(reinterpret_cast<const unsigned*>(qkv), n, Bs, Ts, r0, H, d, ws.att, s, att_lines,
+                                                     kblk ? ws.kblk : nullptr))) return rc;
             }
         } else if (g_attention_fused != 0) {             // all batches of the call in ceil(n/16) fused launches
             fused_done = true;

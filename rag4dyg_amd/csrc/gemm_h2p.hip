@@ -47,6 +47,7 @@ __device__ __forceinline__ float gelu_new_h2p_1(float x) {
 
 struct H2PShape {
     int M, N, K, ldc, ldr;
+    unsigned* kblk; int kb_hd;        // EPI_H2WORDS with N = 3 d: the K columns [d, 2d) go to the key-blocked image (attention_h2.hip) instead of C
 };
 
 // NI DMA instructions of 1 KB each: global address = base + 32-bit lane offset + i KB, LDS address = M0 + i KB + 16 lane (the
@@ -278,11 +279,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kern
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(EPI == EPI_RESIDUAL ? residg + (long long)m0 * g.ldr + n0 : Cg), 0,
                 EPI == EPI_RESIDUAL ? ((BM - 1) * g.ldr + BN) * 4 : 0, 0x00020000);
+            // EPI_H2WORDS with a key-blocked K image: a 32-column block of the K third is (one head, four steps u0 .. u0+3); the MFMA
+            // tile's 32 rows ARE one key block (m0, WM and the tile are multiples of 32): element (row, col) -> chunk (block, head, u),
+            // slot [half = (e >> 2) & 1][row & 31][e & 3], e = the column within the head
+            const int kd = g.N / 3;
+            const __amdgpu_buffer_rsrc_t kb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (EPI == EPI_H2WORDS && g.kb_hd) ? g.kblk : reinterpret_cast<unsigned*>(Cg), 0,
+                (EPI == EPI_H2WORDS && g.kb_hd) ? ((g.M + 31) / 32) * (kd * 128) : 0, 0x00020000);
+            const int lane_kb = (li >> 3) * 1024 + ((li >> 2) & 1) * 512 + ((li & 3) + 4 * lh) * 16;       // chunk (step), half, row slot of the lane after the quad transpose
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float bias = biasg ? biasg[n0 + wn * WN + j * 32 + li] : 0.f;
+                const int colb = n0 + wn * WN + j * 32;
+                const bool to_kb = EPI == EPI_H2WORDS && g.kb_hd && colb >= kd && colb < 2 * kd;        // wave-uniform
+                const int kb_chunk = to_kb ? ((colb - kd) / g.kb_hd) * (g.kb_hd / 8) + ((colb - kd) % g.kb_hd) / 8 : 0;   // head * NSTEP + u0
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    const int kb_soff = (((m0 + wm * WM + i * 32) >> 5) * (kd / 8) + kb_chunk) * 1024;     // bytes: block * (H * NSTEP) chunks of 1 KB
                     float res[16];
                     if (EPI == EPI_RESIDUAL) {
 #pragma unroll
@@ -290,6 +303,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kern
                             res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                 r_rsrc, lane_r, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr + j * 32) * 4, 0));
                     }
+                    unsigned o[16];
 #pragma unroll
                     for (int r2 = 0; r2 < 16; r2 += 2) {
                         f32x2p v2 = {__builtin_fmaf(acc1[i][j][r2], H2_LO_UNSCALE, acc0[i][j][r2]) * UNS + bias,
@@ -297,14 +311,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kern
                         if (EPI == EPI_GELU) v2 = gelu_new_h2p(v2);
                         else if (EPI == EPI_RESIDUAL) { v2.x += res[r2]; v2.y += res[r2 + 1]; }
                         const float vx = v2.x, vy = v2.y;     // (copies first: __builtin_bit_cast on an ext-vector ELEMENT reads element 0)
-                        unsigned o2[2] = {__builtin_bit_cast(unsigned int, vx), __builtin_bit_cast(unsigned int, vy)};
-                        if (EPI == EPI_H2WORDS) h2_words<true>(v2.x, v2.y, o2[0], o2[1]);     // C is the uint32 word image of the result (attention_h2.hip)
+                        o[r2] = __builtin_bit_cast(unsigned int, vx); o[r2 + 1] = __builtin_bit_cast(unsigned int, vy);
+                        if (EPI == EPI_H2WORDS) h2_words<true>(v2.x, v2.y, o[r2], o[r2 + 1]);     // C is the uint32 word image of the result (attention_h2.hip)
+                    }
+                    if (EPI == EPI_H2WORDS && to_kb) {
+                        // registers 4a .. 4a+3 of the four lanes of a quad = rows 8a + (0..3) + 4 lh x the four words of one 16-byte
+                        // slot: a 4 x 4 transpose inside the quad (two DPP exchange stages) gives every lane ONE row's slot, and the
+                        // wavefront's store covers eight whole 128-byte lines (8 consecutive rows of 8 (step, half) chunks) -- as 4-byte
+                        // stores to 16 scattered pieces per instruction the c_attn launch was 80 us longer
+                        const bool o1 = li & 1, o2 = li & 2;
 #pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const int r = r2 + h2;
-                            __builtin_amdgcn_raw_buffer_store_b32(o2[h2], c_rsrc, lane_c,
-                                                                  ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
+                        for (int a4 = 0; a4 < 16; a4 += 4) {
+                            unsigned x0 = o[a4], x1 = o[a4 + 1], x2 = o[a4 + 2], x3 = o[a4 + 3];
+                            {   // stage 1: lanes t ^ 1, registers r ^ 1
+                                const unsigned s01 = o1 ? x0 : x1, s23 = o1 ? x2 : x3;
+                                const unsigned r01 = (unsigned)__builtin_amdgcn_mov_dpp((int)s01, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+                                const unsigned r23 = (unsigned)__builtin_amdgcn_mov_dpp((int)s23, 0xB1, 0xF, 0xF, true);
+                                if (o1) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
+                            }
+                            {   // stage 2: lanes t ^ 2, registers r ^ 2
+                                const unsigned s02 = o2 ? x0 : x2, s13 = o2 ? x1 : x3;
+                                const unsigned r02 = (unsigned)__builtin_amdgcn_mov_dpp((int)s02, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+                                const unsigned r13 = (unsigned)__builtin_amdgcn_mov_dpp((int)s13, 0x4E, 0xF, 0xF, true);
+                                if (o2) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
+                            }
+                            const u32x4p slot = {x0, x1, x2, x3};
+                            __builtin_amdgcn_raw_buffer_store_b128(slot, kb_rsrc, lane_kb, kb_soff + 2 * a4 * 16, 0);      // rows 8 (a4 / 4) ..
                         }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(o[r], c_rsrc, lane_c, ((i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32) * 4, 0);
                     }
                 }
             }
@@ -325,6 +362,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kern
                     if (EPI == EPI_GELU) v = gelu_new_h2p_1(v);
                     else if (EPI == EPI_RESIDUAL) v += residg[(long long)min(row, g.M - 1) * g.ldr + colc];
                     else if (EPI == EPI_H2WORDS) { unsigned w0, w1; h2_words<true>(v, 0.f, w0, w1); v = __builtin_bit_cast(float, w0); }
+                    if (EPI == EPI_H2WORDS && g.kb_hd && col >= g.N / 3 && col < 2 * (g.N / 3)) {      // the K third: key-blocked image
+                        const int kd = g.N / 3, e = (col - kd) % g.kb_hd, chunk = ((col - kd) / g.kb_hd) * (g.kb_hd / 8) + (e >> 3);
+                        if (row < g.M)
+                            g.kblk[((long long)(row >> 5) * (kd / 8) + chunk) * 256 + (((e >> 2) & 1) * 32 + (row & 31)) * 4 + (e & 3)] =
+                                __builtin_bit_cast(unsigned, v);
+                        continue;
+                    }
                     if (row < g.M && col_ok) C[(long long)row * g.ldc + col] = v;
                 }
             }
@@ -359,6 +403,7 @@ static int launch_h2p(const S3Args& a, const unsigned short* a_lines, bool out_l
     ProfScope prof(cls, 2.0 * (double)a.M * a.N * a.K, stream);
     H2PShape sh;
     sh.M = a.M; sh.N = a.N; sh.K = a.K; sh.ldc = a.ldc; sh.ldr = a.ldr;
+    sh.kblk = a.kblk; sh.kb_hd = a.kblk ? a.kb_hd : 0;
 #define H2P_LAUNCH_(E, OL) hipLaunchKernelGGL((gemm_h2p_kernel<128, BN, E, OL>), dim3(tiles), dim3(512), 0, stream, a_lines, a.planes, a.C, a.bias, a.resid, sh)
     if (out_lines) {
         if (a.epilogue != EPI_GELU) { set_error("gemm_h2p: line output exists for the GELU epilogue only"); return R4D_ERR_INVALID; }
@@ -384,6 +429,8 @@ int launch_gemm_h2p(const S3Args& a, const unsigned short* a_lines, bool out_lin
     R4D_REQUIRE(((uintptr_t)a_lines % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_h2p: alignment");
     R4D_REQUIRE(!out_lines || a.N % 32 == 0, "gemm_h2p: line output needs N %% 32 == 0 (N = %d)", a.N);
     R4D_REQUIRE(a.epilogue != EPI_RESIDUAL || a.resid, "gemm_h2p: the residual epilogue needs the second buffer");
+    R4D_REQUIRE(!a.kblk || (a.epilogue == EPI_H2WORDS && a.N % 3 == 0 && (a.kb_hd == 128 || a.kb_hd == 256) && (a.N / 3) % a.kb_hd == 0),
+                "gemm_h2p: the key-blocked K image goes with the h2-word epilogue, N = 3 d and head_dim 128 / 256");
     // fewest tile waves; the wide tile wins ties (gemm_h2.hip's rule: a row's result never depends on the tile either way)
     const long long b0 = (long long)cdiv(a.M, 128) * cdiv(a.N, 256), b1 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const double c0 = (double)((b0 + 255) / 256) * 128 * 256, c1 = (double)((b1 + 255) / 256) * 128 * 128 / 0.9;

@@ -240,6 +240,32 @@ def set_attention_h2(on):
     return bool(_lib.load().r4d_set_attention_h2(int(bool(on))))
 
 
+def set_attention_kblk(on):
+    """head_dim 128 / 256 f16x2 attention: K read from the key-blocked image the c_attn GEMM writes (whole cache lines per load
+    instruction; default on) or from row-major K words.  Same bits either way.  Returns the previous setting."""
+    return bool(_lib.load().r4d_set_attention_kblk(int(bool(on))))
+
+
+def pack_kblk_words(qkv_words, n_head):
+    """Row-major qkv words [B, T, 3d] -> the key-blocked K image (``include/r4d.h``) as a flat int32 tensor."""
+    B, T, d3 = qkv_words.shape
+    d = d3 // 3
+    rows = B * T
+    out = torch.empty((rows + 31) // 32 * 32 * d, dtype=torch.int32, device=qkv_words.device)
+    check(_lib.load().r4d_pack_kblk_words(_dev(qkv_words, torch.int32, "qkv_words"), rows, n_head, d, out.data_ptr(), _stream()), "pack_kblk_words")
+    return out
+
+
+def attention_h2_kblk(qkv_words, kblk, n_head):
+    """:func:`attention_h2` with K taken from ``kblk`` = :func:`pack_kblk_words` (head_dim 128 / 256)."""
+    B, T, d3 = qkv_words.shape
+    d = d3 // 3
+    a = torch.empty(B, T, d, dtype=torch.float32, device=qkv_words.device)
+    check(_lib.load().r4d_attention_h2_kblk_f32(_dev(qkv_words, torch.int32, "qkv_words"), _dev(kblk, torch.int32, "kblk"), B, T, n_head, d,
+                                                a.data_ptr(), _stream()), "attention_h2_kblk")
+    return a
+
+
 def pack_h2_words(x):
     """fp32 tensor -> its "h2 words" (int32 tensor of the same shape: fp16 hi | fp16 lo' << 16 of value / 4), the operand format of
     :func:`attention_h2` -- what the f16x2 c_attn GEMM writes inside the encoder."""

@@ -130,6 +130,15 @@ def test_every_dispatcher_branch_is_exercised(dev):
             out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
             ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]
             assert rel_err(out["hidden"].cpu().numpy(), ref.numpy()) < 1e-4, ("f16x2 attention", H, d)
+        prev = ops.set_attention_kblk(False)                               # head_dim 128 / 256 with row-major K words (the key-blocked image is the default)
+        try:
+            for H, d in ((2, 256), (2, 512)):
+                sd, m = model(1, H, d)
+                out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
+                ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]
+                assert rel_err(out["hidden"].cpu().numpy(), ref.numpy()) < 1e-4, ("f16x2 attention, row-major K", H, d)
+        finally:
+            ops.set_attention_kblk(prev)
     finally:
         ops.set_gemm_mode("bf16x3")
 

@@ -222,6 +222,39 @@ def test_attention_f16x2_golden(dev, tag):
     assert e64 <= 4 * r64 + 1e-6                     # never further from the truth than a small multiple of the reference itself
 
 
+@pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 128), (2, 129, 2, 256), (5, 277, 2, 256), (1, 1024, 2, 128), (3, 257, 6, 128),
+                                      (33, 31, 2, 256), (7, 45, 1, 256), (5, 160, 3, 128), (4, 300, 6, 128)])
+def test_attention_f16x2_key_blocked_image_equals_row_major_bit_for_bit(dev, B, T, H, hd):
+    """Round 5 (late): ``attn_h2_kernel<HD, true>`` reads K from the key-blocked image (32 token rows x head x 8-element step = one
+    contiguous 1 KB chunk: whole cache lines per load instruction instead of 32 partial ones) -- the same words in the same MFMA
+    slots, so the output equals the row-major kernel's BIT FOR BIT: T not a multiple of 32 (sequences start mid-block and span
+    block boundaries), one key, 1,024 keys, a last block that runs past the rows, three launches the same bits; and the K columns
+    of the word buffer are provably not read (overwritten with NaN words)."""
+    from rag4dyg_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T + hd)
+    d = H * hd
+    qkv = torch.randn(B, T, 3 * d, generator=g)
+    qkv[..., :2 * d] *= 3.0
+    words = ops.pack_h2_words(qkv.to(dev))
+    want = ops.attention_h2(words, H)
+    kblk = ops.pack_kblk_words(words, H)
+    assert kblk.numel() == (B * T + 31) // 32 * 32 * d
+    got = ops.attention_h2_kblk(words, kblk, H)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    poisoned = words.clone()
+    poisoned[..., d:2 * d] = 0x7e007e00                             # fp16 NaN in both halves of every K word
+    for _ in range(3):
+        again = ops.attention_h2_kblk(poisoned, kblk, H)
+        assert torch.equal(again.view(torch.int32), want.view(torch.int32))
+    # the image itself: chunk (block, head, step u) slot [half][row & 31] holds words 8u + 4 half .. + 3 of that row's head
+    w = words.view(B * T, 3 * d).cpu()
+    img = kblk.view(-1, H, hd // 8, 2, 32, 4).cpu()
+    for row in (0, B * T - 1, (B * T) // 2):
+        for head, u, half in ((0, 0, 0), (H - 1, hd // 8 - 1, 1)):
+            src = w[row, d + head * hd + 8 * u + 4 * half: d + head * hd + 8 * u + 4 * half + 4]
+            assert torch.equal(img[row // 32, head, u, half, row % 32], src)
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 128), (2, 129, 2, 256), (2, 339, 2, 256), (1, 1024, 2, 128), (2, 257, 6, 128),
                                       (33, 31, 2, 256), (1, 512, 1, 256), (5, 160, 3, 128),
                                       (3, 1, 2, 32), (4, 128, 8, 96), (2, 200, 8, 64), (2, 339, 4, 64), (1, 1024, 2, 96), (7, 33, 4, 32)])

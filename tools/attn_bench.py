@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid (GPU box): fused vs three-launch attention on the encoder's shapes; every head_dim with an instantiation also the f16x2 kernels
-(csrc/attention_h2.hip).  ATT_H2_ONLY=1: that kernel alone (ablated builds: tools/kc_ablate.sh attention_h2.hip ATH_DBG n)."""
+(csrc/attention_h2.hip).  ATT_H2_ONLY=1: that kernel alone (ablated builds: tools/kc_ablate.sh attention_h2.hip ATH_DBG n);
+ATT_KBLK=1: head_dim 128 / 256 with K from the key-blocked image (what the encoder runs)."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -17,16 +18,18 @@ for (B, T, H, hd) in SHAPES:
     h2 = ""
     if hd in (32, 64, 96, 128, 256):
         w = ops.pack_h2_words(qkv)
+        kb = ops.pack_kblk_words(w, H) if os.environ.get("ATT_KBLK") and hd in (128, 256) else None
+        run = (lambda: ops.attention_h2_kblk(w, kb, H)) if kb is not None else (lambda: ops.attention_h2(w, H))
         for _ in range(3):
-            ops.attention_h2(w, H)
+            run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            ops.attention_h2(w, H)
+            run()
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 20 * 1e3
-        h2 = f"  f16x2 {t:8.1f} us ({flop/t/1e6:6.1f} TF)"
+        h2 = f"  f16x2{' (key-blocked K)' if kb is not None else ''} {t:8.1f} us ({flop/t/1e6:6.1f} TF)"
     if os.environ.get("ATT_H2_ONLY"):
         print(f"{os.path.basename(os.environ.get('R4D_LIB_PATH', 'product'))} B={B:4d} T={T:4d} H={H} hd={hd:3d}{h2}", flush=True)
         continue
