@@ -247,10 +247,10 @@ int r4d_set_attention_fused(int32_t mode);
  * r4d_pack_h2_words_f32: x_d fp32 [n] -> words_d uint32 [n] (what the GEMM epilogue writes; for tests and external producers).
  * r4d_attention_h2_f32: r4d_attention_f32 on words: qkv_words_d [B*T, 3d] -> a_d fp32 [B*T, d]; head_dim 128 / 256 only. */
 int r4d_set_attention_h2(int32_t on);
-/* KEY-BLOCKED K (round 5, head_dim 128 / 256): row-major K costs every K load instruction of the attention 32 cache lines (each lane
+/* KEY-BLOCKED K (round 5): row-major K costs every K load instruction of the attention 32 cache lines (each lane
  * its own key row, 32 bytes of each line used); in the key-blocked image -- [ceil(rows / 32)][n_head][head_dim / 8][2][32][4] uint32:
  * for every 32 consecutive token rows, head and 8-element step one contiguous 1 KB chunk [half][row & 31][4 words] -- the same
- * instruction reads 8-10 whole lines (a third off the head_dim-256 launch).  Inside the encoder the LDS-DMA c_attn GEMM writes the
+ * instruction reads 8-10 whole lines (a fifth off the head_dim-256 launch in the bench step; every head_dim the f16x2 attention serves).  Inside the encoder the LDS-DMA c_attn GEMM writes the
  * image directly (r4d_set_attention_kblk(0) keeps row-major K; returns the previous setting; env R4D_ATT_KBLK=0 does the same).
  * r4d_pack_kblk_words builds it from row-major qkv words (tests, external producers); r4d_attention_h2_kblk_f32 is
  * r4d_attention_h2_f32 reading K from it (the K columns of qkv_words_d are not read) -- bit-identical results. */

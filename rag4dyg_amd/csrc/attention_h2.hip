@@ -25,7 +25,7 @@
 #include "h2.h"
 
 #ifndef ATH_DBG
-#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills, bit 5 every second K / V refill only (half the traffic), bit 6 K loads as eight WHOLE 128-byte lines per instruction (lane-linear addresses, wrong operands: what a key-blocked K layout would cost the vector-memory path)
+#define ATH_DBG 0   // tuning aid (tools/kc_ablate.sh attention_h2.hip ATH_DBG n): bit 0 one Q.K^T step only, bit 1 one P.V group only, bit 2 no softmax barriers, bit 3 no K refills, bit 4 no V refills, bit 5 every second K / V refill only (half the traffic), bit 7 the same in the key-split kernel, bit 6 K loads as eight WHOLE 128-byte lines per instruction (lane-linear addresses, wrong operands: what a key-blocked K layout would cost the vector-memory path)
 #endif
 
 #ifndef ATH_KD
@@ -335,8 +335,8 @@ static int launch_ah2(const unsigned* qkv, const unsigned* kblk, const AttnGroup
 // lane and step; B = the Q tile's forms from the LDS word image).  What the small head dims allow: the probabilities never touch LDS
 // -- in the S^T accumulator lane (q, lh) holds keys 8g + 4lh + {0..3} of every 8-key group g, which ARE the k-slots 8lh .. 8lh+7 that
 // lane supplies to the P.V MFMA of that group: four exp2, two h2_words, the two forms by AND / rotate, straight into the operand.
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __restrict__ qkv, const AttnGroups G, int d, int H, int ntq,
+template <int HD, bool KBLK>      // KBLK: K from the key-blocked image (attn_h2_kernel: whole cache lines per K load instruction)
+__global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __restrict__ qkv, const unsigned* __restrict__ kblk, const AttnGroups G, int d, int H, int ntq,
                                                           float qscale, float* __restrict__ out, int out_lines) {
     constexpr int NCB = HD / 32;                       // 32-column blocks of O^T
     constexpr int NSTEP = HD / 8;                      // 16-byte K loads per key row (8 elements per MFMA pair)
@@ -358,15 +358,22 @@ __global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __res
     const int ld3 = 3 * d;
     const unsigned* __restrict__ base = qkv + rowb * ld3 + (long long)h * HD;
     const int seq_bytes = ((T - 1) * ld3 + HD) * 4;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + d), 0, seq_bytes, 0x00020000);
+    const int roff = (int)(rowb & 31);                  // key-blocked: blocks of 32 GLOBAL rows; the sequence may start mid-block
+    const unsigned* kbase = KBLK ? kblk + (rowb >> 5) * (long long)(32 * d) + h * (HD / 8) * 256 : base + d;
+    const int kbytes = KBLK ? (((roff + T - 1) >> 5) + 1) * (d * 128) - h * (HD / 8) * 1024 : seq_bytes;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(kbase), 0, kbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base + 2 * d), 0, seq_bytes, 0x00020000);
     const int qidx = q0 + li;
-    const int k_voff = (li * ld3 + 4 * lh) * 4;                              // bytes; + scalar (key0 * ld3 + 8u) * 4
+    const int gl = roff + li;                          // this lane's key of tile 0, counted from row 0 of the sequence's first block
+    const int k_voff = KBLK ? (gl >> 5) * (d * 128) + (lh * 32 + (gl & 31)) * 16
+                     : (ATH_DBG & 128) ? 16 * lane : (li * ld3 + 4 * lh) * 4;   // bytes; + scalar (tile, step)
+    constexpr int KS_STEP = (KBLK || (ATH_DBG & 128)) ? 1024 : 32;           // (bit 7: lane-linear K addresses, whole lines per instruction, wrong operands)
+    const int k_key = KBLK ? d * 4 : ld3 * 4;                                // bytes per key of tile advance
     const int v_voff = (4 * lh * ld3 + li) * 4;                              // bytes; + scalar ((key0 + 8g + e) * ld3 + 32 j) * 4
     u32x4q kb[NSTEP];
     if (wid <= qt) {                                                         // this wave's first key tile
 #pragma unroll
-        for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, (wid * 32 * ld3 + 8 * u) * 4, 0);
+        for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, wid * 32 * k_key + KS_STEP * u, 0);
     }
     {   // Q tile: thread t stages row t/8, 16-byte pieces 4*(t%8) + 32j; rows past T repeat the last row (never stored)
         const int row = tid >> 3, seg = 4 * (tid & 7);
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __res
         ATK_VLOAD(1)
         if (HD > 64 && kt != wid) {                                           // head_dim 96: no K prefetch across tiles (registers)
 #pragma unroll
-            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, (key0 * ld3 + 8 * u) * 4, 0);
+            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, key0 * k_key + KS_STEP * u, 0);
         }
         f32x16q S0, S1;
 #pragma unroll
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __res
 #undef ATK_VLOAD
         if (HD <= 64 && kt + 4 <= qt) {                                       // the next tile's K rows travel under the softmax and P.V
 #pragma unroll
-            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, ((key0 + 128) * ld3 + 8 * u) * 4, 0);
+            for (int u = 0; u < NSTEP; ++u) kb[u] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff, (key0 + 128) * k_key + KS_STEP * u, 0);
         }
         // online softmax on the raw dot products (attn_h2_kernel: subtract the maximum first, scale the small difference)
         float S[16];
@@ -532,8 +539,8 @@ __global__ __launch_bounds__(256, 2) void attn_h2ks_kernel(const unsigned* __res
     }
 }
 
-template <int HD>
-static int launch_ah2ks(const unsigned* qkv, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
+template <int HD, bool KBLK>
+static int launch_ah2ks(const unsigned* qkv, const unsigned* kblk, const AttnGroups& G, int Tmax, double flop, int H, int d, float* out, int out_lines, hipStream_t s) {
     constexpr int NCB = HD / 32;
     size_t words = (size_t)32 * (HD + 4);                                     // Q tile / O tile
     const size_t merge = 2 * ((size_t)NCB * 16 * 64 + 128);
@@ -543,7 +550,7 @@ static int launch_ah2ks(const unsigned* qkv, const AttnGroups& G, int Tmax, doub
     const int ntq = cdiv(Tmax, 32);
     const long long pairs8 = ((long long)G.seq_prefix[G.n] * H + 7) / 8;
     R4D_REQUIRE(pairs8 * 8 * ntq < (1ll << 31), "attention_h2: grid too large");
-    hipLaunchKernelGGL((attn_h2ks_kernel<HD>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, G, d, H, ntq,
+    hipLaunchKernelGGL((attn_h2ks_kernel<HD, KBLK>), dim3((unsigned)(pairs8 * 8 * ntq)), dim3(256), lds, s, qkv, kblk, G, d, H, ntq,
                        (float)((double)H2_A_UNSCALE * H2_A_UNSCALE * 1.4426950408889634 / sqrt((double)HD)), out, out_lines);
     R4D_CHECK_LAUNCH("attn_h2ks");
     return R4D_OK;
@@ -557,7 +564,7 @@ bool attention_h2_supported(int H, int d) {
 
 // Attention of n <= ATT_MAXG batches in one launch (launch_attention_fused_groups's contract) on h2 words
 // out_lines: `out` receives the merged-head rows as f16x2 lines [rows][d/32][2][32] fp16 (d % 32 == 0) instead of fp32 [rows][d]
-// kblk (nullable; head_dim 128 / 256 only): the key-blocked K image (attn_h2_kernel) -- the K columns of `qkv` are then not read
+// kblk (nullable): the key-blocked K image (attn_h2_kernel) -- the K columns of `qkv` are then not read
 int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const int* Ts, const long long* row0s, int H, int d,
                                float* out, hipStream_t s, bool out_lines, const unsigned* kblk) {
     R4D_REQUIRE(qkv && out, "attention_h2: null pointer");
@@ -579,10 +586,14 @@ int launch_attention_h2_groups(const unsigned* qkv, int n, const int* Bs, const 
     }
     for (int g = n; g < ATT_MAXG; ++g) { G.seq_prefix[g + 1] = G.seq_prefix[n]; G.T[g] = 0; G.row0[g] = 0; }
     R4D_REQUIRE(G.seq_prefix[n] <= 65535, "attention_h2: %d sequences per launch exceed the grid limit", G.seq_prefix[n]);
-    if (hd == 32) { R4D_BRANCH(ATT_H2_KS32); return launch_ah2ks<32>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
-    if (hd == 64) { R4D_BRANCH(ATT_H2_KS64); return launch_ah2ks<64>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
-    if (hd == 96) { R4D_BRANCH(ATT_H2_KS96); return launch_ah2ks<96>(qkv, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
-    R4D_REQUIRE(!kblk || hd == 128 || hd == 256, "attention_h2: the key-blocked K image exists for head_dim 128 / 256 only");
+    if (kblk) {
+        if (hd == 32) { R4D_BRANCH(ATT_H2_KS32_KBLK); return launch_ah2ks<32, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+        if (hd == 64) { R4D_BRANCH(ATT_H2_KS64_KBLK); return launch_ah2ks<64, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+        if (hd == 96) { R4D_BRANCH(ATT_H2_KS96_KBLK); return launch_ah2ks<96, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    }
+    if (hd == 32) { R4D_BRANCH(ATT_H2_KS32); return launch_ah2ks<32, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (hd == 64) { R4D_BRANCH(ATT_H2_KS64); return launch_ah2ks<64, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
+    if (hd == 96) { R4D_BRANCH(ATT_H2_KS96); return launch_ah2ks<96, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (hd == 128 && kblk) { R4D_BRANCH(ATT_H2_128_KBLK); return launch_ah2<128, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (hd == 128) { R4D_BRANCH(ATT_H2_128); return launch_ah2<128, false>(qkv, nullptr, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
     if (kblk) { R4D_BRANCH(ATT_H2_256_KBLK); return launch_ah2<256, true>(qkv, kblk, G, Tmax, flop, H, d, out, out_lines ? 1 : 0, s); }
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(256) void pack_kblk_words_kernel(const unsigned* __
     reinterpret_cast<u32x4q*>(kblk)[i] = v;
 }
 int launch_pack_kblk_words(const unsigned* qkv, long long M, int H, int d, unsigned* kblk, hipStream_t s) {
-    R4D_REQUIRE(qkv && kblk && M >= 1 && H >= 1 && d % H == 0 && (d / H == 128 || d / H == 256), "pack_kblk_words: bad arguments (head_dim 128 / 256)");
+    R4D_REQUIRE(qkv && kblk && M >= 1 && attention_h2_supported(H, d), "pack_kblk_words: bad arguments (head_dim 32 / 64 / 96 / 128 / 256)");
     const long long n4 = (M + 31) / 32 * 32 * (long long)(d / 4);
     hipLaunchKernelGGL(pack_kblk_words_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, qkv, M, H, d, kblk);
     R4D_CHECK_LAUNCH("pack_kblk_words");

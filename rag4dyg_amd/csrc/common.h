@@ -70,7 +70,7 @@ struct ProfScope {
     X(SK16_SPLITK, "skinny16:split-K last-arriver") X(SK8_NG2, "skinny8:ng2") X(SK8_NG3, "skinny8:ng3")                    \
     X(SK8_LN, "tuning:skinny8:+layernorm") X(SK8_SPLITK, "skinny8:split-K + epilogue launch") X(SK_PLAIN, "skinny:plain + epilogue launch") \
     X(ATT_KS32, "attention:key-split hd32") X(ATT_KS64, "attention:key-split hd64") X(ATT_CS96, "attention:column-split hd96") \
-    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256") X(ATT_H2_KS32, "attention:f16x2 key-split hd32") X(ATT_H2_KS64, "attention:f16x2 key-split hd64") X(ATT_H2_KS96, "attention:f16x2 key-split hd96") X(ATT_H2_128, "attention:f16x2 hd128") X(ATT_H2_256, "attention:f16x2 hd256") X(ATT_H2_128_KBLK, "attention:f16x2 hd128, key-blocked K") X(ATT_H2_256_KBLK, "attention:f16x2 hd256, key-blocked K")                              \
+    X(ATT_CS128, "attention:column-split hd128") X(ATT_CS256, "attention:column-split hd256") X(ATT_H2_KS32, "attention:f16x2 key-split hd32") X(ATT_H2_KS64, "attention:f16x2 key-split hd64") X(ATT_H2_KS96, "attention:f16x2 key-split hd96") X(ATT_H2_128, "attention:f16x2 hd128") X(ATT_H2_256, "attention:f16x2 hd256") X(ATT_H2_KS32_KBLK, "attention:f16x2 key-split hd32, key-blocked K") X(ATT_H2_KS64_KBLK, "attention:f16x2 key-split hd64, key-blocked K") X(ATT_H2_KS96_KBLK, "attention:f16x2 key-split hd96, key-blocked K") X(ATT_H2_128_KBLK, "attention:f16x2 hd128, key-blocked K") X(ATT_H2_256_KBLK, "attention:f16x2 hd256, key-blocked K")                              \
     X(ATT_KS_FORCED, "tuning:attention:key-split at hd96/128/256") X(ATT_3LAUNCH, "attention:three-launch GEMM form")      \
     X(SCAN_1_1, "scan:d32") X(SCAN_2_1, "scan:d64") X(SCAN_4_1, "scan:d128") X(SCAN_4_2, "scan:d256") X(SCAN_4_3, "scan:d384") \
     X(SCAN_8_2, "scan:d512") X(SCAN_4_4, "tuning:scan:d512 4-way") X(SCAN_8_3, "scan:d768") X(SCAN_8_4, "scan:d1024")       \

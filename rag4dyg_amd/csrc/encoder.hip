@@ -292,7 +292,7 @@ static int encode_impl(const r4d_gpt2_config* cfg, const r4d_gpt2_weights* w, co
         }
         // ... and its K third as the key-blocked image the head_dim 128 / 256 kernel loads by whole cache lines (attention_h2.hip)
         if (g_attention_kblk < 0) { const char* e = getenv("R4D_ATT_KBLK"); g_attention_kblk = e ? atoi(e) != 0 : 1; }
-        const bool kblk = words && lines && g_attention_kblk && (d / H == 128 || d / H == 256);
+        const bool kblk = words && lines && g_attention_kblk && (d / H) % 32 == 0;      // every head_dim attention_h2.hip serves
         if (kblk && (M & 31) &&        // the last block's rows past M are never written: keep them finite (they are masked keys at most)
             hipMemsetAsync(ws.kblk + (size_t)(M / 32) * 32 * d, 0, (size_t)32 * d * sizeof(unsigned), s) != hipSuccess) {
             set_error("gpt2: memset of the key-block tail failed");

@@ -429,8 +429,8 @@ int launch_gemm_h2p(const S3Args& a, const unsigned short* a_lines, bool out_lin
     R4D_REQUIRE(((uintptr_t)a_lines % 16) == 0 && ((uintptr_t)a.planes % 16) == 0, "gemm_h2p: alignment");
     R4D_REQUIRE(!out_lines || a.N % 32 == 0, "gemm_h2p: line output needs N %% 32 == 0 (N = %d)", a.N);
     R4D_REQUIRE(a.epilogue != EPI_RESIDUAL || a.resid, "gemm_h2p: the residual epilogue needs the second buffer");
-    R4D_REQUIRE(!a.kblk || (a.epilogue == EPI_H2WORDS && a.N % 3 == 0 && (a.kb_hd == 128 || a.kb_hd == 256) && (a.N / 3) % a.kb_hd == 0),
-                "gemm_h2p: the key-blocked K image goes with the h2-word epilogue, N = 3 d and head_dim 128 / 256");
+    R4D_REQUIRE(!a.kblk || (a.epilogue == EPI_H2WORDS && a.N % 3 == 0 && a.kb_hd >= 32 && a.kb_hd % 32 == 0 && (a.N / 3) % a.kb_hd == 0),
+                "gemm_h2p: the key-blocked K image goes with the h2-word epilogue, N = 3 d and a head_dim that is a multiple of 32");
     // fewest tile waves; the wide tile wins ties (gemm_h2.hip's rule: a row's result never depends on the tile either way)
     const long long b0 = (long long)cdiv(a.M, 128) * cdiv(a.N, 256), b1 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const double c0 = (double)((b0 + 255) / 256) * 128 * 256, c1 = (double)((b1 + 255) / 256) * 128 * 128 / 0.9;

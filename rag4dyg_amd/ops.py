@@ -241,7 +241,7 @@ def set_attention_h2(on):
 
 
 def set_attention_kblk(on):
-    """head_dim 128 / 256 f16x2 attention: K read from the key-blocked image the c_attn GEMM writes (whole cache lines per load
+    """f16x2 attention: K read from the key-blocked image the c_attn GEMM writes (whole cache lines per load
     instruction; default on) or from row-major K words.  Same bits either way.  Returns the previous setting."""
     return bool(_lib.load().r4d_set_attention_kblk(int(bool(on))))
 
@@ -257,7 +257,7 @@ def pack_kblk_words(qkv_words, n_head):
 
 
 def attention_h2_kblk(qkv_words, kblk, n_head):
-    """:func:`attention_h2` with K taken from ``kblk`` = :func:`pack_kblk_words` (head_dim 128 / 256)."""
+    """:func:`attention_h2` with K taken from ``kblk`` = :func:`pack_kblk_words`."""
     B, T, d3 = qkv_words.shape
     d = d3 // 3
     a = torch.empty(B, T, d, dtype=torch.float32, device=qkv_words.device)

@@ -125,14 +125,14 @@ def test_every_dispatcher_branch_is_exercised(dev):
     # ---- f16x2 mode: attention on the fp16 matrix cores (column-split at head_dim 128 / 256, key-split at 32 / 64 / 96), fed with h2 words by the c_attn GEMM (attention_h2.hip)
     ops.set_gemm_mode("f16x2")
     try:
-        for H, d in ((2, 256), (2, 512), (2, 64), (4, 256), (8, 768)):      # head_dim 128, 256; key-split form: 32, 64, 96
+        for H, d in ((2, 256), (2, 512), (2, 64), (4, 256), (8, 768), (8, 256)):      # head_dim 128, 256; key-split form: 32 (row-major K at d = 64, key-blocked at d = 256), 64, 96
             sd, m = model(1, H, d)
             out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
             ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]
             assert rel_err(out["hidden"].cpu().numpy(), ref.numpy()) < 1e-4, ("f16x2 attention", H, d)
         prev = ops.set_attention_kblk(False)                               # head_dim 128 / 256 with row-major K words (the key-blocked image is the default)
         try:
-            for H, d in ((2, 256), (2, 512)):
+            for H, d in ((2, 256), (2, 512), (4, 256), (8, 768)):
                 sd, m = model(1, H, d)
                 out = m.transformer.encode(ids.to(dev), want_hidden=True, want_meanpool=True)
                 ref = gpt2_ref.gpt2_forward(sd, ids, H, want_logits=False)["hidden"]

@@ -223,9 +223,10 @@ def test_attention_f16x2_golden(dev, tag):
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 1, 2, 128), (2, 129, 2, 256), (5, 277, 2, 256), (1, 1024, 2, 128), (3, 257, 6, 128),
-                                      (33, 31, 2, 256), (7, 45, 1, 256), (5, 160, 3, 128), (4, 300, 6, 128)])
+                                      (33, 31, 2, 256), (7, 45, 1, 256), (5, 160, 3, 128), (4, 300, 6, 128),
+                                      (3, 1, 2, 32), (4, 128, 8, 96), (3, 277, 8, 64), (5, 339, 4, 64), (1, 1024, 2, 96), (7, 33, 4, 32)])
 def test_attention_f16x2_key_blocked_image_equals_row_major_bit_for_bit(dev, B, T, H, hd):
-    """Round 5 (late): ``attn_h2_kernel<HD, true>`` reads K from the key-blocked image (32 token rows x head x 8-element step = one
+    """Round 5 (late): ``attn_h2_kernel<HD, true>`` / ``attn_h2ks_kernel<HD, true>`` read K from the key-blocked image (32 token rows x head x 8-element step = one
     contiguous 1 KB chunk: whole cache lines per load instruction instead of 32 partial ones) -- the same words in the same MFMA
     slots, so the output equals the row-major kernel's BIT FOR BIT: T not a multiple of 32 (sequences start mid-block and span
     block boundaries), one key, 1,024 keys, a last block that runs past the rows, three launches the same bits; and the K columns

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid (GPU box): fused vs three-launch attention on the encoder's shapes; every head_dim with an instantiation also the f16x2 kernels
 (csrc/attention_h2.hip).  ATT_H2_ONLY=1: that kernel alone (ablated builds: tools/kc_ablate.sh attention_h2.hip ATH_DBG n);
-ATT_KBLK=1: head_dim 128 / 256 with K from the key-blocked image (what the encoder runs)."""
+ATT_KBLK=1: K from the key-blocked image (what the encoder runs at d % 256 == 0)."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -18,7 +18,7 @@ for (B, T, H, hd) in SHAPES:
     h2 = ""
     if hd in (32, 64, 96, 128, 256):
         w = ops.pack_h2_words(qkv)
-        kb = ops.pack_kblk_words(w, H) if os.environ.get("ATT_KBLK") and hd in (128, 256) else None
+        kb = ops.pack_kblk_words(w, H) if os.environ.get("ATT_KBLK") else None
         run = (lambda: ops.attention_h2_kblk(w, kb, H)) if kb is not None else (lambda: ops.attention_h2(w, H))
         for _ in range(3):
             run()
