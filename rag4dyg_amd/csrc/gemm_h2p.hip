@@ -318,7 +318,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_h2p_kern
                         // registers 4a .. 4a+3 of the four lanes of a quad = rows 8a + (0..3) + 4 lh x the four words of one 16-byte
                         // slot: a 4 x 4 transpose inside the quad (two DPP exchange stages) gives every lane ONE row's slot, and the
                         // wavefront's store covers eight whole 128-byte lines (8 consecutive rows of 8 (step, half) chunks) -- as 4-byte
-                        // stores to 16 scattered pieces per instruction the c_attn launch was 80 us longer
+                        // stores to 16 scattered pieces per instruction the c_attn launch was 80 us longer.  (The same transpose for the
+                        // ROW-MAJOR stores of every epilogue -- 16 bytes per lane, four times fewer store instructions -- was measured too:
+                        // c_attn 295 -> 307 us, residual 258 -> 261: the VALU work costs more than the stores save.  Not kept.)
                         const bool o1 = li & 1, o2 = li & 2;
 #pragma unroll
                         for (int a4 = 0; a4 < 16; a4 += 4) {
