@@ -43,7 +43,7 @@ def timed(fn):
 
 def main():
     g = torch.Generator(device=dev).manual_seed(5)
-    print("| B x T x H x head_dim | inputs | f16x2: us / TF-equivalent / max-norm error | exact f32: us / TF / max-norm error |")
+    print("| B x T x H x head_dim | inputs | f16x2: us (row-major K) / us (key-blocked K, what the encoder runs) / TF-equivalent / max-norm error | exact f32: us / TF / max-norm error |")
     print("|---|---|---|---|")
     ops.set_attention_fused(True)
     worse = total = 0
@@ -62,10 +62,13 @@ def main():
             words = ops.pack_h2_words(qkv)
             nb = min(B, 4)
             ref = ref64(qkv[:nb], H)
-            out_h2, out_f32 = ops.attention_h2(words, H), ops.attention(qkv, H)
+            kblk = ops.pack_kblk_words(words, H)
+            out_h2, out_f32 = ops.attention_h2_kblk(words, kblk, H), ops.attention(qkv, H)
+            assert torch.equal(out_h2.view(torch.int32), ops.attention_h2(words, H).view(torch.int32))      # the two K layouts: same bits
             e = [float((o[:nb].double() - ref).abs().max() / ref.abs().max()) for o in (out_h2, out_f32)]
-            t = [timed(lambda: ops.attention_h2(words, H)), timed(lambda: ops.attention(qkv, H))] if kind == "N(0,1)" else [None, None]
-            cell = lambda i: (f"{t[i]:.1f} / {flop / t[i] / 1e6:.1f} / " if t[i] else "- / - / ") + f"{e[i]:.2e}"
+            t = [timed(lambda: ops.attention_h2_kblk(words, kblk, H)), timed(lambda: ops.attention(qkv, H))] if kind == "N(0,1)" else [None, None]
+            t_rm = timed(lambda: ops.attention_h2(words, H)) if kind == "N(0,1)" else None
+            cell = lambda i: ((f"{t_rm:.1f} / " if i == 0 else "") + f"{t[i]:.1f} / {flop / t[i] / 1e6:.1f} / " if t[i] else ("- / " if i == 0 else "") + "- / - / ") + f"{e[i]:.2e}"
             print(f"| {B} x {T} x {H} x {hd} | {kind} | {cell(0)} | {cell(1)} |", flush=True)
             worse += e[0] > 2.0 * e[1] + 2.5e-7
             total += 1
